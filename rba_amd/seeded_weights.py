@@ -1,0 +1,111 @@
+"""Deterministic, key-addressed weight fill.
+
+There are no released weights in the container (the reference ships only
+``ckpts/*/config.yaml``), so the golden fixtures, the
+oracle, the parity tests and ``bench.py`` all fill a state dict with the SAME
+recipe: every tensor is drawn from its own ``torch.Generator`` seeded by
+``crc32(key) ^ seed``, so the value of a tensor depends only on its key name,
+its shape and the seed -- not on iteration order, device or module layout.
+
+The scale per tensor class keeps activations O(1) through the 24 Swin blocks:
+
+* norm weights (LayerNorm / GroupNorm ``weight``)      1 + 0.1 n
+* 1-d biases                                           0.05 n
+* ``class_embed.bias``         0.05 n, void column + 5 (most queries predict "no object",
+  as in a trained model, so RbA stays in the un-saturated range)
+* ``relative_position_bias_table``                     0.5 n
+* embeddings (``query_feat``, ``query_embed``, ``level_embed``)   n
+* ``sampling_offsets.bias``    Deformable-DETR ring init + 0.1 n
+  (the ring follows reference ``ops/modules/ms_deform_attn.py:66-74``)
+* every other tensor with dim >= 2                     fan_in**-0.5 n
+* integer buffers (``relative_position_index``) are left untouched.
+"""
+import math
+import zlib
+
+import torch
+
+__all__ = ["seeded_tensor", "fill_state_dict_", "seeded_state_dict", "deform_ring_bias"]
+
+
+def deform_ring_bias(n_heads: int, n_levels: int, n_points: int) -> torch.Tensor:
+    """Sampling-offset bias ring of Deformable-DETR: head m points at angle
+    2*pi*m/n_heads (scaled to the unit square), point p at radius p+1."""
+    thetas = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid = grid / grid.abs().max(-1, keepdim=True)[0]
+    grid = grid.view(n_heads, 1, 1, 2).repeat(1, n_levels, n_points, 1)
+    for p in range(n_points):
+        grid[:, :, p, :] *= p + 1
+    return grid.reshape(-1)
+
+
+def _is_norm_weight(key: str, t: torch.Tensor) -> bool:
+    if t.dim() != 1 or not key.endswith(".weight"):
+        return False
+    stem = key[: -len(".weight")]
+    last = stem.split(".")[-1]
+    if "norm" in last:
+        return True
+    # GroupNorm inside ``input_proj.<l>.1`` (nn.Sequential(conv, GroupNorm))
+    parts = stem.split(".")
+    return len(parts) >= 3 and parts[-3] == "input_proj" and parts[-1] == "1"
+
+
+def seeded_tensor(key: str, like: torch.Tensor, seed: int = 0, meta: dict = None) -> torch.Tensor:
+    """Value for state-dict entry ``key`` (shape/dtype of ``like``)."""
+    if not like.dtype.is_floating_point:
+        return like.clone()
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    n = torch.randn(tuple(like.shape), generator=g, dtype=torch.float32)
+    if key.endswith("relative_position_bias_table"):
+        out = 0.5 * n
+    elif key.endswith("sampling_offsets.bias"):
+        meta = meta or {}
+        n_heads = meta.get("n_heads", 8)
+        n_points = meta.get("n_points", 4)
+        n_levels = like.numel() // (n_heads * n_points * 2)
+        out = deform_ring_bias(n_heads, n_levels, n_points) + 0.1 * n
+    elif _is_norm_weight(key, like):
+        out = 1.0 + 0.1 * n
+    elif key.endswith("class_embed.bias"):
+        # trained Mask2Former sends most queries to the void ("no object") column; without this the
+        # class mass of 100 random queries saturates tanh(sem_seg) and RbA sits at -K everywhere.
+        out = 0.05 * n
+        out[-1] += 5.0
+    elif like.dim() == 1:
+        out = 0.05 * n
+    elif key.endswith(("query_feat.weight", "query_embed.weight", "level_embed.weight", "level_embed")):
+        out = n
+    else:
+        fan_in = 1
+        for s in like.shape[1:]:
+            fan_in *= int(s)
+        out = n * (float(fan_in) ** -0.5)
+    return out.to(like.dtype)
+
+
+def seeded_state_dict(shapes: dict, seed: int = 0, meta: dict = None) -> dict:
+    """``shapes``: {key: (shape tuple, torch dtype)} -> {key: tensor}. Integer
+    entries are skipped (the module recomputes them)."""
+    out = {}
+    for key in sorted(shapes):
+        shape, dtype = shapes[key]
+        if not dtype.is_floating_point:
+            continue
+        out[key] = seeded_tensor(key, torch.empty(shape, dtype=dtype), seed, meta)
+    return out
+
+
+@torch.no_grad()
+def fill_state_dict_(module: torch.nn.Module, seed: int = 0, meta: dict = None, prefix: str = "") -> None:
+    """Overwrite every floating-point entry of ``module.state_dict()`` in place.
+    ``prefix`` is prepended to the key before hashing so that a sub-module
+    filled on its own gets the values it would get inside the full model."""
+    sd = module.state_dict()
+    for key in sorted(sd):
+        t = sd[key]
+        if not t.dtype.is_floating_point:
+            continue
+        t.copy_(seeded_tensor(prefix + key, t, seed, meta))

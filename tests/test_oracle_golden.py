@@ -1,0 +1,122 @@
+"""CPU: the oracle (oracle/) against the fixtures the reference's own modules produced
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_metrics, ref_model, ref_ops
+from rba_amd import arch as A
+
+T = torch.from_numpy
+
+
+def close(a, b, atol, rtol=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max()
+    assert err <= atol + rtol * np.abs(b).max(), f"max abs err {err:.3e} > {atol:.1e}"
+
+
+def test_k1_rba_reduce(golden):
+    g = golden("g1_rba_reduce")
+    sem, rba, am = ref_ops.rba_reduce(T(g["mask_pred"]), T(g["mask_cls"]))
+    close(sem, g["sem_seg"], 1e-6)
+    close(rba, g["rba"], 1e-6)
+    assert np.array_equal(am.numpy(), g["argmax"])
+    # ordered-accumulation variant (what the HIP kernel does) differs by re-association only
+    sem2, rba2, am2 = ref_ops.rba_reduce_ordered(T(g["mask_pred"]), ref_ops.class_probs(T(g["mask_cls"])))
+    close(sem2, g["sem_seg"], 5e-6)
+    close(rba2, g["rba"], 5e-6)
+    gap = np.sort(g["sem_seg"], axis=0)
+    flips = am2.numpy() != g["argmax"]
+    assert not (flips & ((gap[-1] - gap[-2]) > 1e-5)).any()
+    # x4 bilinear upsample in front (maskformer_model.py:294-299)
+    up = ref_ops.upsample_bilinear(T(g["low"])[None], (16, 32))[0]
+    close(up, g["up"], 1e-6)
+    close(ref_ops.rba_reduce(up, T(g["mask_cls"]))[1], g["rba_up"], 1e-6)
+
+
+def test_k2_ms_deform_attn_reference_test_set(golden):
+    """shape / seed set of the reference's own ops/test.py:24-39."""
+    g = golden("g2_ms_deform_attn")
+    shapes = T(g["a_shapes"])
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    o64 = ref_ops.ms_deform_attn(T(g["a64_value"]).double(), shapes, T(g["a64_loc"]).double(), T(g["a64_w"]).double())
+    close(o64, g["a64_out"], 1e-12)
+    o32 = ref_ops.ms_deform_attn(T(g["a32_value"]), shapes, T(g["a32_loc"]), T(g["a32_w"]))
+    close(o32, g["a32_out"], 1e-8)
+    # scalar restatement of the CUDA kernel arithmetic agrees with the grid_sample formulation
+    loops = ref_ops.ms_deform_attn_loops(T(g["a64_value"]).double(), shapes, lsi, T(g["a64_loc"]).double(),
+                                         T(g["a64_w"]).double())
+    close(loops, g["a64_out"], 1e-12)
+
+
+def test_k2_ms_deform_attn_3level(golden):
+    g = golden("g2_ms_deform_attn")
+    shapes = T(g["b_shapes"])
+    o = ref_ops.ms_deform_attn(T(g["b_value"]), shapes, T(g["b_loc"]), T(g["b_w"]))
+    close(o, g["b_out"], 1e-6)
+    close(o, g["b_out64"], 2e-5)
+    # loop restatement on a slice of queries (python loops are slow)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    sl = slice(0, 12)
+    loops = ref_ops.ms_deform_attn_loops(T(g["b_value"]).double(), shapes, lsi, T(g["b_loc"][:, sl]).double(),
+                                         T(g["b_w"][:, sl]).double())
+    close(loops, g["b_out64"][:, sl], 1e-5)
+
+
+def test_position_embedding(golden):
+    g = golden("g3_pos_embed")
+    close(ref_ops.position_embedding_sine(23, 40, 128), g["pe128_23x40"], 1e-6)
+    close(ref_ops.position_embedding_sine(2, 3, 32), g["pe32_2x3"], 1e-6)
+
+
+def test_swin_parts(golden):
+    g = golden("g3_swin_parts")
+    sd = {k[len("wa_sd."):]: T(g[k]) for k in g.files if k.startswith("wa_sd.")}
+    args = (sd["qkv.weight"], sd["qkv.bias"], sd["proj.weight"], sd["proj.bias"],
+            sd["relative_position_bias_table"], 6, 2)
+    assert np.array_equal(ref_ops.relative_position_index(6).numpy(), g["wa_sd.relative_position_index"])
+    close(ref_ops.window_attention(T(g["wa_x"]), *args), g["wa_out"], 2e-6)
+    close(ref_ops.window_attention(T(g["wa_x"]), *args, mask=T(g["wa_mask"])), g["wa_out_masked"], 2e-6)
+    # BasicLayer on a 13 x 20 grid: window pad, shifted block, odd-H PatchMerging
+    sd = {"L." + k[len("bl_sd."):]: T(g[k]) for k in g.files if k.startswith("bl_sd.")}
+    H, W, Wh, Ww = g["bl_hw"]
+    x = T(g["bl_x"])
+    mask = ref_ops.shift_attn_mask(H, W, 6, 3)
+    for b in range(2):
+        x = ref_model.swin_block(x, H, W, sd, f"L.blocks.{b}", 6, 0 if b == 0 else 3, 2, mask)
+    close(x, g["bl_out"], 5e-6)
+    close(ref_model.patch_merging(x, H, W, sd, "L.downsample"), g["bl_down"], 5e-6)
+    assert ((H + 1) // 2, (W + 1) // 2) == (Wh, Ww)
+
+
+@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90"])
+def test_end_to_end_tiny(golden, name):
+    g = golden(name)
+    a = A.complete(A.ARCHS[str(g["arch"])])
+    shapes = A.state_dict_shapes(a)
+    # the checkpoint contract: same keys, same shapes as the reference module tree
+    assert sorted(shapes) == list(g["sd_keys"])
+    assert [",".join(map(str, shapes[k][0])) for k in sorted(shapes)] == list(g["sd_shapes"])
+    sd = A.seeded_weights(a, int(g["seed"]))
+    taps = {}
+    o = ref_model.forward(T(g["image"]), sd, a, taps)
+    for k in ("res2", "res3", "res4", "res5"):
+        close(taps["feats"][k][0], g["feat_" + k], 2e-5)
+    close(taps["mask_features"][0], g["mask_features"], 2e-5)
+    for i, v in enumerate(taps["multi_scale"]):
+        close(v[0], g[f"multi_scale_{i}"], 2e-5)
+    close(o["pred_logits"], g["pred_logits"], 2e-5)
+    close(o["pred_masks"], g["pred_masks"], 1e-4)
+    close(o["sem_seg"], g["sem_seg"], 1e-5)
+    close(o["rba"], g["rba"], 1e-5)
+    gap = np.sort(g["sem_seg"], axis=0)
+    flips = o["argmax"].numpy() != g["argmax"]
+    assert not (flips & ((gap[-1] - gap[-2]) > 1e-5)).any()
+
+
+@pytest.mark.parametrize("case", "abcd")
+def test_metrics(golden, case):
+    g = golden("g6_metrics")
+    r = ref_metrics.evaluate_ood(g[case + "_score"], g[case + "_gt"])
+    np.testing.assert_allclose([r["auroc"], r["aupr"], r["fpr95"]], g[case + "_metrics"], rtol=0, atol=1e-12)
