@@ -1,0 +1,90 @@
+/*
+ * rba_hip.h -- C ABI of librba_hip.so, the MI355X (gfx950) kernels on RbA's inference hot path.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, no global state,
+ *     re-entrant; tensors are dense row-major ("contiguous") in the index order written next to them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
+ *   - return value is a hipError_t as int (0 = hipSuccess); argument errors return hipErrorInvalidValue (1);
+ *   - fp32 everywhere (the reference op refuses half: pixel_decoder/msdeformattn.py:323,329).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo NazirNayal8/RbA):
+ *   rba_ms_deform_attn_fwd_f32  <- MultiScaleDeformableAttention.ms_deform_attn_forward
+ *                                  (pixel_decoder/ops/src/vision.cpp:19, ops/src/ms_deform_attn.h:25-44,
+ *                                   ops/src/cuda/ms_deform_attn_cuda.cu:25-85, ms_deform_im2col_cuda.cuh:242-304,928-959)
+ *   rba_reduce_f32              <- MaskFormer.semantic_inference (mask2former/maskformer_model.py:381-386)
+ *                                  + get_RbA (evaluate_ood.py:143-150) + argmax (support.py:385-388)
+ *   rba_reduce_up4_f32          <- the same preceded by the x4 mask upsample (maskformer_model.py:294-299)
+ *                                  and followed by the sem_seg_postprocess crop (maskformer_model.py:330-332)
+ *   rba_resample_bilinear_f32   <- F.interpolate(mode="bilinear", align_corners=False) call sites
+ *                                  (maskformer_model.py:294-299, msdeformattn.py:358, mask2former_transformer_decoder.py:483)
+ *   rba_masked_xattn_f32        <- nn.MultiheadAttention core with bool attn_mask
+ *                                  (mask2former_transformer_decoder.py:106-118, 433, 483-487)
+ *   rba_mask_logits_f32         <- torch.einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479)
+ *   rba_swin_window_attn_f32    <- WindowAttention core + window_partition/reverse + roll + pad
+ *                                  (backbone/swin.py:44-71, 131-171, 251-284)
+ */
+#ifndef RBA_HIP_H
+#define RBA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library/ABI version (major*100 + minor). */
+int rba_hip_version(void);
+
+/* K1.  mask [Q,HW] full-resolution mask logits; cls_prob [Q,K] = softmax(class logits)[:, :-1].
+ *   sem[k,p]  = sum_q cls_prob[q,k] * sigmoid(mask[q,p])      (ascending-q fp32 FMA order)
+ *   rba[p]    = - sum_k tanh(sem[k,p])
+ *   argmax[p] = first k maximising sem[k,p]
+ * rba [HW] required; sem_seg [K,HW] and argmax [HW] (int32) optional (NULL = not written).  1 <= K <= 160. */
+int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
+                   int Q, int K, int64_t HW, void* stream);
+
+/* K1 fused with the x4 bilinear upsample (align_corners=False) in front and the crop behind it.
+ * mask_lowres [Q,h,w]; the virtual full-resolution map is [Q,4h,4w]; outputs cover rows < crop_h and
+ * columns < crop_w of it: rba [crop_h,crop_w], sem_seg [K,crop_h,crop_w] or NULL, argmax or NULL. */
+int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_prob, float* rba, float* sem_seg,
+                       int32_t* argmax, int Q, int K, int h, int w, int crop_h, int crop_w, void* stream);
+
+/* Bilinear resample, align_corners=False, no antialias (ATen upsample_bilinear2d semantics):
+ * in [C,h,w] -> out [C,H,W];  if `add` != NULL (same shape as out): out = resample(in) + add. */
+int rba_resample_bilinear_f32(const float* in, const float* add, float* out, int C, int h, int w, int H, int W,
+                              void* stream);
+
+/* K2.  Multi-scale deformable attention forward.
+ * value [N,S,M,D]; spatial_shapes [L,2] int64 (H_l,W_l); level_start_index [L] int64;
+ * sampling_loc [N,Lq,M,L,P,2] (x,y) normalised to [0,1]; attn_weight [N,Lq,M,L,P]; out [N,Lq,M*D].
+ * Sample position h = y*H_l - 0.5, w = x*W_l - 0.5; bilinear, taps outside the map contribute 0. */
+int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* sampling_loc, const float* attn_weight, float* out,
+                               int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+
+/* K3.  Masked multi-head cross attention core (projections are done by the caller):
+ * q [B,Q,nH,hd] (already includes the in_proj bias, NOT yet scaled), k,v [B,S,nH,hd];
+ * mask_logits [B,Q,S] or NULL: key s is blocked for query q (all heads) iff sigmoid(mask_logits) < 0.5,
+ * except that a row with every key blocked attends to all keys.  out [B,Q,nH*hd].
+ * scale = hd^-0.5 applied to q.  hd must be 32. */
+int rba_masked_xattn_f32(const float* q, const float* k, const float* v, const float* mask_logits, float* out,
+                         int B, int Q, int S, int nH, int hd, void* stream);
+
+/* K4.  Mask logits: out[b,q,n] = sum_c embed[b,q,c] * feat[b,c,n]   (embed [B,Q,C], feat [B,C,N], out [B,Q,N]). */
+int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,
+                        void* stream);
+
+/* K5.  Swin (shifted-)window attention core over a token map, fusing zero-pad to a multiple of the window,
+ * cyclic shift, window partition, q*scale @ k^T + relative-position bias (+ shift mask), softmax, @ v,
+ * window reverse, un-shift and crop.
+ * qkv [B,H*W,3,nH,hd] = Linear(norm1(x)) of the UNPADDED tokens; padded tokens take qkv_bias [3*nH*hd]
+ * (= Linear(0)).  bias [nH,ws*ws,ws*ws] gathered relative-position bias.  shift = 0 or ws/2.
+ * out [B,H*W,nH*hd] (attention output before the proj Linear).  hd must be 32; ws*ws <= 256. */
+int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias, float* out,
+                             int B, int H, int W, int nH, int hd, int ws, int shift, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBA_HIP_H */

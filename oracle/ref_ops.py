@@ -191,3 +191,24 @@ def position_embedding_sine(h, w, num_pos_feats, temperature=10000.0):
     pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
     pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
     return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)[0]
+
+
+def attention_core(q, k, v, blocked=None):
+    """softmax((q * hd^-0.5) k^T, blocked -> -inf) v for q [B,Q,nH,hd], k/v [B,S,nH,hd], blocked bool [B,Q,S]
+    (True = not allowed to attend) -> [B,Q,nH*hd].  The arithmetic inside nn.MultiheadAttention
+    (mask2former_transformer_decoder.py:106-118) between the in- and out-projections."""
+    B, Q, nH, hd = q.shape
+    qq = (q * hd ** -0.5).permute(0, 2, 1, 3)
+    att = qq @ k.permute(0, 2, 3, 1)
+    if blocked is not None:
+        att = att.masked_fill(blocked[:, None], float("-inf"))
+    att = F.softmax(att, dim=-1)
+    return (att @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, Q, nH * hd)
+
+
+def attn_mask_from_logits(mask_logits):
+    """blocked = sigmoid(x) < 0.5, rows with every key blocked are un-blocked entirely
+    (mask2former_transformer_decoder.py:486 and :433)."""
+    blocked = mask_logits.sigmoid() < 0.5
+    blocked[torch.where(blocked.sum(-1) == blocked.shape[-1])] = False
+    return blocked

@@ -1,0 +1,69 @@
+"""ctypes binding of librba_hip.so (the C ABI declared in include/rba_hip.h).
+
+The product has no CPU path: if the library is missing, or a wrapper is handed a tensor that is not a
+contiguous fp32 tensor on a HIP device, it raises -- it never falls back to PyTorch or to the oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librba_hip.so")
+
+_c_f32p = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+
+# name -> argtypes ; every function returns int (hipError_t)
+SIGNATURES = {
+    "rba_hip_version": [],
+    "rba_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp],
+    "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_mask_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],
+    "rba_swin_window_attn_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+}
+
+_lib = None
+
+
+class RbaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises RbaHipError when the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RbaHipError(
+            f"{LIB_PATH} not found: build it with `python -m rba_amd.csrc.build` (hipcc --offload-arch=gfx950). "
+            "rba_amd has no CPU or PyTorch fallback for its HIP kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RbaHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def hip_error_string(code: int) -> str:
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipGetErrorString.restype = ctypes.c_char_p
+        hip.hipGetErrorString.argtypes = [ctypes.c_int]
+        return hip.hipGetErrorString(code).decode()
+    except Exception:
+        return "hipError"
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RbaHipError(f"{what} failed: hipError {code} ({hip_error_string(code)})")

@@ -1,0 +1,58 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of librba_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RBA_WAVE 64
+
+// native clang vectors (the nontemporal builtins reject HIP's float4 class)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define RBA_CHECK_ARG(cond)                      \
+  do {                                           \
+    if (!(cond)) return (int)hipErrorInvalidValue; \
+  } while (0)
+
+static inline int rba_launch_status() { return (int)hipGetLastError(); }
+
+// 1 / (1 + e^-x): v_exp_f32 + v_rcp_f32, abs error <~ 1e-7 (ample for the 1e-4 score tolerance).
+__device__ __forceinline__ float rba_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+// tanh(x) = sign(x) * (1 - 2 / (e^{2|x|} + 1)); e^{2|x|} -> inf gives exactly 1.
+__device__ __forceinline__ float rba_tanh(float x) {
+  float ax = fabsf(x);
+  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * ax) + 1.0f);
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, RBA_WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RBA_WAVE);
+  return v;
+}
+
+// Source coordinate of ATen's upsample_bilinear2d (align_corners=False): scale*(dst+0.5)-0.5 clamped at 0.
+struct BilinearTap {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ BilinearTap bilinear_tap(int dst, float scale, int in_size) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  int i0 = (int)src;  // src >= 0: trunc == floor
+  i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+  BilinearTap t;
+  t.i0 = i0;
+  t.i1 = i0 < in_size - 1 ? i0 + 1 : i0;
+  t.l1 = src - (float)i0;
+  t.l0 = 1.0f - t.l1;
+  return t;
+}

@@ -1,0 +1,112 @@
+"""Multi-GPU evaluation: images shard across ranks (one process per GPU, no communication in the forward), and the
+OoD metrics -- which rank ALL pixels of ALL images together (support.py:275-290), so they are not averages of
+per-shard values -- are pooled with one RCCL all-gather of (score, label) pairs over xGMI.  New functionality
+w.r.t. the reference, whose evaluation is single process.  Works on gloo (CPU tests) and nccl=RCCL.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int):
+    """Image i -> rank i mod world (round-robin keeps shards balanced for any n)."""
+    return list(range(rank, n_items, world))
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+@torch.no_grad()
+def all_gather_variable(t: torch.Tensor) -> torch.Tensor:
+    """Concatenate 1-d tensors of different lengths from all ranks (rank order): all_gather the sizes, pad to the
+    max, one all_gather_into_tensor, trim."""
+    world = _world()
+    if world == 1:
+        return t
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    buf = t.new_zeros(mx)
+    buf[: t.numel()] = t
+    out = t.new_empty(world * mx)
+    dist.all_gather_into_tensor(out, buf)
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)])
+
+
+@torch.no_grad()
+def pooled_ood_metrics(scores: torch.Tensor, labels: torch.Tensor) -> dict:
+    """Exact metrics over the union of every rank's labelled pixels.  scores fp32 [n_r], labels bool/uint8 [n_r]
+    (already restricted to labels in {0,1}).  Every rank returns the same dict."""
+    from .metrics import ood_metrics
+
+    s = all_gather_variable(scores.reshape(-1).float().contiguous())
+    l = all_gather_variable(labels.reshape(-1).to(torch.uint8).contiguous())
+    return ood_metrics(s, l)
+
+
+@torch.no_grad()
+def histogram_ood_metrics(scores: torch.Tensor, labels: torch.Tensor, bits: int = 16) -> dict:
+    """Approximate pooled metrics from 2 x 2^bits int64 histograms over the order-preserving integer key of the fp32
+    score (top `bits` bits): one 1 MB all_reduce instead of gathering every pixel.  Scores sharing a bin are treated
+    as tied, so the result is the exact metric of the quantised scores (error <~ 1e-4 for RbA-range scores)."""
+    from .metrics import ood_metrics
+
+    s = scores.reshape(-1).float().contiguous()
+    u = s.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    key = torch.where(u >= 0x80000000, 0xFFFFFFFF - u, u + 0x80000000) >> (32 - bits)     # monotone in s
+    nb = 1 << bits
+    pos = labels.reshape(-1).to(torch.bool)
+    hist = torch.stack([torch.bincount(key[~pos], minlength=nb), torch.bincount(key[pos], minlength=nb)])
+    if _world() > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    nz = torch.nonzero(hist.sum(0)).reshape(-1)
+    cnt = hist[:, nz]
+    # expand to weighted curve: reuse ood_metrics by emitting each occupied bin once per class with multiplicity
+    # through cumulative counts (descending key)
+    neg, posc = cnt[0].flip(0), cnt[1].flip(0)
+    tps, fps = torch.cumsum(posc, 0), torch.cumsum(neg, 0)
+    return _metrics_from_curve(fps, tps)
+
+
+def _metrics_from_curve(fps, tps):
+    P, Nn = tps[-1].double(), fps[-1].double()
+    tpd, fpd = tps.double(), fps.double()
+    precision = tpd / (tpd + fpd)
+    recall = tpd / P
+    prev = torch.cat([recall.new_zeros(1), recall[:-1]])
+    aupr = torch.sum((recall - prev) * precision)
+    if fps.numel() > 2:
+        d2f = fps[2:] - 2 * fps[1:-1] + fps[:-2]
+        d2t = tps[2:] - 2 * tps[1:-1] + tps[:-2]
+        one = torch.ones(1, dtype=torch.bool, device=fps.device)
+        keep = torch.cat([one, (d2f != 0) | (d2t != 0), one])
+        fps, tps = fps[keep], tps[keep]
+    fpr = torch.cat([fps.new_zeros(1), fps]).double() / Nn
+    tpr = torch.cat([tps.new_zeros(1), tps]).double() / P
+    auroc = torch.sum((fpr[1:] - fpr[:-1]) * (tpr[1:] + tpr[:-1]) * 0.5)
+    above = torch.nonzero(tpr > 0.95).reshape(-1)
+    fpr95 = fpr[above[0]] if above.numel() else fpr.new_zeros(())
+    return {"auroc": float(auroc), "aupr": float(aupr), "fpr95": float(fpr95)}

@@ -1,0 +1,103 @@
+"""``MaskFormer`` meta-architecture, inference branch only (reference: mask2former/maskformer_model.py:23-386).
+
+Drop-in surface: ``model([{"image": uint8/float [3,H,W] RGB 0..255}]) -> [{"sem_seg": [K,H,W] fp32}]`` on the model's
+device, identical to the reference, so the unmodified ``get_RbA`` / ``get_logits`` of evaluate_ood.py work on it.
+In addition each result dict carries ``"rba"`` ([H,W], the RbA score of evaluate_ood.py:150 produced by the same
+fused kernel) and, on request, ``"argmax"``; ``model.rba_scores(...)`` skips materialising ``sem_seg`` altogether.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .arch import complete
+from .modeling.backbone import swin as _swin  # noqa: F401  (registers D2SwinTransformer)
+from .modeling.meta_arch import mask_former_head as _head  # noqa: F401
+from .registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY
+
+
+@META_ARCH_REGISTRY.register()
+class MaskFormer(nn.Module):
+    def __init__(self, arch, backbone_name="D2SwinTransformer", head_name="MaskFormerHead"):
+        super().__init__()
+        a = complete(arch)
+        self.arch = a
+        self.backbone = BACKBONE_REGISTRY.get(backbone_name)(a)
+        self.sem_seg_head = SEM_SEG_HEADS_REGISTRY.get(head_name)(a)
+        self.num_queries = a["num_queries"]
+        self.size_divisibility = a["size_divisibility"] if a["size_divisibility"] > 0 else self.backbone.size_divisibility
+        self.register_buffer("pixel_mean", torch.tensor(a["pixel_mean"], dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(a["pixel_std"], dtype=torch.float32).view(-1, 1, 1), False)
+        self.fused_upsample = True      # K1 reads the low-res logits and up-samples on the fly (rba_reduce_up4)
+        self.eval()
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ------------------------------------------------------------------ pre-processing (:255-257)
+    def preprocess(self, batched_inputs):
+        images = [(x["image"].to(self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        sizes = [tuple(int(v) for v in im.shape[-2:]) for im in images]
+        d = self.size_divisibility
+        H = (max(s[0] for s in sizes) + d - 1) // d * d
+        W = (max(s[1] for s in sizes) + d - 1) // d * d
+        batch = images[0].new_zeros((len(images), images[0].shape[0], H, W))
+        for i, im in enumerate(images):
+            batch[i, :, : sizes[i][0], : sizes[i][1]] = im       # ImageList.from_tensors: zero pad bottom/right
+        return batch, sizes
+
+    # ------------------------------------------------------------------ network
+    @torch.no_grad()
+    def predict(self, batched_inputs):
+        """-> (pred_logits [B,Q,K+1], pred_masks [B,Q,H/4,W/4], image_sizes, padded (H,W))."""
+        batch, sizes = self.preprocess(batched_inputs)
+        features = self.backbone(batch)
+        outputs = self.sem_seg_head(features)
+        return outputs["pred_logits"], outputs["pred_masks"], sizes, tuple(batch.shape[-2:])
+
+    def _post(self, mask_cls, mask_pred, image_size, padded, want_sem_seg, want_argmax):
+        """Up-sample (:294-299), semantic inference (:381-386), crop (:330-332), RbA (evaluate_ood.py:150)."""
+        prob = F.softmax(mask_cls, dim=-1)[..., :-1].contiguous()
+        H, W = padded
+        exact4 = mask_pred.shape[-2] * 4 == H and mask_pred.shape[-1] * 4 == W
+        if self.fused_upsample and exact4 and prob.shape[1] <= 32:
+            return ops.rba_reduce_up4(mask_pred.contiguous(), prob, image_size, want_sem_seg, want_argmax)
+        up = ops.resample_bilinear(mask_pred.contiguous(), (H, W))
+        rba, sem, arg = ops.rba_reduce(up, prob, want_sem_seg, want_argmax)
+        h, w = image_size
+        if (h, w) != (H, W):
+            rba = rba[:h, :w].contiguous()
+            sem = sem[:, :h, :w].contiguous() if sem is not None else None
+            arg = arg[:h, :w].contiguous() if arg is not None else None
+        return rba, sem, arg
+
+    @torch.no_grad()
+    def forward(self, batched_inputs, include_void=False, return_separately=False, return_aux=False,
+                return_ood_pred=False, return_argmax=False, **kwargs):
+        if include_void or return_separately or return_aux or return_ood_pred or kwargs:
+            raise NotImplementedError("only the default semantic inference path of MaskFormer.forward is provided")
+        mask_cls, mask_pred, sizes, padded = self.predict(batched_inputs)
+        results = []
+        for i, inp in enumerate(batched_inputs):
+            rba, sem, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, True, return_argmax)
+            height, width = inp.get("height", sizes[i][0]), inp.get("width", sizes[i][1])
+            if (height, width) != sizes[i]:       # sem_seg_postprocess resize to the requested output resolution
+                sem = ops.resample_bilinear(sem, (height, width))
+                rba = -sem.tanh().sum(dim=0)
+                arg = sem.argmax(0).to(torch.int32) if return_argmax else None
+            r = {"sem_seg": sem, "rba": rba}
+            if return_argmax:
+                r["argmax"] = arg
+            results.append(r)
+        return results
+
+    @torch.no_grad()
+    def rba_scores(self, batched_inputs, return_argmax=False):
+        """Fast path: RbA maps (and optional int32 argmax maps) without materialising sem_seg."""
+        mask_cls, mask_pred, sizes, padded = self.predict(batched_inputs)
+        out = []
+        for i in range(len(batched_inputs)):
+            rba, _, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, False, return_argmax)
+            out.append((rba, arg) if return_argmax else rba)
+        return out

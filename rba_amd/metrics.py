@@ -1,0 +1,67 @@
+"""AUROC / AuPRC / FPR@95 over pooled pixels, computed with torch on whatever device the scores live on (the GPU
+in the product) and matching what the reference gets from scikit-learn (support.py:247-268):
+
+* AuPRC  = average_precision_score = sum_n (R_n - R_{n-1}) P_n over distinct thresholds, descending score;
+* AUROC  = auc(roc_curve(...)) -- trapezoid over the ROC polyline;
+* FPR95  = fpr of the first ROC point with tpr > 0.95 (strict) on the curve roc_curve returns with its default
+  ``drop_intermediate=True`` (collinear interior points removed: keep i iff the second difference of fps or tps
+  around i is non-zero, plus both end points, plus the prepended (0, 0)).
+
+One global descending sort (rocPRIM radix sort on the GPU), integer cumsums, float64 ratios.
+"""
+import torch
+
+
+@torch.no_grad()
+def binary_clf_curve(scores: torch.Tensor, labels: torch.Tensor):
+    """fps, tps (int64) at each distinct threshold, descending score order."""
+    scores = scores.reshape(-1)
+    labels = labels.reshape(-1)
+    order = torch.argsort(scores, descending=True, stable=True)
+    s = scores[order]
+    y = labels[order].to(torch.int64)
+    n = s.numel()
+    distinct = torch.nonzero(s[1:] != s[:-1]).reshape(-1)
+    idx = torch.cat([distinct, torch.tensor([n - 1], device=s.device, dtype=distinct.dtype)])
+    tps = torch.cumsum(y, 0)[idx]
+    fps = 1 + idx - tps
+    return fps, tps
+
+
+@torch.no_grad()
+def ood_metrics(scores: torch.Tensor, labels: torch.Tensor) -> dict:
+    """scores: float tensor, labels: {0,1} tensor of the same number of elements (1 = OoD = positive)."""
+    if scores.numel() != labels.numel():
+        raise ValueError("scores and labels differ in size")
+    if scores.numel() == 0:
+        raise ValueError("no labelled pixels")
+    fps, tps = binary_clf_curve(scores, labels)
+    P, Nn = tps[-1].double(), fps[-1].double()
+    # ---- average precision
+    tpd, fpd = tps.double(), fps.double()
+    precision = tpd / (tpd + fpd)
+    recall = tpd / P
+    prev = torch.cat([recall.new_zeros(1), recall[:-1]])
+    aupr = torch.sum((recall - prev) * precision)
+    # ---- ROC with drop_intermediate
+    if fps.numel() > 2:
+        d2f = fps[2:] - 2 * fps[1:-1] + fps[:-2]
+        d2t = tps[2:] - 2 * tps[1:-1] + tps[:-2]
+        keep = torch.cat([torch.ones(1, dtype=torch.bool, device=fps.device), (d2f != 0) | (d2t != 0),
+                          torch.ones(1, dtype=torch.bool, device=fps.device)])
+        fps, tps = fps[keep], tps[keep]
+    fpr = torch.cat([fps.new_zeros(1), fps]).double() / Nn
+    tpr = torch.cat([tps.new_zeros(1), tps]).double() / P
+    auroc = torch.sum((fpr[1:] - fpr[:-1]) * (tpr[1:] + tpr[:-1]) * 0.5)
+    above = torch.nonzero(tpr > 0.95).reshape(-1)
+    fpr95 = fpr[above[0]] if above.numel() else fpr.new_zeros(())
+    return {"auroc": float(auroc), "aupr": float(aupr), "fpr95": float(fpr95)}
+
+
+@torch.no_grad()
+def select_labelled(anomaly_score: torch.Tensor, ood_gts: torch.Tensor):
+    """Keep pixels labelled 0 (inlier) or 1 (OoD); everything else (255) is ignored (support.py:275-285)."""
+    s = anomaly_score.reshape(-1)
+    g = ood_gts.reshape(-1)
+    m = (g == 0) | (g == 1)
+    return s[m], (g[m] == 1)

@@ -1,0 +1,156 @@
+"""Swin Transformer backbone, inference only, for MI355X.
+
+Same parameter tree (hence state-dict keys) as the reference's ``D2SwinTransformer``
+(mask2former/modeling/backbone/swin.py:498-770) but a different dataflow: the token map stays [B, H*W, C]
+for the whole stage; the zero-pad to a multiple of the window, the cyclic shift, window partition / reverse,
+relative-position bias, shift mask, softmax and P@V of a block are ONE HIP kernel (``ops.swin_window_attn``,
+K5) reading the un-padded qkv tensor; dense projections are MFMA GEMMs through rocBLAS/hipBLASLt.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...registry import BACKBONE_REGISTRY
+
+
+def relative_position_index(ws: int) -> torch.Tensor:
+    """[ws*ws, ws*ws] int64 index into the (2ws-1)^2 bias table (swin.py:108-121)."""
+    ar = torch.arange(ws)
+    gy, gx = torch.meshgrid(ar, ar, indexing="ij")
+    gy, gx = gy.reshape(-1), gx.reshape(-1)
+    dy = gy[:, None] - gy[None, :] + (ws - 1)
+    dx = gx[:, None] - gx[None, :] + (ws - 1)
+    return dy * (2 * ws - 1) + dx
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, num_heads):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * window_size - 1) ** 2, num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(window_size))
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self._bias_cache = None
+
+    def gathered_bias(self):
+        """[nH, N, N] relative-position bias (swin.py:148-155), gathered once per weight load."""
+        t = self.relative_position_bias_table
+        key = (t.data_ptr(), t._version, t.device)
+        if self._bias_cache is None or self._bias_cache[0] != key:
+            N = self.window_size ** 2
+            b = t[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
+            self._bias_cache = (key, b)
+        return self._bias_cache[1]
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class SwinTransformerBlock(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio):
+        super().__init__()
+        self.window_size, self.shift_size, self.num_heads = window_size, shift_size, num_heads
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, window_size, num_heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, H, W):
+        """x [B, H*W, C] (swin.py:235-295)."""
+        a = self.attn
+        y = F.layer_norm(x, (x.shape[-1],), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = F.linear(y, a.qkv.weight, a.qkv.bias)
+        y = ops.swin_window_attn(qkv, a.qkv.bias, a.gathered_bias(), H, W, self.num_heads, self.window_size,
+                                 self.shift_size)
+        x = x + F.linear(y, a.proj.weight, a.proj.bias)
+        y = F.layer_norm(x, (x.shape[-1],), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        y = F.gelu(F.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
+        return x + F.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x, H, W):
+        """2x2 gather in the order (ee, oe, eo, oo) -> LN -> Linear (swin.py:311-337)."""
+        B, L, C = x.shape
+        x = x.view(B, H, W, C)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+        x = x.reshape(B, -1, 4 * C)
+        x = F.layer_norm(x, (4 * C,), self.norm.weight, self.norm.bias, self.norm.eps)
+        return F.linear(x, self.reduction.weight)
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, downsample):
+        super().__init__()
+        self.blocks = nn.ModuleList(
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio)
+            for i in range(depth))
+        self.downsample = PatchMerging(dim) if downsample else None
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        """[B,3,H,W] -> tokens [B, Wh*Ww, C], Wh, Ww (swin.py:479-495)."""
+        ps = self.patch_size
+        _, _, H, W = x.shape
+        if W % ps or H % ps:
+            x = F.pad(x, (0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
+        x = F.conv2d(x, self.proj.weight, self.proj.bias, stride=ps)
+        Wh, Ww = x.shape[2], x.shape[3]
+        x = x.flatten(2).transpose(1, 2)
+        return F.layer_norm(x, (x.shape[-1],), self.norm.weight, self.norm.bias, self.norm.eps), Wh, Ww
+
+
+@BACKBONE_REGISTRY.register()
+class D2SwinTransformer(nn.Module):
+    """forward(x [B,3,H,W]) -> {"res2".."res5": [B,C_i,H/4..H/32, W/4..W/32]} (swin.py:743-758)."""
+
+    def __init__(self, arch):
+        super().__init__()
+        E, depths = arch["embed_dim"], arch["depths"]
+        self.patch_embed = PatchEmbed(arch["patch_size"], 3, E)
+        self.layers = nn.ModuleList(
+            BasicLayer(E * 2 ** i, depths[i], arch["num_heads"][i], arch["window_size"], arch["mlp_ratio"],
+                       downsample=i < len(depths) - 1) for i in range(len(depths)))
+        self.num_features = [E * 2 ** i for i in range(len(depths))]
+        for i, c in enumerate(self.num_features):
+            self.add_module(f"norm{i}", nn.LayerNorm(c))
+
+    @property
+    def size_divisibility(self):
+        return 32
+
+    def forward(self, x):
+        if x.dim() != 4:
+            raise ValueError(f"SwinTransformer takes an input of shape (N, C, H, W). Got {tuple(x.shape)} instead!")
+        x, Wh, Ww = self.patch_embed(x)
+        outs = {}
+        for i, layer in enumerate(self.layers):
+            for blk in layer.blocks:
+                x = blk(x, Wh, Ww)
+            norm = getattr(self, f"norm{i}")
+            y = F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+            outs[f"res{i + 2}"] = y.view(-1, Wh, Ww, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
+            if layer.downsample is not None:
+                x = layer.downsample(x, Wh, Ww)
+                Wh, Ww = (Wh + 1) // 2, (Ww + 1) // 2
+        return outs

@@ -1,0 +1,158 @@
+"""Masked-attention transformer decoder, inference only (reference:
+transformer_decoder/mask2former_transformer_decoder.py:232-502, post-norm, dropout 0).  Same parameter names.
+
+MI355X dataflow: memory is kept batch-first [B, S, C]; the cross/self attention cores are the HIP kernel K3 with
+the ``sigmoid(mask) < 0.5`` threshold and the all-masked-row fix fused in (the bool [B*h, Q, S] mask of the
+reference is never materialised); mask logits are the HIP kernel K4; the bilinear down-sample that feeds the
+attention mask is the HIP resampler.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...registry import TRANSFORMER_DECODER_REGISTRY
+from .position_encoding import PositionEmbeddingSine
+
+
+class _MHAParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names: in_proj_weight, in_proj_bias, out_proj.{weight,bias}."""
+
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.embed_dim, self.num_heads = d_model, nhead
+        self.in_proj_weight = nn.Parameter(torch.zeros(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+
+    def forward(self, query, key, value, mask_logits=None):
+        """batch-first: query [B,Q,E], key/value [B,S,E]; mask_logits [B,Q,S] (blocked iff sigmoid < 0.5)."""
+        E, nH = self.embed_dim, self.num_heads
+        B, Q, _ = query.shape
+        S = key.shape[1]
+        w, b = self.in_proj_weight, self.in_proj_bias
+        q = F.linear(query, w[:E], b[:E]).view(B, Q, nH, E // nH)
+        k = F.linear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
+        v = F.linear(value, w[2 * E:], b[2 * E:]).view(B, S, nH, E // nH)
+        o = ops.masked_xattn(q, k, v, mask_logits)
+        return F.linear(o, self.out_proj.weight, self.out_proj.bias)
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.self_attn = _MHAParams(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, query_pos):
+        qk = tgt + query_pos
+        return self.norm(tgt + self.self_attn(qk, qk, tgt))          # forward_post :48-58
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.multihead_attn = _MHAParams(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, memory, mask_logits, pos, query_pos):
+        t2 = self.multihead_attn(tgt + query_pos, memory + pos, memory, mask_logits)
+        return self.norm(tgt + t2)                                    # forward_post :106-118
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, tgt):
+        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))   # forward_post :171-175
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class MultiScaleMaskedTransformerDecoder(nn.Module):
+    def __init__(self, arch):
+        super().__init__()
+        a = arch
+        d = a["conv_dim"]
+        self.num_heads, self.num_layers = a["nheads"], a["dec_layers"]
+        self.num_queries, self.num_feature_levels = a["num_queries"], len(a["enc_in"])
+        self.pe_layer = PositionEmbeddingSine(d // 2, normalize=True)
+        self.transformer_self_attention_layers = nn.ModuleList(SelfAttentionLayer(d, a["nheads"]) for _ in range(self.num_layers))
+        self.transformer_cross_attention_layers = nn.ModuleList(CrossAttentionLayer(d, a["nheads"]) for _ in range(self.num_layers))
+        self.transformer_ffn_layers = nn.ModuleList(FFNLayer(d, a["dim_feedforward"]) for _ in range(self.num_layers))
+        self.decoder_norm = nn.LayerNorm(d)
+        self.query_feat = nn.Embedding(a["num_queries"], d)
+        self.query_embed = nn.Embedding(a["num_queries"], d)
+        self.level_embed = nn.Embedding(self.num_feature_levels, d)
+        self.class_embed = nn.Linear(d, a["num_classes"] + 1)
+        self.mask_embed = MLP(d, d, a["mask_dim"], 3)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # v1 checkpoints call query_feat "static_query" (reference :237-258)
+        for k in list(state_dict.keys()):
+            if k.startswith(prefix) and "static_query" in k:
+                state_dict[k.replace("static_query", "query_feat")] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True):
+        """output [B,Q,C] -> class logits [B,Q,K+1], mask logits [B,Q,H/4,W/4], attention-mask logits [B,Q,h*w]
+        (reference :472-489; the threshold itself happens inside K3)."""
+        dec = self.decoder_norm(output)
+        outputs_class = self.class_embed(dec)
+        mask_embed = self.mask_embed(dec)
+        outputs_mask = ops.mask_logits(mask_embed.contiguous(), mask_features)
+        attn_logits = None
+        if need_attn_mask:
+            attn_logits = ops.resample_bilinear(outputs_mask, attn_mask_target_size).flatten(2)
+        return outputs_class, outputs_mask, attn_logits
+
+    def forward(self, x, mask_features, mask=None):
+        """x: list of [B,C,h_l,w_l]; mask_features [B,md,H/4,W/4] -> dict(pred_logits, pred_masks, aux_outputs)
+        (reference :398-470)."""
+        assert len(x) == self.num_feature_levels
+        del mask
+        src, pos, size_list = [], [], []
+        for i in range(self.num_feature_levels):
+            size_list.append(tuple(int(v) for v in x[i].shape[-2:]))
+            pos.append(self.pe_layer(x[i]).flatten(2).transpose(1, 2))                      # [1,S,C]
+            src.append((x[i].flatten(2) + self.level_embed.weight[i][None, :, None]).transpose(1, 2).contiguous())
+        B = src[0].shape[0]
+        query_embed = self.query_embed.weight[None].expand(B, -1, -1)
+        output = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
+        mask_features = mask_features.contiguous()
+        predictions_class, predictions_mask = [], []
+        cls, msk, attn_logits = self.forward_prediction_heads(output, mask_features, size_list[0], self.num_layers > 0)
+        predictions_class.append(cls)
+        predictions_mask.append(msk)
+        for i in range(self.num_layers):
+            li = i % self.num_feature_levels
+            output = self.transformer_cross_attention_layers[i](output, src[li], attn_logits, pos[li], query_embed)
+            output = self.transformer_self_attention_layers[i](output, query_embed)
+            output = self.transformer_ffn_layers[i](output)
+            last = i == self.num_layers - 1
+            cls, msk, attn_logits = self.forward_prediction_heads(
+                output, mask_features, size_list[(i + 1) % self.num_feature_levels], need_attn_mask=not last)
+            predictions_class.append(cls)
+            predictions_mask.append(msk)
+        return {
+            "pred_logits": predictions_class[-1],
+            "pred_masks": predictions_mask[-1],
+            "aux_outputs": [{"pred_logits": a, "pred_masks": b}
+                            for a, b in zip(predictions_class[:-1], predictions_mask[:-1])],
+        }

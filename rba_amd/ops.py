@@ -1,0 +1,184 @@
+"""Python entry points of the HIP kernels: validate (device / dtype / contiguity / shape), allocate the
+output with torch (device memory + stream plumbing only) and enqueue the kernel on torch's current stream.
+
+Error behaviour mirrors the reference's native op (pixel_decoder/ops/src/cuda/ms_deform_attn_cuda.cu:33-43:
+AT_ASSERTM on contiguity and device -> RuntimeError): a bad argument raises RuntimeError (RbaHipError); there is
+no fallback path.
+"""
+import torch
+
+from . import _lib
+from ._lib import RbaHipError
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=torch.float32, dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise RbaHipError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RbaHipError(f"{name} must be a HIP (cuda) tensor; rba_amd kernels have no CPU path")
+    if t.dtype != dtype:
+        raise RbaHipError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RbaHipError(f"{name} tensor has to be contiguous")
+    if dim is not None and t.dim() != dim:
+        raise RbaHipError(f"{name} must have {dim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False):
+    """K1.  mask_pred [Q,H,W] full-resolution mask logits, cls_prob [Q,K] -> (rba [H,W], sem_seg [K,H,W] | None,
+    argmax int32 [H,W] | None).  maskformer_model.py:381-386 + evaluate_ood.py:150 + support.py:385-388."""
+    lib = _lib.load()
+    _chk(mask_pred, "mask_pred", dim=3)
+    _chk(cls_prob, "cls_prob", dim=2)
+    Q, H, W = mask_pred.shape
+    if cls_prob.shape[0] != Q:
+        raise RbaHipError(f"cls_prob has {cls_prob.shape[0]} queries, mask_pred {Q}")
+    K = cls_prob.shape[1]
+    dev = mask_pred.device
+    rba = torch.empty((H, W), dtype=torch.float32, device=dev)
+    sem = torch.empty((K, H, W), dtype=torch.float32, device=dev) if want_sem_seg else None
+    arg = torch.empty((H, W), dtype=torch.int32, device=dev) if want_argmax else None
+    _lib.check(lib.rba_reduce_f32(_p(mask_pred), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, H * W, _stream()),
+               "rba_reduce_f32")
+    return rba, sem, arg
+
+
+def rba_reduce_up4(mask_lowres, cls_prob, crop_hw, want_sem_seg=False, want_argmax=False):
+    """K1 fused with the x4 upsample (maskformer_model.py:294-299) and the crop (:330-332).
+    mask_lowres [Q,h,w]; outputs are [crop_h, crop_w] of the virtual [4h,4w] map."""
+    lib = _lib.load()
+    _chk(mask_lowres, "mask_lowres", dim=3)
+    _chk(cls_prob, "cls_prob", dim=2)
+    Q, h, w = mask_lowres.shape
+    K = cls_prob.shape[1]
+    ch, cw = int(crop_hw[0]), int(crop_hw[1])
+    dev = mask_lowres.device
+    rba = torch.empty((ch, cw), dtype=torch.float32, device=dev)
+    sem = torch.empty((K, ch, cw), dtype=torch.float32, device=dev) if want_sem_seg else None
+    arg = torch.empty((ch, cw), dtype=torch.int32, device=dev) if want_argmax else None
+    _lib.check(lib.rba_reduce_up4_f32(_p(mask_lowres), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, h, w, ch, cw,
+                                      _stream()), "rba_reduce_up4_f32")
+    return rba, sem, arg
+
+
+def resample_bilinear(x, size, add=None):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) for x [C,h,w] or [B,C,h,w]; optional fused
+    `+ add` (the FPN top-down sum of msdeformattn.py:358)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    if x.dim() not in (3, 4):
+        raise RbaHipError("x must be [C,h,w] or [B,C,h,w]")
+    H, W = int(size[0]), int(size[1])
+    lead = x.shape[:-2]
+    C = 1
+    for s in lead:
+        C *= int(s)
+    h, w = x.shape[-2:]
+    out = torch.empty(tuple(lead) + (H, W), dtype=torch.float32, device=x.device)
+    if add is not None:
+        _chk(add, "add")
+        if tuple(add.shape) != tuple(out.shape):
+            raise RbaHipError("add must have the output's shape")
+    _lib.check(lib.rba_resample_bilinear_f32(_p(x), _p(add), _p(out), C, h, w, H, W, _stream()),
+               "rba_resample_bilinear_f32")
+    return out
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                           im2col_step=128):
+    """K2.  Same signature and checks as MultiScaleDeformableAttention.ms_deform_attn_forward
+    (pixel_decoder/ops/functions/ms_deform_attn_func.py:36-37, ops/src/cuda/ms_deform_attn_cuda.cu:25-85):
+    value [N,S,M,D], spatial_shapes [L,2] int64, level_start_index [L] int64, sampling_locations
+    [N,Lq,M,L,P,2], attention_weights [N,Lq,M,L,P] -> [N,Lq,M*D].  `im2col_step` is accepted for signature
+    compatibility and only validated (the kernel needs no batch chunking)."""
+    lib = _lib.load()
+    _chk(value, "value", dim=4)
+    _chk(spatial_shapes, "spatial_shapes", torch.int64, 2)
+    _chk(level_start_index, "level_start_index", torch.int64, 1)
+    _chk(sampling_locations, "sampling_loc", dim=6)
+    _chk(attention_weights, "attn_weight", dim=5)
+    N, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_locations.shape
+    if M2 != M or two != 2 or sampling_locations.shape[0] != N:
+        raise RbaHipError("sampling_loc shape does not match value")
+    if tuple(attention_weights.shape) != (N, Lq, M, L, P):
+        raise RbaHipError("attn_weight shape does not match sampling_loc")
+    if spatial_shapes.shape[0] != L or level_start_index.shape[0] != L:
+        raise RbaHipError("spatial_shapes / level_start_index must have L rows")
+    step = min(N, int(im2col_step))
+    if N > 0 and N % step != 0:
+        raise RbaHipError(f"batch({N}) must divide im2col_step({step})")
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    _lib.check(lib.rba_ms_deform_attn_fwd_f32(_p(value), _p(spatial_shapes), _p(level_start_index),
+                                              _p(sampling_locations), _p(attention_weights), _p(out),
+                                              N, S, M, D, L, Lq, P, _stream()), "rba_ms_deform_attn_fwd_f32")
+    return out
+
+
+def masked_xattn(q, k, v, mask_logits=None):
+    """K3.  q [B,Q,nH,hd] (unscaled), k, v [B,S,nH,hd], mask_logits [B,Q,S] | None -> [B,Q,nH*hd]."""
+    lib = _lib.load()
+    _chk(q, "q", dim=4)
+    _chk(k, "k", dim=4)
+    _chk(v, "v", dim=4)
+    B, Q, nH, hd = q.shape
+    S = k.shape[1]
+    if tuple(k.shape) != (B, S, nH, hd) or tuple(v.shape) != (B, S, nH, hd):
+        raise RbaHipError("k / v shape mismatch")
+    if mask_logits is not None:
+        _chk(mask_logits, "mask_logits", dim=3)
+        if tuple(mask_logits.shape) != (B, Q, S):
+            raise RbaHipError("mask_logits must be [B,Q,S]")
+    out = torch.empty((B, Q, nH * hd), dtype=torch.float32, device=q.device)
+    _lib.check(lib.rba_masked_xattn_f32(_p(q), _p(k), _p(v), _p(mask_logits), _p(out), B, Q, S, nH, hd, _stream()),
+               "rba_masked_xattn_f32")
+    return out
+
+
+def mask_logits(embed, feat):
+    """K4.  einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479): embed [B,Q,C], feat [B,C,h,w]."""
+    lib = _lib.load()
+    _chk(embed, "embed", dim=3)
+    _chk(feat, "feat")
+    if feat.dim() not in (3, 4):
+        raise RbaHipError("feat must be [B,C,N] or [B,C,h,w]")
+    B, Q, C = embed.shape
+    if feat.shape[0] != B or feat.shape[1] != C:
+        raise RbaHipError("feat shape does not match embed")
+    sp = tuple(feat.shape[2:])
+    N = 1
+    for s in sp:
+        N *= int(s)
+    out = torch.empty((B, Q) + sp, dtype=torch.float32, device=embed.device)
+    _lib.check(lib.rba_mask_logits_f32(_p(embed), _p(feat), _p(out), B, Q, C, N, _stream()), "rba_mask_logits_f32")
+    return out
+
+
+def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shift):
+    """K5.  qkv [B,H*W,3*C] = Linear(norm1(x)) on un-padded tokens, qkv_bias [3*C], rel_bias [nH,N,N] ->
+    attention output [B,H*W,C] (before proj).  swin.py:131-171 + :251-284 + :413-440."""
+    lib = _lib.load()
+    _chk(qkv, "qkv", dim=3)
+    _chk(qkv_bias, "qkv_bias", dim=1)
+    _chk(rel_bias, "rel_bias", dim=3)
+    B, L, C3 = qkv.shape
+    C = C3 // 3
+    if L != H * W or C3 != 3 * C or C % num_heads:
+        raise RbaHipError("qkv shape does not match H, W, num_heads")
+    hd = C // num_heads
+    N = window_size * window_size
+    if tuple(rel_bias.shape) != (num_heads, N, N) or qkv_bias.numel() != C3:
+        raise RbaHipError("rel_bias must be [nH, ws*ws, ws*ws] and qkv_bias [3C]")
+    out = torch.empty((B, L, C), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.rba_swin_window_attn_f32(_p(qkv), _p(qkv_bias), _p(rel_bias), _p(out), B, H, W, num_heads, hd,
+                                            window_size, shift, _stream()), "rba_swin_window_attn_f32")
+    return out

@@ -1,0 +1,69 @@
+"""``OODEvaluator`` with the reference's constructor and method signatures (support.py:228-399): per-image scoring
+loop, then AUROC / AuPRC / FPR95 over all labelled pixels.  The metrics are computed by ``rba_amd.metrics`` (GPU
+sort) instead of scikit-learn; results match to float64 round-off (tests/test_metrics.py)."""
+from typing import Callable
+
+import numpy as np
+import torch
+
+from .metrics import ood_metrics, select_labelled
+
+
+class OODEvaluator:
+    def __init__(self, model, inference_func: Callable, anomaly_score_func: Callable):
+        self.model = model
+        self.inference_func = inference_func
+        self.anomaly_score_func = anomaly_score_func
+
+    def get_logits(self, x, **kwargs):
+        return self.inference_func(self.model, x, **kwargs)
+
+    def get_anomaly_score(self, x, **kwargs):
+        return self.anomaly_score_func(self.model, x, **kwargs)
+
+    def calculate_ood_metrics(self, out, label):
+        """-> (auroc, aupr, fpr95) for flat score / {0,1} label arrays (support.py:259-268)."""
+        dev = getattr(self.model, "device", torch.device("cpu")) if self.model is not None else torch.device("cpu")
+        r = ood_metrics(torch.as_tensor(out, device=dev), torch.as_tensor(label, device=dev))
+        return r["auroc"], r["aupr"], r["fpr95"]
+
+    def evaluate_ood(self, anomaly_score, ood_gts, verbose=True):
+        """anomaly_score [N,H,W], ood_gts [N,1,H,W] (numpy or torch); labels 1 = OoD, 0 = inlier, else ignored."""
+        dev = getattr(self.model, "device", torch.device("cpu")) if self.model is not None else torch.device("cpu")
+        s = torch.as_tensor(np.asarray(anomaly_score) if not torch.is_tensor(anomaly_score) else anomaly_score).to(dev)
+        g = torch.as_tensor(np.asarray(ood_gts) if not torch.is_tensor(ood_gts) else ood_gts).to(dev)
+        s, y = select_labelled(s.squeeze(), g.squeeze())
+        if verbose:
+            print(f"Calculating Metrics for {s.numel()} Points ...")
+        result = ood_metrics(s, y)
+        if verbose:
+            print(f"Max Logits: AUROC score: {result['auroc']}")
+            print(f"Max Logits: AUPRC score: {result['aupr']}")
+            print(f"Max Logits: FPR@TPR95: {result['fpr95']}")
+        return result
+
+    def compute_anomaly_scores(self, loader, device=torch.device("cpu"), return_preds=False,
+                               use_gaussian_smoothing=False, upper_limit=450):
+        """Batch-1 scoring loop (support.py:353-399).  Returns numpy arrays like the reference."""
+        if use_gaussian_smoothing:
+            raise NotImplementedError("gaussian smoothing of the score map is outside the RbA hot path")
+        anomaly_score, ood_gts, predictions = [], [], []
+        for jj, (x, y) in enumerate(loader):
+            if jj >= upper_limit:
+                break
+            x = x.to(device)
+            ood_gts.append(np.asarray(y.cpu()))
+            if return_preds and hasattr(self.model, "rba_scores") and self.anomaly_score_func.__name__ == "get_RbA":
+                # one forward instead of the reference's two (support.py:380,386)
+                score, preds = self.model.rba_scores([{"image": x[0]}], return_argmax=True)[0]
+                predictions.append(preds.to(torch.int64).unsqueeze(0).cpu().numpy())
+            else:
+                score = self.get_anomaly_score(x)
+                if return_preds:
+                    logits = self.get_logits(x)
+                    predictions.append(logits[:, :19].max(dim=1)[1].cpu().numpy())
+            anomaly_score.append(score.cpu().numpy())
+        ood_gts, anomaly_score = np.array(ood_gts), np.array(anomaly_score)
+        if return_preds:
+            return anomaly_score, ood_gts, np.array(predictions)
+        return anomaly_score, ood_gts

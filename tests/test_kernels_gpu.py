@@ -1,0 +1,243 @@
+"""GPU: each HIP kernel (through the C ABI, via rba_amd.ops) against the oracle on the same inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_model, ref_ops
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from rba_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def maxerr(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def argmax_ok(arg, sem_ref, tol=1e-5):
+    """bit-exact except where the top-2 classes of the reference are closer than `tol`."""
+    top2 = sem_ref.topk(2, dim=0).values
+    gap = top2[0] - top2[1]
+    flips = arg.cpu().long() != sem_ref.argmax(0)
+    return int((flips & (gap > tol)).sum()), int(flips.sum())
+
+
+# ----------------------------------------------------------------------------------- K1
+def test_k1_golden(ops, golden):
+    g = golden("g1_rba_reduce")
+    mp, mc = T(g["mask_pred"]), T(g["mask_cls"])
+    prob = ref_ops.class_probs(mc)
+    rba, sem, arg = ops.rba_reduce(dev(mp), dev(prob), True, True)
+    assert maxerr(sem, T(g["sem_seg"])) < 2e-6
+    assert maxerr(rba, T(g["rba"])) < 1e-5           # north-star tolerance is 1e-4
+    assert np.array_equal(arg.cpu().numpy(), g["argmax"])
+    rba2, sem2, arg2 = ops.rba_reduce(dev(mp), dev(prob))
+    assert sem2 is None and arg2 is None and torch.equal(rba2, rba)
+    # fused x4 upsample + crop
+    low = T(g["low"])
+    r_up, s_up, a_up = ops.rba_reduce_up4(dev(low), dev(prob), (16, 32), True, True)
+    assert maxerr(s_up, T(g["sem_up"])) < 5e-6
+    assert maxerr(r_up, T(g["rba_up"])) < 1e-5
+    r_c, s_c, _ = ops.rba_reduce_up4(dev(low), dev(prob), (13, 30), True, False)      # ragged crop
+    assert maxerr(s_c, T(g["sem_up"])[:, :13, :30]) < 5e-6 and maxerr(r_c, T(g["rba_up"])[:13, :30]) < 1e-5
+
+
+@pytest.mark.parametrize("Q,K,H,W", [(100, 19, 64, 128), (7, 19, 5, 13), (100, 20, 16, 20), (3, 5, 9, 7),
+                                      (50, 65, 8, 24), (1, 1, 1, 1), (100, 19, 1, 4096), (12, 133, 6, 10)])
+def test_k1_shapes(ops, Q, K, H, W):
+    g = torch.Generator().manual_seed(Q * 1000 + K)
+    mp = torch.randn(Q, H, W, generator=g) * 5
+    prob = F.softmax(torch.randn(Q, K + 1, generator=g) * 3, -1)[:, :-1].contiguous()
+    sem_r, rba_r, _ = ref_ops.rba_reduce_ordered(mp, prob)
+    rba, sem, arg = ops.rba_reduce(dev(mp), dev(prob), True, True)
+    assert maxerr(sem, sem_r) < 5e-6 and maxerr(rba, rba_r) < 2e-5
+    bad, _ = argmax_ok(arg, sem_r)
+    assert bad == 0
+
+
+def test_k1_empty_and_errors(ops):
+    from rba_amd._lib import RbaHipError
+    prob = torch.full((4, 19), 0.01).cuda()
+    rba, _, _ = ops.rba_reduce(torch.zeros(4, 0, 8).cuda(), prob)
+    assert rba.shape == (0, 8)
+    with pytest.raises(RbaHipError):
+        ops.rba_reduce(torch.zeros(4, 2, 2), prob)                  # CPU tensor: no fallback
+    with pytest.raises(RbaHipError):
+        ops.rba_reduce(torch.zeros(4, 2, 2).cuda().double(), prob)  # wrong dtype
+    with pytest.raises(RbaHipError):
+        ops.rba_reduce(torch.zeros(5, 2, 2).cuda(), prob)           # Q mismatch
+    with pytest.raises(RbaHipError):
+        ops.rba_reduce(torch.zeros(4, 2, 4).cuda()[:, :, ::2], prob)   # non-contiguous
+
+
+def test_k1_extreme_values(ops):
+    mp = torch.tensor([[-200.0, 200.0, 0.0, -1e-8], [88.0, -88.0, 30.0, 1e-8]]).view(2, 1, 4)
+    prob = torch.tensor([[0.7, 0.2], [0.1, 0.6]])
+    sem_r, rba_r, arg_r = ref_ops.rba_reduce_ordered(mp, prob)
+    rba, sem, arg = ops.rba_reduce(dev(mp), dev(prob), True, True)
+    assert torch.isfinite(rba).all() and maxerr(sem, sem_r) < 1e-6 and maxerr(rba, rba_r) < 1e-6
+
+
+@pytest.mark.parametrize("h,w,ch,cw", [(8, 16, 32, 64), (5, 7, 20, 28), (6, 9, 21, 33), (1, 1, 4, 4), (184, 320, 720, 1280)])
+def test_k1_up4_shapes(ops, h, w, ch, cw):
+    g = torch.Generator().manual_seed(h * 100 + w)
+    Q = 100 if h < 50 else 12
+    low = torch.randn(Q, h, w, generator=g) * 5
+    prob = F.softmax(torch.randn(Q, 20, generator=g) * 3, -1)[:, :-1].contiguous()
+    up = ref_ops.upsample_bilinear(low[None], (4 * h, 4 * w))[0]
+    sem_r, rba_r, _ = ref_ops.rba_reduce_ordered(up, prob)
+    sem_r, rba_r = sem_r[:, :ch, :cw], rba_r[:ch, :cw]
+    rba, sem, arg = ops.rba_reduce_up4(dev(low), dev(prob), (ch, cw), True, True)
+    assert maxerr(sem, sem_r) < 1e-5 and maxerr(rba, rba_r) < 2e-5
+    assert argmax_ok(arg, sem_r)[0] == 0
+
+
+# ----------------------------------------------------------------------------------- resample
+@pytest.mark.parametrize("C,h,w,H,W", [(100, 8, 16, 32, 64), (3, 23, 40, 46, 80), (5, 64, 128, 8, 16), (2, 184, 320, 23, 40),
+                                        (4, 7, 9, 13, 30), (1, 1, 1, 5, 3), (6, 45, 80, 90, 160), (3, 30, 45, 32, 48)])
+def test_resample(ops, C, h, w, H, W):
+    g = torch.Generator().manual_seed(C + h)
+    x = torch.randn(C, h, w, generator=g)
+    ref = ref_ops.upsample_bilinear(x[None], (H, W))[0]
+    assert maxerr(ops.resample_bilinear(dev(x), (H, W)), ref) < 2e-6
+    add = torch.randn(C, H, W, generator=g)
+    assert maxerr(ops.resample_bilinear(dev(x), (H, W), add=dev(add)), ref + add) < 2e-6
+    x4 = x[None].repeat(2, 1, 1, 1)
+    assert maxerr(ops.resample_bilinear(dev(x4), (H, W)), ref[None].repeat(2, 1, 1, 1)) < 2e-6
+
+
+# ----------------------------------------------------------------------------------- K2
+def test_k2_reference_test_set(ops, golden):
+    """the reference's own ops/test.py shapes (float variant, :50-63; tolerance there rtol 1e-2 atol 1e-3)."""
+    g = golden("g2_ms_deform_attn")
+    shapes = T(g["a_shapes"])
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    out = ops.ms_deform_attn_forward(dev(T(g["a32_value"])), dev(shapes), dev(lsi), dev(T(g["a32_loc"])),
+                                     dev(T(g["a32_w"])), 2)
+    assert maxerr(out, T(g["a32_out"])) < 1e-8
+
+
+def test_k2_golden_3level(ops, golden):
+    g = golden("g2_ms_deform_attn")
+    shapes = T(g["b_shapes"])
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    out = ops.ms_deform_attn_forward(dev(T(g["b_value"])), dev(shapes), dev(lsi), dev(T(g["b_loc"])), dev(T(g["b_w"])))
+    assert maxerr(out, T(g["b_out"])) < 5e-6
+    assert maxerr(out, T(g["b_out64"])) < 2e-5
+
+
+@pytest.mark.parametrize("N,M,D,shapes,P", [(1, 8, 32, [(32, 64)], 4), (2, 8, 32, [(23, 40), (12, 20), (6, 10)], 4),
+                                             (1, 2, 2, [(6, 4), (3, 2)], 2), (1, 3, 5, [(4, 7)], 3), (3, 2, 16, [(9, 9), (1, 1)], 1)])
+def test_k2_shapes(ops, N, M, D, shapes, P):
+    g = torch.Generator().manual_seed(N * 10 + M)
+    sh = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
+    S = int(sh.prod(1).sum())
+    L, Lq = len(shapes), S
+    value = torch.randn(N, S, M, D, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.4 - 0.2
+    w = F.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    ref = ref_ops.ms_deform_attn(value, sh, loc, w)
+    out = ops.ms_deform_attn_forward(dev(value), dev(sh), dev(lsi), dev(loc), dev(w))
+    assert out.shape == (N, Lq, M * D) and maxerr(out, ref) < 1e-5
+
+
+def test_k2_errors(ops):
+    from rba_amd._lib import RbaHipError
+    sh = torch.as_tensor([(2, 2)], dtype=torch.long).cuda()
+    lsi = torch.zeros(1, dtype=torch.long).cuda()
+    v = torch.zeros(3, 4, 2, 4).cuda()
+    loc = torch.zeros(3, 4, 2, 1, 2, 2).cuda()
+    w = torch.zeros(3, 4, 2, 1, 2).cuda()
+    with pytest.raises(RbaHipError):
+        ops.ms_deform_attn_forward(v, sh, lsi, loc, w, im2col_step=2)      # 3 % 2 != 0 (ms_deform_attn_cuda.cu:55-57)
+    with pytest.raises(RbaHipError):
+        ops.ms_deform_attn_forward(v.cpu(), sh, lsi, loc, w)
+    with pytest.raises(RbaHipError):
+        ops.ms_deform_attn_forward(v, sh.int(), lsi, loc, w)
+
+
+# ----------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("B,Q,S,nH", [(1, 100, 2048, 8), (2, 16, 77, 2), (1, 5, 1, 1), (1, 100, 920, 8)])
+def test_k3_masked_xattn(ops, B, Q, S, nH):
+    g = torch.Generator().manual_seed(Q + S)
+    q, k, v = (torch.randn(B, n, nH, 32, generator=g) for n in (Q, S, S))
+    ml = torch.randn(B, Q, S, generator=g) * 3
+    ml[:, 0] = -5.0                   # a fully blocked row -> attends everywhere (decoder.py:433)
+    if Q > 1:
+        ml[:, 1] = 5.0
+    blocked = ref_ops.attn_mask_from_logits(ml.clone())
+    ref = ref_ops.attention_core(q, k, v, blocked)
+    out = ops.masked_xattn(dev(q), dev(k), dev(v), dev(ml))
+    assert maxerr(out, ref) < 5e-6
+    ref0 = ref_ops.attention_core(q, k, v, None)
+    assert maxerr(ops.masked_xattn(dev(q), dev(k), dev(v), None), ref0) < 5e-6
+
+
+# ----------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("B,Q,C,h,w", [(1, 100, 256, 32, 64), (2, 16, 64, 15, 23), (1, 100, 256, 7, 9), (1, 3, 8, 1, 1)])
+def test_k4_mask_logits(ops, B, Q, C, h, w):
+    g = torch.Generator().manual_seed(Q + C)
+    e = torch.randn(B, Q, C, generator=g)
+    f = torch.randn(B, C, h, w, generator=g)
+    ref = torch.einsum("bqc,bchw->bqhw", e.double(), f.double())
+    out = ops.mask_logits(dev(e), dev(f))
+    assert out.shape == (B, Q, h, w) and maxerr(out, ref) < 2e-4 * (C / 256) ** 0.5 + 1e-5
+
+
+# ----------------------------------------------------------------------------------- K5
+def test_k5_swin_block_golden(ops, golden):
+    """BasicLayer of the reference on a 13 x 20 grid (window pad, shifted block): product block on GPU vs golden."""
+    from rba_amd.modeling.backbone.swin import BasicLayer
+    g = golden("g3_swin_parts")
+    layer = BasicLayer(32, 2, 2, 6, 4.0, downsample=True)
+    sd = {k[len("bl_sd."):]: T(g[k]) for k in g.files if k.startswith("bl_sd.")}
+    layer.load_state_dict(sd)
+    layer = layer.cuda().eval()
+    H, W, Wh, Ww = (int(v) for v in g["bl_hw"])
+    x = dev(T(g["bl_x"]))
+    with torch.no_grad():
+        for blk in layer.blocks:
+            x = blk(x, H, W)
+        down = layer.downsample(x, H, W)
+    assert maxerr(x, T(g["bl_out"])) < 2e-5
+    assert maxerr(down, T(g["bl_down"])) < 2e-5
+
+
+@pytest.mark.parametrize("H,W,ws,nH,shift", [(12, 12, 6, 2, 0), (13, 20, 6, 2, 3), (24, 36, 12, 4, 6), (7, 5, 12, 1, 6),
+                                              (30, 41, 7, 3, 3)])
+def test_k5_window_attn_core(ops, H, W, ws, nH, shift):
+    g = torch.Generator().manual_seed(H * W)
+    C, B = nH * 32, 2
+    qkv_w, qkv_b = torch.randn(3 * C, C, generator=g) * C ** -0.5, torch.randn(3 * C, generator=g) * 0.2
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g) * 0.5
+    x = torch.randn(B, H * W, C, generator=g)
+    # oracle: pad -> roll -> partition -> window attention (identity proj) -> reverse -> un-roll -> crop
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    xp = F.pad(x.view(B, H, W, C), (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = xp.shape[1], xp.shape[2]
+    if shift:
+        xp = torch.roll(xp, (-shift, -shift), (1, 2))
+    xw = xp.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    mask = ref_ops.shift_attn_mask(H, W, ws, shift) if shift else None
+    aw = ref_ops.window_attention(xw, qkv_w, qkv_b, torch.eye(C), torch.zeros(C), table, ws, nH, mask)
+    y = aw.view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    if shift:
+        y = torch.roll(y, (shift, shift), (1, 2))
+    ref = y[:, :H, :W].reshape(B, H * W, C)
+    qkv = F.linear(x, qkv_w, qkv_b)
+    N = ws * ws
+    bias = table[ref_ops.relative_position_index(ws).view(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
+    out = ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift)
+    assert maxerr(out, ref) < 1e-5

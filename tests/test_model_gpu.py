@@ -1,0 +1,123 @@
+"""GPU: the whole product path (Swin -> pixel decoder -> masked decoder -> RbA reduction, HIP kernels K1-K5) against
+the golden fixtures of the reference and against the oracle run on the same seeded weights."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model
+from rba_amd import arch as A
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def build(name, seed=0):
+    from rba_amd.checkpoint import load_checkpoint
+    from rba_amd.maskformer_model import MaskFormer
+    a = A.complete(A.ARCHS[name])
+    sd = A.seeded_weights(a, seed)
+    model = load_checkpoint(MaskFormer(a), sd).cuda().eval()
+    return model, a, sd
+
+
+def maxerr(a, b):
+    return (a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max().item()
+
+
+def argmax_bad(arg, sem_ref, tol=1e-4):
+    top2 = sem_ref.topk(2, dim=0).values
+    flips = arg.cpu().long() != sem_ref.argmax(0)
+    return int((flips & ((top2[0] - top2[1]) > tol)).sum()), int(flips.sum())
+
+
+@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90"])
+def test_tiny_vs_golden(golden, name):
+    g = golden(name)
+    model, a, _ = build(str(g["arch"]), int(g["seed"]))
+    image = T(g["image"])
+    feats = model.backbone(model.preprocess([{"image": image}])[0])
+    for k in ("res2", "res3", "res4", "res5"):
+        assert maxerr(feats[k][0], g["feat_" + k]) < 5e-5, k
+    mask_cls, mask_pred, sizes, padded = model.predict([{"image": image}])
+    assert sizes == [(60, 90)] and padded == (64, 96)
+    assert maxerr(mask_cls[0], g["pred_logits"]) < 1e-4
+    assert maxerr(mask_pred[0], g["pred_masks"]) < 5e-4
+    for fused in (True, False):
+        model.fused_upsample = fused
+        out = model([{"image": image}], return_argmax=True)[0]
+        assert out["sem_seg"].shape == (19, 60, 90)
+        assert maxerr(out["sem_seg"], g["sem_seg"]) < 1e-4          # north star: scores within 1e-4
+        assert maxerr(out["rba"], g["rba"]) < 1e-4
+        bad, flips = argmax_bad(out["argmax"], T(g["sem_seg"]))
+        assert bad == 0, (bad, flips)
+        rba, arg = model.rba_scores([{"image": image}], return_argmax=True)[0]
+        assert torch.equal(rba, out["rba"]) and torch.equal(arg, out["argmax"])
+
+
+def test_evaluator_surface_tiny(golden, tmp_path):
+    """get_model(config.yaml, model_final.pth) -> get_RbA / get_logits / OODEvaluator, as evaluate_ood.py drives them."""
+    import yaml
+    from rba_amd import evaluate_ood as E
+    from rba_amd.support import OODEvaluator
+    g = golden("g4_tiny1_60x90")
+    a = A.complete(A.ARCHS["tiny1"])
+    cfg = {"MODEL": {"META_ARCHITECTURE": "MaskFormer", "BACKBONE": {"NAME": "D2SwinTransformer"},
+                     "SWIN": {"EMBED_DIM": 32, "DEPTHS": [2, 2, 2, 2], "NUM_HEADS": [1, 2, 4, 8], "WINDOW_SIZE": 6},
+                     "SEM_SEG_HEAD": {"CONVS_DIM": 64, "MASK_DIM": 64, "TRANSFORMER_ENC_LAYERS": 2,
+                                      "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res5"]},
+                     "MASK_FORMER": {"HIDDEN_DIM": 64, "NHEADS": 2, "NUM_OBJECT_QUERIES": 16, "DIM_FEEDFORWARD": 128,
+                                     "DEC_LAYERS": 2}}}
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(cfg))
+    sd = A.seeded_weights(a, 0)
+    sd["criterion.empty_weight"] = torch.ones(20)          # present in real checkpoints, must be tolerated
+    torch.save({"model": sd, "iteration": 1}, tmp_path / "model_final.pth")
+    model = E.get_model(str(tmp_path / "config.yaml"), str(tmp_path / "model_final.pth"))
+    x = T(g["image"])[None]
+    assert maxerr(E.get_RbA(model, x), g["rba"]) < 1e-4
+    logits = E.get_logits(model, x)
+    assert logits.shape == (1, 19, 60, 90) and maxerr(logits[0], g["sem_seg"]) < 1e-4
+    # the reference's own get_RbA formula applied to our model's output dict
+    out = model([{"image": x[0]}])
+    assert maxerr(-out[0]["sem_seg"].tanh().sum(dim=0), g["rba"]) < 1e-4
+    ev = OODEvaluator(model, E.get_logits, E.get_RbA)
+    gt = torch.zeros(1, 60, 90, dtype=torch.long)
+    gt[:, 10:20, 10:30] = 1
+    gt[:, :2] = 255
+    scores, gts, preds = ev.compute_anomaly_scores([(x, gt)], device=torch.device("cuda"), return_preds=True)
+    assert scores.shape == (1, 60, 90) and gts.shape == (1, 1, 60, 90) and preds.shape == (1, 1, 60, 90)
+    r = ev.evaluate_ood(scores, gts, verbose=False)
+    from oracle import ref_metrics
+    want = ref_metrics.evaluate_ood(scores, gts)
+    assert all(abs(r[k] - want[k]) < 1e-9 for k in want)
+
+
+def _full_size(golden, fixture, arch_name, tol_rba):
+    g = golden(fixture)
+    model, a, sd = build(arch_name, int(g["seed"]))
+    h, w = (int(v) for v in g["hw"])
+    gen = torch.Generator().manual_seed(int(g["img_seed"]))
+    image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
+    mask_cls, mask_pred, _, _ = model.predict([{"image": image}])
+    rba, arg = model.rba_scores([{"image": image}], return_argmax=True)[0]
+    ys, xs, ys4, xs4 = (T(g[k]).long() for k in ("ys", "xs", "ys4", "xs4"))
+    e_logits = maxerr(mask_cls[0], g["pred_logits"])
+    e_masks = maxerr(mask_pred[0].cpu()[:, ys4, xs4], g["pred_masks_s"])
+    e_rba = maxerr(rba.cpu()[ys, xs], g["rba_s"])
+    sem_s = T(g["sem_s"])
+    top2 = sem_s.topk(2, dim=0).values
+    flips = arg.cpu().long()[ys, xs] != T(g["argmax_s"]).long()
+    bad = int((flips & ((top2[0] - top2[1]) > 1e-4)).sum())
+    print(f"{fixture}: |d logits| {e_logits:.2e} |d masks| {e_masks:.2e} |d rba| {e_rba:.2e} argmax flips {int(flips.sum())} (bad {bad}); "
+          f"attn-mask margin of the reference run {float(g['attn_mask_margin']):.1e}")
+    assert e_rba < tol_rba and bad == 0
+    assert abs(float(rba.double().sum()) - float(g["rba_stats"][0])) < 1e-4 * h * w * 0.05
+
+
+def test_full_size_swin_b_1dl_1024x2048(golden):
+    """BASELINE config C2 against values the reference's own modules produced (sampled pixels)."""
+    _full_size(golden, "g5_swin_b_1dl_1024x2048", "swin_b_1dl", 1e-4)
+
+
+def test_full_size_swin_b_9dl_720x1280(golden):
+    """BASELINE config C5 (9 decoder layers, 3-level MSDeformAttn, 720 -> 736 padding)."""
+    _full_size(golden, "g5_swin_b_9dl_720x1280", "swin_b_9dl", 1e-4)
