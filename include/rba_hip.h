@@ -80,7 +80,7 @@ int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B
  * window reverse, un-shift and crop.
  * qkv [B,H*W,3,nH,hd] = Linear(norm1(x)) of the UNPADDED tokens; padded tokens take qkv_bias [3*nH*hd]
  * (= Linear(0)).  bias [nH,ws*ws,ws*ws] gathered relative-position bias.  shift = 0 or ws/2.
- * out [B,H*W,nH*hd] (attention output before the proj Linear).  hd must be 32; ws*ws <= 256. */
+ * out [B,H*W,nH*hd] (attention output before the proj Linear).  hd in {16,32,64}; ws*ws <= 256. */
 int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias, float* out,
                              int B, int H, int W, int nH, int hd, int ws, int shift, void* stream);
 

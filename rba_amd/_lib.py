@@ -38,6 +38,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be the HIP runtime already resident when librba_hip.so's
+    # DT_NEEDED libamdhip64.so.N is resolved, otherwise the process ends up with a second runtime (the system one)
+    # that owns our code objects but not torch's device context -> launches fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RbaHipError(
             f"{LIB_PATH} not found: build it with `python -m rba_amd.csrc.build` (hipcc --offload-arch=gfx950). "

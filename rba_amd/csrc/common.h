@@ -14,6 +14,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
     if (!(cond)) return (int)hipErrorInvalidValue; \
   } while (0)
 
+// hipGetLastError() is per-thread and sticky: an unrelated earlier failure of the host program (e.g. a device
+// probe) would otherwise be reported as ours.  Every entry point calls rba_begin() before launching.
+static inline void rba_begin() { (void)hipGetLastError(); }
 static inline int rba_launch_status() { return (int)hipGetLastError(); }
 
 // 1 / (1 + e^-x): v_exp_f32 + v_rcp_f32, abs error <~ 1e-7 (ample for the 1e-4 score tolerance).

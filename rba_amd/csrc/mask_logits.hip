@@ -81,8 +81,10 @@ int launch(const float* embed, const float* feat, float* out, int B, int Q, int 
 
 extern "C" int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,
                                    void* stream) {
-  RBA_CHECK_ARG(embed && feat && out && B >= 0 && Q >= 0 && C >= 1 && N >= 0 && B <= 65535);
+  RBA_CHECK_ARG(B >= 0 && Q >= 0 && C >= 1 && N >= 0 && B <= 65535);
   if (B == 0 || Q == 0 || N == 0) return 0;
+  RBA_CHECK_ARG(embed && feat && out);
+  rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const bool vec2 = (N % 2 == 0) && ((((uintptr_t)feat | (uintptr_t)out) & 7) == 0);
   if (vec2) return launch<52, 2>(embed, feat, out, B, Q, C, N, st);

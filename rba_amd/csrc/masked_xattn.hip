@@ -115,10 +115,10 @@ __global__ __launch_bounds__(256) void masked_xattn_kernel(const float* __restri
 
 extern "C" int rba_masked_xattn_f32(const float* q, const float* k, const float* v, const float* mask_logits, float* out,
                                     int B, int Q, int S, int nH, int hd, void* stream) {
-  RBA_CHECK_ARG(q && k && v && out && B >= 0 && Q >= 0 && S >= 1 && nH >= 1 && hd == HD);
-  RBA_CHECK_ARG(nH <= 65535 && B <= 65535);
-  RBA_CHECK_ARG((((uintptr_t)k | (uintptr_t)v) & 15) == 0);
+  RBA_CHECK_ARG(B >= 0 && Q >= 0 && S >= 1 && nH >= 1 && hd == HD && nH <= 65535 && B <= 65535);
   if (B == 0 || Q == 0) return 0;
+  RBA_CHECK_ARG(q && k && v && out && (((uintptr_t)k | (uintptr_t)v) & 15) == 0);
+  rba_begin();
   hipLaunchKernelGGL(masked_xattn_kernel, dim3(Q, nH, B), dim3(256), 0, (hipStream_t)stream, q, k, v, mask_logits, out, Q, S, nH);
   return rba_launch_status();
 }

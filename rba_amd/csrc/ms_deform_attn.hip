@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
 extern "C" int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                           const float* sampling_loc, const float* attn_weight, float* out,
                                           int N, int S, int M, int D, int L, int Lq, int P, void* stream) {
-  RBA_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out);
   RBA_CHECK_ARG(N >= 0 && S >= 1 && M >= 1 && D >= 1 && L >= 1 && Lq >= 0 && P >= 1);
   if (N == 0 || Lq == 0) return 0;
+  RBA_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out);
+  rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (D % 4 == 0) && ((((uintptr_t)value | (uintptr_t)out) & 15) == 0);
   const int vec = vec4 ? 4 : 1;

@@ -179,6 +179,86 @@ __global__ __launch_bounds__(256) void rba_reduce_up4_kernel(const float* __rest
   }
 }
 
+// Fast path: K is a compile-time constant (no per-class guards -> straight-line v_pk_fma with SGPR operands),
+// a ring of U prefetched mask planes keeps U x 1 KiB loads in flight per wave (the compiler otherwise waits
+// vmcnt(0) after every load), and the grid is persistent: `tiles` tiles of 256*VEC pixels are strided over a
+// grid sized to whole multiples of the resident-wave capacity, so no partially filled last round.
+template <int K, int VEC, bool SEM, bool ARG, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_fast_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                 float* __restrict__ rba, float* __restrict__ sem,
+                                                                 int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles) {
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * VEC;
+    if (p0 >= HW) continue;
+    float acc[K][VEC];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+    const float* mp = mask + p0;
+    float buf[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec<VEC>(mp + (int64_t)(u < Q ? u : Q - 1) * HW, buf[u]);
+    const int Qmain = Q / U * U;
+    for (int q0 = 0; q0 < Qmain; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        float s[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = rba_sigmoid(buf[u][i]);
+        const int qn = q + U < Q ? q + U : Q - 1;          // clamped prefetch (re-reads the last plane from L2)
+        load_vec<VEC>(mp + (int64_t)qn * HW, buf[u]);
+        const float* pq = prob + q * K;                    // wave-uniform -> scalar loads, SGPR operands
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float pk = pq[k];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(pk, s[i], acc[k][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                          // tail: Q % U planes, already in the ring
+      const int q = Qmain + u;
+      if (q < Q) {
+        const float* pq = prob + q * K;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float si = rba_sigmoid(buf[u][i]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k][i] = fmaf(pq[k], si, acc[k][i]);
+        }
+      }
+    }
+    rba_epilogue<K, VEC, SEM, ARG>(acc, K, rba, sem, argmax, p0, HW);
+  }
+}
+
+template <int K, int VEC, int U, int WPS>
+int launch_reduce_fast(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q,
+                       int64_t HW, hipStream_t st) {
+  const int64_t per_block = 256 * (int64_t)VEC;
+  const int64_t tiles = (HW + per_block - 1) / per_block;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  // 256 CUs x WPS resident 256-thread blocks (WPS waves per SIMD); round the grid so that every block
+  // gets the same number of tiles when possible
+  const int64_t cap = 256 * WPS;
+  int64_t grid = tiles;
+  if (tiles > cap) {
+    const int64_t rounds = (tiles + cap - 1) / cap;
+    grid = (tiles + rounds - 1) / rounds;
+  }
+#define RBA_L(S, A) \
+  hipLaunchKernelGGL((rba_reduce_fast_kernel<K, VEC, S, A, U, WPS>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW, (int)tiles)
+  if (sem && argmax) RBA_L(true, true);
+  else if (sem) RBA_L(true, false);
+  else if (argmax) RBA_L(false, true);
+  else RBA_L(false, false);
+#undef RBA_L
+  return rba_launch_status();
+}
+
 template <int KMAX, int VEC>
 int launch_reduce(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K,
                   int64_t HW, hipStream_t st) {
@@ -217,12 +297,14 @@ extern "C" int rba_hip_version(void) { return 100; }
 
 extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
                               int Q, int K, int64_t HW, void* stream) {
-  RBA_CHECK_ARG(mask && cls_prob && rba && Q >= 1 && K >= 1 && K <= 160 && HW >= 0);
+  RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 160 && HW >= 0);
   if (HW == 0) return 0;
+  RBA_CHECK_ARG(mask && cls_prob && rba);
+  rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (HW % 4 == 0) && ((((uintptr_t)mask | (uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
-  if (K == 19 && vec4) return launch_reduce<19, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
-  if (K == 20 && vec4) return launch_reduce<20, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
+  if (K == 19 && vec4) return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st);
+  if (K == 20 && vec4) return launch_reduce_fast<20, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st);
   if (K <= 32 && vec4) return launch_reduce<32, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
   if (K <= 32) return launch_reduce<32, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
   if (K <= 80) return launch_reduce<80, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
@@ -231,12 +313,36 @@ extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* r
 
 extern "C" int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_prob, float* rba, float* sem_seg,
                                   int32_t* argmax, int Q, int K, int h, int w, int crop_h, int crop_w, void* stream) {
-  RBA_CHECK_ARG(mask_lowres && cls_prob && rba && Q >= 1 && K >= 1 && K <= 32 && h >= 1 && w >= 1);
+  RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 32 && h >= 1 && w >= 1);
   RBA_CHECK_ARG(crop_h >= 0 && crop_w >= 0 && crop_h <= 4 * h && crop_w <= 4 * w && crop_h <= 65535);
   if (crop_h == 0 || crop_w == 0) return 0;
+  RBA_CHECK_ARG(mask_lowres && cls_prob && rba);
+  rba_begin();
   hipStream_t st = (hipStream_t)stream;
   // vector stores need 16 B aligned rows; the kernel falls back to scalar stores when crop_w % 4 != 0
   RBA_CHECK_ARG((((uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
   if (K == 19) return launch_up4<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st);
   return launch_up4<32>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st);
+}
+
+// Tuning hook (not part of the public ABI in include/rba_hip.h): K = 19 score-only variants of the fast kernel.
+extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, float* rba, int Q, int64_t HW, int variant,
+                                   void* stream) {
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    case 0: return launch_reduce_fast<19, 4, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 1: return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 2: return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 3: return launch_reduce_fast<19, 4, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 4: return launch_reduce_fast<19, 2, 4, 8>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 5: return launch_reduce_fast<19, 2, 8, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 6: return launch_reduce_fast<19, 4, 6, 3>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 7: return launch_reduce_fast<19, 4, 8, 2>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 8: return launch_reduce<19, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, 19, HW, st);
+    case 9: return launch_reduce_fast<19, 2, 4, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 10: return launch_reduce_fast<19, 4, 2, 3>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 11: return launch_reduce_fast<19, 1, 8, 8>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    default: return (int)hipErrorInvalidValue;
+  }
 }

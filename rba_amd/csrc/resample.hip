@@ -50,10 +50,12 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 
 extern "C" int rba_resample_bilinear_f32(const float* in, const float* add, float* out, int C, int h, int w, int H, int W,
                                          void* stream) {
-  RBA_CHECK_ARG(in && out && C >= 0 && h >= 1 && w >= 1 && H >= 0 && W >= 0 && H <= 65535);
+  RBA_CHECK_ARG(C >= 0 && h >= 1 && w >= 1 && H >= 0 && W >= 0 && H <= 65535);
   if (C == 0 || H == 0 || W == 0) return 0;
+  RBA_CHECK_ARG(in && out);
   const int cz = (C + CCHUNK - 1) / CCHUNK;
   RBA_CHECK_ARG(cz <= 65535);
+  rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const int wq = (W + 3) / 4;
   const int threads = wq >= 256 ? 256 : (wq >= 128 ? 128 : 64);

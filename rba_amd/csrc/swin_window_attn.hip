@@ -13,12 +13,12 @@
 
 namespace {
 
-constexpr int HD = 32;
 constexpr int CH = 16;   // keys per softmax chunk
 
+template <int HD>
 __global__ __launch_bounds__(256) void swin_window_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               int H, int W, int Hp, int Wp, int nH, int ws, int shift) {
+                                                               int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int N = ws * ws;
   float* Ks = lds;                 // [N][HD]
@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const float* __re
   // padded query rows are dropped by the crop, but keep the lanes busy-free: nothing to do for them
   if (!valid) return;
 
-  const float scale = 0.17677669529663687f;   // head_dim^-0.5, head_dim = 32
   float q[HD];
   {
     const float4* p = reinterpret_cast<const float4*>(qkv_b + ((int64_t)rr * W + cc) * tok_stride + h * HD);
@@ -138,16 +137,23 @@ __global__ __launch_bounds__(256) void swin_window_attn_kernel(const float* __re
 
 extern "C" int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias, float* out,
                                         int B, int H, int W, int nH, int hd, int ws, int shift, void* stream) {
-  RBA_CHECK_ARG(qkv && qkv_bias && bias && out && B >= 0 && H >= 1 && W >= 1 && nH >= 1 && hd == HD);
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && nH >= 1 && (hd == 16 || hd == 32 || hd == 64));
   RBA_CHECK_ARG(ws >= 1 && ws * ws <= 256 && shift >= 0 && shift < ws);
-  RBA_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_bias | (uintptr_t)out) & 15) == 0);
   if (B == 0) return 0;
+  RBA_CHECK_ARG(qkv && qkv_bias && bias && out);
+  RBA_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_bias | (uintptr_t)out) & 15) == 0);
   const int Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;
   const int N = ws * ws;
   RBA_CHECK_ARG((int64_t)B * nH <= 65535 && Hp / ws <= 65535);
   const int threads = (N + 63) / 64 * 64;
-  const size_t shm = (size_t)(2 * N * HD) * sizeof(float) + (size_t)N * sizeof(int);
-  hipLaunchKernelGGL(swin_window_attn_kernel, dim3(Wp / ws, Hp / ws, B * nH), dim3(threads), shm, (hipStream_t)stream,
-                     qkv, qkv_bias, bias, out, H, W, Hp, Wp, nH, ws, shift);
+  rba_begin();
+  const size_t shm = (size_t)(2 * N * hd) * sizeof(float) + (size_t)N * sizeof(int);
+  const float scale = (float)(1.0 / sqrt((double)hd));   // head_dim ** -0.5 in double, then fp32 (swin.py:103,145)
+  const dim3 grid(Wp / ws, Hp / ws, B * nH);
+#define RBA_L(D) hipLaunchKernelGGL(swin_window_attn_kernel<D>, grid, dim3(threads), shm, (hipStream_t)stream, qkv, qkv_bias, bias, out, H, W, Hp, Wp, nH, ws, shift, scale)
+  if (hd == 16) RBA_L(16);
+  else if (hd == 32) RBA_L(32);
+  else RBA_L(64);
+#undef RBA_L
   return rba_launch_status();
 }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time the K1 tuning variants (rba_reduce_f32_tune) on the BASELINE C2 micro-benchmark tensors:
+mask_pred ~ N(0,5^2) [100,1024,2048], mask_cls ~ N(0,3^2) [100,20], seed 0.  Interleaved rounds, HIP events."""
+import ctypes
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from rba_amd import _lib
+
+lib = _lib.load()
+fn = lib.rba_reduce_f32_tune
+fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+fn.restype = ctypes.c_int
+Q, H, W = 100, 1024, 2048
+g = torch.Generator(device="cuda").manual_seed(0)
+mask = torch.randn(Q, H, W, device="cuda", generator=g) * 5
+prob = torch.softmax(torch.randn(Q, 20, device="cuda", generator=g) * 3, -1)[:, :19].contiguous()
+ref = None
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(12))
+times = {v: [] for v in variants}
+outs = {}
+st = torch.cuda.current_stream().cuda_stream
+for rnd in range(6):
+    for v in variants:
+        rba = torch.empty(H, W, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(mask.data_ptr(), prob.data_ptr(), rba.data_ptr(), Q, H * W, v, st)
+        e1.record()
+        torch.cuda.synchronize()
+        assert rc == 0, (v, rc)
+        if rnd:
+            times[v].append(e0.elapsed_time(e1) * 1e3)
+        outs[v] = rba
+base = outs[8] if 8 in outs else outs[variants[0]]
+nbytes = 4 * Q * H * W + 4 * Q * 19 + 4 * H * W
+for v in variants:
+    t = sorted(times[v])
+    med = t[len(t) // 2]
+    print(f"variant {v:2d}: median {med:7.1f} us  min {t[0]:7.1f} us  {nbytes / med / 1e3:7.0f} GB/s ({nbytes / med / 1e3 / 80:.1f}% of 8 TB/s)  "
+          f"max|d vs base| {(outs[v] - base).abs().max().item():.2e}")
