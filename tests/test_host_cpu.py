@@ -1,0 +1,183 @@
+"""CPU (no GPU): the C ABI loads and exports what include/rba_hip.h declares; host logic (config reader, arch /
+checkpoint contract, error behaviour of the op wrappers without a device); multi-process metric exchange on gloo."""
+import ctypes
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from rba_amd import arch as A
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(REPO, "include", "rba_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"\bint\s+(rba_\w+)\s*\(", src)
+
+
+def test_cabi_exports_every_declared_symbol():
+    from rba_amd import _lib
+    names = header_functions()
+    assert len(names) >= 8 and "rba_reduce_f32" in names and "rba_ms_deform_attn_fwd_f32" in names
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rba_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signatures out of sync with the header"
+    assert _lib.load().rba_hip_version() >= 100
+
+
+def test_ops_have_no_cpu_path():
+    from rba_amd import ops
+    from rba_amd._lib import RbaHipError
+    with pytest.raises(RbaHipError, match="no CPU path"):
+        ops.rba_reduce(torch.zeros(2, 4, 4), torch.zeros(2, 19))
+    with pytest.raises(RbaHipError):
+        ops.ms_deform_attn_forward(torch.zeros(1, 4, 2, 4), torch.ones(1, 2, dtype=torch.long), torch.zeros(1, dtype=torch.long),
+                                   torch.zeros(1, 4, 2, 1, 2, 2), torch.zeros(1, 4, 2, 1, 2))
+    with pytest.raises(RbaHipError):
+        ops.resample_bilinear(torch.zeros(1, 2, 2), (4, 4))
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under rba_amd/ may import it"""
+    for root, _, files in os.walk(os.path.join(REPO, "rba_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(root, f)
+
+
+def test_relative_position_index_matches_reference(golden):
+    from rba_amd.modeling.backbone.swin import relative_position_index
+    g = golden("g3_swin_parts")
+    assert np.array_equal(relative_position_index(6).numpy(), g["wa_sd.relative_position_index"])
+
+
+@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90"])
+def test_model_state_dict_contract(golden, name):
+    """our module tree has exactly the reference's state-dict keys and shapes (the model_final.pth contract)"""
+    from rba_amd.maskformer_model import MaskFormer
+    g = golden(name)
+    m = MaskFormer(A.ARCHS[str(g["arch"])])
+    sd = m.state_dict()
+    assert sorted(sd) == list(g["sd_keys"])
+    assert [",".join(map(str, sd[k].shape)) for k in sorted(sd)] == list(g["sd_shapes"])
+
+
+def test_checkpoint_loading(tmp_path):
+    from rba_amd.checkpoint import load_checkpoint
+    from rba_amd.maskformer_model import MaskFormer
+    a = A.complete(A.ARCHS["tiny1"])
+    sd = A.seeded_weights(a, 3)
+    # .pth as Detectron2 writes it, DDP "module." prefix, extra criterion buffer
+    pth = tmp_path / "model_final.pth"
+    torch.save({"model": {"module." + k: v for k, v in sd.items()} | {"module.criterion.empty_weight": torch.ones(20)},
+                "iteration": 7}, pth)
+    m = load_checkpoint(MaskFormer(a), str(pth))
+    k = "sem_seg_head.predictor.class_embed.bias"
+    assert torch.equal(m.state_dict()[k], sd[k])
+    # .pkl with numpy arrays (tools/convert-pretrained-swin-model-to-d2.py layout)
+    pkl = tmp_path / "model_final.pkl"
+    with open(pkl, "wb") as f:
+        pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "third_party", "matching_heuristics": True}, f)
+    m2 = load_checkpoint(MaskFormer(a), str(pkl))
+    assert torch.equal(m2.state_dict()[k], sd[k])
+    # legacy names: static_query -> query_feat (decoder.py:237-258), pixel-decoder keys directly under the head (head.py:31-53)
+    old = {}
+    for kk, v in sd.items():
+        kk = kk.replace("query_feat", "static_query")
+        kk = kk.replace("sem_seg_head.pixel_decoder.", "sem_seg_head.")
+        old[kk] = v
+    m3 = load_checkpoint(MaskFormer(a), old)
+    assert torch.equal(m3.state_dict()["sem_seg_head.predictor.query_feat.weight"], sd["sem_seg_head.predictor.query_feat.weight"])
+    assert torch.equal(m3.state_dict()["sem_seg_head.pixel_decoder.mask_features.weight"],
+                       sd["sem_seg_head.pixel_decoder.mask_features.weight"])
+    # failures are loud
+    bad = dict(sd)
+    bad.pop(k)
+    with pytest.raises(RuntimeError, match="missing"):
+        load_checkpoint(MaskFormer(a), bad)
+    bad = dict(sd)
+    bad[k] = torch.zeros(7)
+    with pytest.raises(RuntimeError, match="shape mismatch"):
+        load_checkpoint(MaskFormer(a), bad)
+
+
+def test_config_reader(tmp_path):
+    from rba_amd.config import load_cfg
+    base = tmp_path / "base.yaml"
+    base.write_text("MODEL:\n  SWIN:\n    EMBED_DIM: 128\n    DEPTHS: [2, 2, 18, 2]\n    NUM_HEADS: [4, 8, 16, 32]\n    WINDOW_SIZE: 12\n"
+                    "  MASK_FORMER:\n    DEC_LAYERS: 10\nINPUT:\n  MIN_SIZE_TRAIN: !!python/object/apply:eval [\"[1, 2]\"]\n")
+    child = tmp_path / "child.yaml"
+    child.write_text("_BASE_: base.yaml\nMODEL:\n  MASK_FORMER:\n    DEC_LAYERS: 2\n  SEM_SEG_HEAD:\n"
+                     "    DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES: [res5]\n")
+    cfg = load_cfg(str(child), ["OUTPUT_DIR", "output/"])
+    assert cfg.OUTPUT_DIR == "output/" and cfg.MODEL.SWIN.EMBED_DIM == 128 and cfg.MODEL.MASK_FORMER.DEC_LAYERS == 2
+    assert A.arch_from_cfg(cfg) == A.complete(A.ARCHS["swin_b_1dl"])
+    # unsupported features fail loudly instead of silently building something else
+    cfg.MODEL.MASK_FORMER.PRE_NORM = True
+    with pytest.raises(NotImplementedError):
+        A.arch_from_cfg(cfg)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ckpts"), reason="reference tree not present on this box")
+def test_reference_ckpt_configs_parse():
+    from rba_amd.config import load_cfg
+    want = {"swin_b_1dl": "swin_b_1dl", "swin_b_1dl_rba_ood_coco": "swin_b_1dl", "swin_b_1dl_rba_ood_map_coco": "swin_b_1dl",
+            "swin_l_1dl": "swin_l_1dl", "swin_l_1dl_rba_ood_map_coco": "swin_l_1dl"}
+    for d, name in want.items():
+        a = A.arch_from_cfg(load_cfg(f"/root/reference/ckpts/{d}/config.yaml"))
+        assert a == A.complete(A.ARCHS[name]), d
+
+
+def test_shard_indices():
+    from rba_amd.distributed import shard_indices
+    for n in (0, 1, 16, 17):
+        for world in (1, 2, 8):
+            parts = [shard_indices(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+_WORKER = r'''
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from rba_amd import distributed as D
+from rba_amd.metrics import ood_metrics, select_labelled
+rank, world, _ = D.init_from_env("gloo")
+rng = np.random.RandomState(0)
+n_img = 5
+gts = rng.choice([0, 1, 255], size=(n_img, 40, 50), p=[0.85, 0.05, 0.10])
+scores = (rng.randn(n_img, 40, 50) + 1.5 * (gts == 1)).astype(np.float32)
+mine = D.shard_indices(n_img, rank, world)                      # ragged: 3 + 2 images
+s, y = select_labelled(torch.from_numpy(scores[mine]), torch.from_numpy(gts[mine]))
+pooled = D.pooled_ood_metrics(s, y)
+hist = D.histogram_ood_metrics(s, y)
+single = ood_metrics(*select_labelled(torch.from_numpy(scores), torch.from_numpy(gts)))
+# order of pooling differs from the single-process concatenation but the metrics are rank statistics: identical
+ok = all(abs(pooled[k] - single[k]) < 1e-12 for k in single) and all(abs(hist[k] - single[k]) < 2e-3 for k in single)
+g = D.all_gather_variable(torch.arange(rank + 2, dtype=torch.float32))
+ok = ok and g.tolist() == [0.0, 1.0, 0.0, 1.0, 2.0]
+print(json.dumps({"rank": rank, "ok": bool(ok), "pooled": pooled, "single": single, "hist": hist}), flush=True)
+torch.distributed.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_metric_exchange_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), REPO],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('"ok": true') == 2

@@ -120,3 +120,43 @@ def test_metrics(golden, case):
     g = golden("g6_metrics")
     r = ref_metrics.evaluate_ood(g[case + "_score"], g[case + "_gt"])
     np.testing.assert_allclose([r["auroc"], r["aupr"], r["fpr95"]], g[case + "_metrics"], rtol=0, atol=1e-12)
+
+
+def test_c_oracle_k1_k2(golden):
+    """the plain-C restatement (oracle/c/rba_oracle.c) against the same fixtures"""
+    from oracle import c_oracle
+    g = golden("g1_rba_reduce")
+    prob = ref_ops.class_probs(T(g["mask_cls"])).numpy()
+    sem, rba, arg = c_oracle.rba_reduce(g["mask_pred"], prob)
+    close(sem, g["sem_seg"], 5e-6)
+    close(rba, g["rba"], 5e-6)
+    gap = np.sort(g["sem_seg"], axis=0)
+    assert not ((arg != g["argmax"]) & ((gap[-1] - gap[-2]) > 1e-5)).any()
+    g = golden("g2_ms_deform_attn")
+    for tag in ("a32", "b"):
+        sh = g["a_shapes"] if tag == "a32" else g["b_shapes"]
+        lsi = np.concatenate(([0], np.cumsum(sh.prod(1))[:-1]))
+        out = c_oracle.ms_deform_attn(g[tag + "_value"], sh, lsi, g[tag + "_loc"], g[tag + "_w"])
+        close(out, g[tag + "_out"], 5e-6)
+
+
+@pytest.mark.parametrize("fixture,arch_name", [("g5_swin_b_1dl_1024x2048", "swin_b_1dl"),
+                                               ("g5_swin_b_9dl_720x1280", "swin_b_9dl")])
+def test_end_to_end_full_size(golden, fixture, arch_name):
+    """BASELINE configs C2 / C5 at full size: oracle vs sampled outputs of the reference's own modules (about 10 s each)."""
+    g = golden(fixture)
+    a = A.complete(A.ARCHS[arch_name])
+    sd = A.seeded_weights(a, int(g["seed"]))
+    h, w = (int(v) for v in g["hw"])
+    gen = torch.Generator().manual_seed(int(g["img_seed"]))
+    image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
+    o = ref_model.forward(image, sd, a)
+    ys, xs, ys4, xs4 = (T(g[k]).long() for k in ("ys", "xs", "ys4", "xs4"))
+    close(o["pred_logits"], g["pred_logits"], 2e-5)
+    close(o["pred_masks"][:, ys4, xs4], g["pred_masks_s"], 2e-4)
+    close(o["rba"][ys, xs], g["rba_s"], 2e-5)
+    close(o["sem_seg"][:, ys, xs], g["sem_s"], 2e-5)
+    top2 = np.sort(g["sem_s"], axis=0)
+    flips = o["argmax"][ys, xs].numpy() != g["argmax_s"]
+    assert not (flips & ((top2[-1] - top2[-2]) > 1e-4)).any()
+    assert abs(o["rba"].double().sum().item() - g["rba_stats"][0]) < 1e-5 * h * w
