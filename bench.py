@@ -39,6 +39,9 @@ def parse():
                     help="fullres: materialise the x4-upsampled mask logits and run the HBM-bound K1 the metric names; "
                          "up4: K1 reads the low-res logits and upsamples on the fly (less traffic, compute bound)")
     ap.add_argument("--graph", type=int, default=0, help="replay the forward from a captured hipGraph (0 = eager)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="images per GPU per step, each on its own HIP stream (concurrent kernels fill under-occupied "
+                         "stage-3/4 launches: +7..10 %% images/s at 2-3, but K1's live timing then includes contention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-images", type=int, default=4, help="distinct resident synthetic images cycled through")
     return ap.parse_args()
@@ -95,11 +98,16 @@ def main():
     k1_events = []
 
     # ---- the step: everything after the image is resident, up to the RbA map
-    static_in = images[0].clone()
+    S = max(1, args.streams)
+    if S > 1 and args.graph:
+        raise SystemExit("--graph and --streams > 1 are mutually exclusive")
+    static_ins = [images[i % len(images)].clone() for i in range(S)]
+    static_in = static_ins[0]
+    side_streams = [torch.cuda.Stream() for _ in range(S - 1)]
     k1_probe = {}
 
-    def forward_once(record=True):
-        mask_cls, mask_pred, sizes, padded = model.predict([{"image": static_in}])
+    def forward_once(record=True, src=None):
+        mask_cls, mask_pred, sizes, padded = model.predict([{"image": static_in if src is None else src}])
         prob = torch.softmax(mask_cls[0], dim=-1)[..., :-1].contiguous()
         if args.k1 == "up4":
             low = mask_pred[0].contiguous()
@@ -150,9 +158,18 @@ def main():
         if graph is not None:
             graph.replay()
             return static_out
+        main = torch.cuda.current_stream()
+        for j, st in enumerate(side_streams):                           # images 1..S-1 of this step, concurrently
+            st.wait_stream(main)
+            with torch.cuda.stream(st), torch.no_grad():
+                static_ins[j + 1].copy_(images[(i + j + 1) % len(images)], non_blocking=True)
+                forward_once(src=static_ins[j + 1])
+                k1_events.append(k1_probe["ev"])
         with torch.no_grad():
             r = forward_once()
         k1_events.append(k1_probe["ev"])
+        for st in side_streams:
+            main.wait_stream(st)
         return r
 
     def barrier():
@@ -217,10 +234,18 @@ def main():
         torch.cuda.synchronize()
         exch_ms = (time.perf_counter() - t1) * 1e3
 
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "k1_pmc.json")
+    if args.k1 == "fullres" and os.path.exists(pmc):
+        with open(pmc) as f:
+            pj = json.load(f)
+        if pj.get("algorithmic_bytes_per_launch") == alg_bytes:        # same kernel, same shape
+            traffic = pj["traffic_bytes_per_launch"]
+
     if rank == 0:
         res = {
             "metric": "images/sec @1024x2048 Swin-B-1dl (RbA inference hot path)",
-            "value": world * args.steps / elapsed,
+            "value": world * args.steps * S / elapsed,
             "unit": "images/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -231,13 +256,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per step "
+            "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per stream per step "
                                    f"(BASELINE.json configs[1]); random-init seeded weights",
-                       "images_per_gpu_per_step": 1, "k1_variant": args.k1, "hip_graph": graph is not None,
+                       "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None,
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/k1_pmc.json)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg_ms,
                          "min_launch_ms": k1_ms[0], "launches_timed": len(k1_ms)},
         }
         if exch_ms is not None:

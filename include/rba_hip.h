@@ -23,6 +23,8 @@
  *   rba_mask_logits_f32         <- torch.einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479)
  *   rba_swin_window_attn_f32    <- WindowAttention core + window_partition/reverse + roll + pad
  *                                  (backbone/swin.py:44-71, 131-171, 251-284)
+ *   rba_group_norm_f32          <- GroupNorm(32) [+ ReLU] behind Detectron2's Conv2d(norm=get_norm("GN"), activation)
+ *                                  (pixel_decoder/msdeformattn.py:222-235, 278-297)
  */
 #ifndef RBA_HIP_H
 #define RBA_HIP_H
@@ -80,9 +82,21 @@ int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B
  * window reverse, un-shift and crop.
  * qkv [B,H*W,3,nH,hd] = Linear(norm1(x)) of the UNPADDED tokens; padded tokens take qkv_bias [3*nH*hd]
  * (= Linear(0)).  bias [nH,ws*ws,ws*ws] gathered relative-position bias.  shift = 0 or ws/2.
+ * bias_frag: optional (NULL = unused) copy of `bias` permuted by rba_swin_bias_fragments_f32 into the order the
+ * MFMA path's lanes consume it (coalesced loads); computed once per weight load.
  * out [B,H*W,nH*hd] (attention output before the proj Linear).  hd in {16,32,64}; ws*ws <= 256. */
-int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias, float* out,
-                             int B, int H, int W, int nH, int hd, int ws, int shift, void* stream);
+int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias, const float* bias, const float* bias_frag,
+                             float* out, int B, int H, int W, int nH, int hd, int ws, int shift, void* stream);
+/* bias [nH,ws*ws,ws*ws] -> frag with rba_swin_bias_fragments_elems(nH, ws) floats. */
+int64_t rba_swin_bias_fragments_elems(int nH, int ws);
+int rba_swin_bias_fragments_f32(const float* bias, float* frag, int nH, int ws, void* stream);
+
+/* GroupNorm over x [B,C,HW] with G groups (statistics over (C/G) x HW), y = (x-mean)*rstd*gamma[c] + beta[c],
+ * optional ReLU.  `workspace` must hold rba_group_norm_workspace_bytes(B,C,HW,G) bytes (per-chunk moments).
+ * x and y may alias. */
+int64_t rba_group_norm_workspace_bytes(int B, int C, int HW, int G);
+int rba_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* workspace,
+                       int B, int C, int HW, int G, float eps, int relu, void* stream);
 
 #ifdef __cplusplus
 }

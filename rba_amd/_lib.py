@@ -23,7 +23,11 @@ SIGNATURES = {
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_mask_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],
-    "rba_swin_window_attn_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_swin_window_attn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_swin_bias_fragments_elems": [_i, _i],
+    "rba_swin_bias_fragments_f32": [_vp, _vp, _i, _i, _vp],
+    "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],
+    "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
 _lib = None
@@ -53,7 +57,7 @@ def load():
         except AttributeError as e:
             raise RbaHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_elems")) else ctypes.c_int
     _lib = lib
     return lib
 

@@ -1,0 +1,126 @@
+// GroupNorm (+ optional ReLU) for the pixel decoder's conv -> GN(32) [-> ReLU] wrappers (reference:
+// pixel_decoder/msdeformattn.py:222-235, 278-297 through Detectron2's Conv2d/get_norm("GN")).
+//
+// The library kernel reduces each of the 32 groups with ONE workgroup (32 workgroups on a 256-CU part:
+// 2.3 ms per image in the first profile).  Here a group (C/G channels x HW, contiguous in NCHW) is cut into
+// 64 KiB chunks: pass 1 writes per-chunk (n, mean, M2), pass 2 merges the chunk moments with Chan's formula in
+// double precision and normalises its own chunk.  HBM-bound: x is read twice (second read mostly from
+// Infinity Cache) and written once.
+#include "common.h"
+#include "../../include/rba_hip.h"
+
+namespace {
+
+constexpr int CHUNK = 16384;   // elements per workgroup (64 KiB), 256 threads x 16 float4
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RBA_WAVE);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ ws, int64_t gsize,
+                                                       int splits) {
+  const int s = blockIdx.x, g = blockIdx.y;
+  const int64_t lo = (int64_t)s * CHUNK, hi = lo + CHUNK < gsize ? lo + CHUNK : gsize;
+  const float* p = x + (int64_t)g * gsize;
+  float sum = 0.f, sq = 0.f;
+  if ((gsize & 3) == 0 && (((uintptr_t)p) & 15) == 0) {
+    for (int64_t i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      sum += (v.x + v.y) + (v.z + v.w);
+      sq = fmaf(v.x, v.x, sq); sq = fmaf(v.y, v.y, sq); sq = fmaf(v.z, v.z, sq); sq = fmaf(v.w, v.w, sq);
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const float v = p[i]; sum += v; sq = fmaf(v, v, sq); }
+  }
+  __shared__ double sh[8];
+  double ds = wave_sum_d((double)sum), dq = wave_sum_d((double)sq);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[wave] = ds; sh[4 + wave] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ds = sh[0] + sh[1] + sh[2] + sh[3];
+    dq = sh[4] + sh[5] + sh[6] + sh[7];
+    const double n = (double)(hi - lo);
+    const double mean = ds / n;
+    double m2 = dq - ds * mean;
+    float* o = ws + ((int64_t)g * splits + s) * 3;
+    o[0] = (float)n; o[1] = (float)mean; o[2] = (float)(m2 > 0 ? m2 : 0);
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ ws,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int64_t gsize, int splits, int HW,
+                                                       int cpg, int G, float eps) {
+  const int s = blockIdx.x, g = blockIdx.y;
+  __shared__ float sh_mean, sh_rstd;
+  if (threadIdx.x < 64) {   // one wave merges the chunk moments (Chan et al.) in double
+    const float* w = ws + (int64_t)g * splits * 3;
+    double n = 0, nm = 0;
+    for (int i = threadIdx.x; i < splits; i += 64) { n += w[3 * i]; nm += (double)w[3 * i] * w[3 * i + 1]; }
+    n = wave_sum_d(n); nm = wave_sum_d(nm);
+    const double mean = nm / n;
+    double m2 = 0;
+    for (int i = threadIdx.x; i < splits; i += 64) {
+      const double d = (double)w[3 * i + 1] - mean;
+      m2 += (double)w[3 * i + 2] + (double)w[3 * i] * d * d;
+    }
+    m2 = wave_sum_d(m2);
+    if (threadIdx.x == 0) { sh_mean = (float)mean; sh_rstd = (float)(1.0 / sqrt(m2 / n + (double)eps)); }
+  }
+  __syncthreads();
+  const float mean = sh_mean, rstd = sh_rstd;
+  const int64_t lo = (int64_t)s * CHUNK, hi = lo + CHUNK < gsize ? lo + CHUNK : gsize;
+  const float* p = x + (int64_t)g * gsize;
+  float* q = y + (int64_t)g * gsize;
+  const int c0 = (g % G) * cpg;   // first channel of this group (batch folded into g)
+  if ((HW & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)q)) & 15) == 0) {
+    for (int64_t i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      const int c = c0 + (int)(i / HW);   // HW % 4 == 0: the 4 elements share a channel
+      const float a = gamma[c] * rstd, b = beta[c] - mean * a;
+      float4 v = *reinterpret_cast<const float4*>(p + i);
+      v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
+      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(q + i) = v;
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+      const int c = c0 + (int)(i / HW);
+      const float a = gamma[c] * rstd, b = beta[c] - mean * a;
+      float v = fmaf(p[i], a, b);
+      q[i] = RELU ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t rba_group_norm_workspace_bytes(int B, int C, int HW, int G) {
+  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
+  const int64_t gsize = (int64_t)(C / G) * HW;
+  const int64_t splits = (gsize + CHUNK - 1) / CHUNK;
+  return (int64_t)B * G * splits * 3 * (int64_t)sizeof(float);
+}
+
+extern "C" int rba_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* workspace,
+                                  int B, int C, int HW, int G, float eps, int relu, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && C >= 1 && HW >= 0 && G >= 1 && C % G == 0);
+  if (B == 0 || HW == 0) return 0;
+  RBA_CHECK_ARG(x && gamma && beta && y && workspace);
+  const int cpg = C / G;
+  const int64_t gsize = (int64_t)cpg * HW;
+  const int64_t splits = (gsize + CHUNK - 1) / CHUNK;
+  RBA_CHECK_ARG(splits <= 0x7fffffff && (int64_t)B * G <= 65535);
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)splits, B * G);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, workspace, gsize, (int)splits);
+  if (relu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, st, x, workspace, gamma, beta, y, gsize, (int)splits, HW, cpg, G, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, st, x, workspace, gamma, beta, y, gsize, (int)splits, HW, cpg, G, eps);
+  return rba_launch_status();
+}

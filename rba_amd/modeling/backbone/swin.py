@@ -41,8 +41,9 @@ class WindowAttention(nn.Module):
         if self._bias_cache is None or self._bias_cache[0] != key:
             N = self.window_size ** 2
             b = t[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
-            self._bias_cache = (key, b)
-        return self._bias_cache[1]
+            frag = ops.swin_bias_fragments(b, self.window_size) if b.is_cuda else None
+            self._bias_cache = (key, b, frag)
+        return self._bias_cache[1], self._bias_cache[2]
 
 
 class Mlp(nn.Module):
@@ -66,8 +67,9 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn
         y = F.layer_norm(x, (x.shape[-1],), self.norm1.weight, self.norm1.bias, self.norm1.eps)
         qkv = F.linear(y, a.qkv.weight, a.qkv.bias)
-        y = ops.swin_window_attn(qkv, a.qkv.bias, a.gathered_bias(), H, W, self.num_heads, self.window_size,
-                                 self.shift_size)
+        bias, bias_frag = a.gathered_bias()
+        y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size,
+                                 bias_frag=bias_frag)
         x = x + F.linear(y, a.proj.weight, a.proj.bias)
         y = F.layer_norm(x, (x.shape[-1],), self.norm2.weight, self.norm2.bias, self.norm2.eps)
         y = F.gelu(F.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))

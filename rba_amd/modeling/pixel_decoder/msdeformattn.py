@@ -26,7 +26,7 @@ class ConvNorm(nn.Module):
     def forward(self, x):
         x = F.conv2d(x, self.weight, self.bias, padding=self.padding)
         if self.norm is not None:
-            x = F.group_norm(x, 32, self.norm.weight, self.norm.bias, self.norm.eps)
+            return ops.group_norm(x.contiguous(), 32, self.norm.weight, self.norm.bias, self.norm.eps, relu=self.relu)
         return F.relu(x) if self.relu else x
 
 
@@ -122,7 +122,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
         srcs, pos = [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
             x = features[f].float()
-            srcs.append(self.input_proj[idx](x))
+            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+            srcs.append(ops.group_norm(F.conv2d(x, conv.weight, conv.bias).contiguous(), 32, gn.weight, gn.bias, gn.eps))
             pos.append(self.pe_layer(x))
         y, shapes = self.transformer(srcs, pos)
         B = y.shape[0]

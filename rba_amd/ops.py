@@ -163,7 +163,19 @@ def mask_logits(embed, feat):
     return out
 
 
-def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shift):
+def swin_bias_fragments(rel_bias, window_size):
+    """[nH,N,N] gathered relative-position bias -> the MFMA-fragment-ordered copy K5 reads with coalesced loads."""
+    lib = _lib.load()
+    _chk(rel_bias, "rel_bias", dim=3)
+    nH = rel_bias.shape[0]
+    n = lib.rba_swin_bias_fragments_elems(nH, window_size)
+    frag = torch.empty(n, dtype=torch.float32, device=rel_bias.device)
+    _lib.check(lib.rba_swin_bias_fragments_f32(_p(rel_bias), _p(frag), nH, window_size, _stream()),
+               "rba_swin_bias_fragments_f32")
+    return frag
+
+
+def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shift, bias_frag=None):
     """K5.  qkv [B,H*W,3*C] = Linear(norm1(x)) on un-padded tokens, qkv_bias [3*C], rel_bias [nH,N,N] ->
     attention output [B,H*W,C] (before proj).  swin.py:131-171 + :251-284 + :413-440."""
     lib = _lib.load()
@@ -178,7 +190,29 @@ def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shif
     N = window_size * window_size
     if tuple(rel_bias.shape) != (num_heads, N, N) or qkv_bias.numel() != C3:
         raise RbaHipError("rel_bias must be [nH, ws*ws, ws*ws] and qkv_bias [3C]")
+    if bias_frag is not None:
+        _chk(bias_frag, "bias_frag", dim=1)
+        if bias_frag.numel() != lib.rba_swin_bias_fragments_elems(num_heads, window_size):
+            raise RbaHipError("bias_frag has the wrong size")
     out = torch.empty((B, L, C), dtype=torch.float32, device=qkv.device)
-    _lib.check(lib.rba_swin_window_attn_f32(_p(qkv), _p(qkv_bias), _p(rel_bias), _p(out), B, H, W, num_heads, hd,
-                                            window_size, shift, _stream()), "rba_swin_window_attn_f32")
+    _lib.check(lib.rba_swin_window_attn_f32(_p(qkv), _p(qkv_bias), _p(rel_bias), _p(bias_frag), _p(out), B, H, W,
+                                            num_heads, hd, window_size, shift, _stream()), "rba_swin_window_attn_f32")
     return out
+
+
+def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
+    """GroupNorm (+ReLU) of x [B,C,h,w] -- the norm/activation of Detectron2's Conv2d wrapper
+    (msdeformattn.py:222-235, 278-297)."""
+    lib = _lib.load()
+    _chk(x, "x", dim=4)
+    _chk(weight, "weight", dim=1)
+    _chk(bias, "bias", dim=1)
+    B, C, h, w = x.shape
+    if C % num_groups or weight.numel() != C or bias.numel() != C:
+        raise RbaHipError("channels must be divisible by num_groups and match weight/bias")
+    nbytes = lib.rba_group_norm_workspace_bytes(B, C, h * w, num_groups)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.rba_group_norm_f32(_p(x), _p(weight), _p(bias), _p(y), _p(ws), B, C, h * w, num_groups, float(eps),
+                                      int(bool(relu)), _stream()), "rba_group_norm_f32")
+    return y

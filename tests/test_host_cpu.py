@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     src = open(os.path.join(REPO, "include", "rba_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return re.findall(r"\bint\s+(rba_\w+)\s*\(", src)
+    return re.findall(r"\b(?:int|int64_t)\s+(rba_\w+)\s*\(", src)
 
 
 def test_cabi_exports_every_declared_symbol():

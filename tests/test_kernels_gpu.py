@@ -243,3 +243,21 @@ def test_k5_window_attn_core(ops, H, W, ws, nH, shift):
     bias = table[ref_ops.relative_position_index(ws).view(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
     out = ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift)
     assert maxerr(out, ref) < 1e-5
+    frag = ops.swin_bias_fragments(dev(bias), ws)            # coalesced fragment-ordered bias: same result
+    out2 = ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag)
+    assert torch.equal(out2, out)
+
+
+# ----------------------------------------------------------------------------------- GroupNorm
+@pytest.mark.parametrize("B,C,h,w,relu", [(1, 256, 32, 64, False), (1, 256, 64, 128, True), (2, 64, 15, 23, True),
+                                           (1, 256, 256, 512, True)])
+def test_group_norm(ops, B, C, h, w, relu):
+    g = torch.Generator().manual_seed(C + h)
+    x = torch.randn(B, C, h, w, generator=g) * 3 + 1.5
+    wt, bs = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x.double(), 32, wt.double(), bs.double(), 1e-5)
+    ref = F.relu(ref) if relu else ref
+    out = ops.group_norm(dev(x), 32, dev(wt), dev(bs), 1e-5, relu)
+    assert maxerr(out, ref) < 2e-5
+    ref32 = F.group_norm(x, 32, wt, bs, 1e-5)       # what the reference runs on CPU
+    assert maxerr(out, F.relu(ref32) if relu else ref32) < 2e-5
