@@ -19,7 +19,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 mask = torch.randn(Q, H, W, device="cuda", generator=g) * 5
 prob = torch.softmax(torch.randn(Q, 20, device="cuda", generator=g) * 3, -1)[:, :19].contiguous()
 ref = None
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(12))
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 12, 13, 14]
 times = {v: [] for v in variants}
 outs = {}
 st = torch.cuda.current_stream().cuda_stream
@@ -36,6 +36,7 @@ for rnd in range(6):
             times[v].append(e0.elapsed_time(e1) * 1e3)
         outs[v] = rba
 base = outs[8] if 8 in outs else outs[variants[0]]
+if 2 in outs: base = outs[2]
 nbytes = 4 * Q * H * W + 4 * Q * 19 + 4 * H * W
 for v in variants:
     t = sorted(times[v])
