@@ -40,17 +40,19 @@ int rba_hip_version(void);
 
 /* K1.  mask [Q,HW] full-resolution mask logits; cls_prob [Q,K] = softmax(class logits)[:, :-1].
  *   sem[k,p]  = sum_q cls_prob[q,k] * sigmoid(mask[q,p])      (ascending-q fp32 FMA order)
- *   rba[p]    = - sum_k tanh(sem[k,p])
+ *   rba[p]    = - sum_k tanh(sem[k,p])                     (score_mode 0, RbA: evaluate_ood.py:143-150)
+ *             = - logsumexp_k sem[k,p]                     (score_mode 1, energy: evaluate_ood.py:152-159)
+ *             = - sum_k sem[k,p]                           (score_mode 2, negative logit sum: support.py:115-132)
  *   argmax[p] = first k maximising sem[k,p]
  * rba [HW] required; sem_seg [K,HW] and argmax [HW] (int32) optional (NULL = not written).  1 <= K <= 160. */
 int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
-                   int Q, int K, int64_t HW, void* stream);
+                   int Q, int K, int64_t HW, int score_mode, void* stream);
 
 /* K1 fused with the x4 bilinear upsample (align_corners=False) in front and the crop behind it.
  * mask_lowres [Q,h,w]; the virtual full-resolution map is [Q,4h,4w]; outputs cover rows < crop_h and
  * columns < crop_w of it: rba [crop_h,crop_w], sem_seg [K,crop_h,crop_w] or NULL, argmax or NULL. */
 int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_prob, float* rba, float* sem_seg,
-                       int32_t* argmax, int Q, int K, int h, int w, int crop_h, int crop_w, void* stream);
+                       int32_t* argmax, int Q, int K, int h, int w, int crop_h, int crop_w, int score_mode, void* stream);
 
 /* Bilinear resample, align_corners=False, no antialias (ATen upsample_bilinear2d semantics):
  * in [C,h,w] -> out [C,H,W];  if `add` != NULL (same shape as out): out = resample(in) + add. */

@@ -17,8 +17,8 @@ _vp = ctypes.c_void_p
 # name -> argtypes ; every function returns int (hipError_t)
 SIGNATURES = {
     "rba_hip_version": [],
-    "rba_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp],
-    "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp],
+    "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

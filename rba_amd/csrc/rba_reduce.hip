@@ -44,21 +44,62 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
 }
 
 // epilogue shared by both kernels: tanh-sum, optional sem_seg / argmax stores for VEC pixels at p0
+// score modes (the reference's interchangeable anomaly_score_func's on the same sem_seg):
+//   0  RbA               -sum_k tanh(sem_k)        evaluate_ood.py:143-150
+//   1  energy            -logsumexp_k(sem_k)       evaluate_ood.py:152-159
+//   2  neg. logit sum    -sum_k sem_k              support.py:115-132
+template <int KMAX, int VEC>
+__device__ __forceinline__ void rba_score(const float (&acc)[KMAX][VEC], int K, int mode, float (&r)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r[i] = 0.f;
+  if (mode == 0) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] -= rba_tanh(acc[k][i]);
+  } else if (mode == 2) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] -= acc[k][i];
+  } else {
+    float mx[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) mx[i] = acc[0][i];
+#pragma unroll
+    for (int k = 1; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], acc[k][i]);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] += expf(acc[k][i] - mx[i]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = -(mx[i] + logf(r[i]));
+  }
+}
+
+// epilogue shared by both kernels: score, optional sem_seg / argmax stores for VEC pixels at p0
 template <int KMAX, int VEC, bool SEM, bool ARG>
-__device__ __forceinline__ void rba_epilogue(float (&acc)[KMAX][VEC], int K, float* rba, float* sem, int32_t* argmax,
+__device__ __forceinline__ void rba_epilogue(float (&acc)[KMAX][VEC], int K, int mode, float* rba, float* sem, int32_t* argmax,
                                              int64_t p0, int64_t plane) {
   float r[VEC];
+  rba_score<KMAX, VEC>(acc, K, mode, r);
   int best[VEC];
   float bestv[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { r[i] = 0.f; best[i] = 0; bestv[i] = acc[0][i]; }
+  for (int i = 0; i < VEC; ++i) { best[i] = 0; bestv[i] = acc[0][i]; }
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     if (k < K) {
+      if (ARG) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        r[i] -= rba_tanh(acc[k][i]);
-        if (ARG && acc[k][i] > bestv[i]) { bestv[i] = acc[k][i]; best[i] = k; }
+        for (int i = 0; i < VEC; ++i)
+          if (acc[k][i] > bestv[i]) { bestv[i] = acc[k][i]; best[i] = k; }
       }
       if (SEM) store_vec<VEC>(sem + (int64_t)k * plane + p0, acc[k]);
     }
@@ -74,7 +115,7 @@ __device__ __forceinline__ void rba_epilogue(float (&acc)[KMAX][VEC], int K, flo
 template <int KMAX, int VEC, bool SEM, bool ARG>
 __global__ __launch_bounds__(256) void rba_reduce_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
                                                          float* __restrict__ rba, float* __restrict__ sem,
-                                                         int32_t* __restrict__ argmax, int Q, int K, int64_t HW) {
+                                                         int32_t* __restrict__ argmax, int Q, int K, int64_t HW, int mode) {
   const int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (p0 >= HW) return;
   float acc[KMAX][VEC];
@@ -100,7 +141,7 @@ __global__ __launch_bounds__(256) void rba_reduce_kernel(const float* __restrict
       }
     }
   }
-  rba_epilogue<KMAX, VEC, SEM, ARG>(acc, K, rba, sem, argmax, p0, HW);
+  rba_epilogue<KMAX, VEC, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
 }
 
 // x4 upsample fused in front: thread owns 4 consecutive output pixels of one output row, i.e. output
@@ -109,7 +150,7 @@ template <int KMAX, bool SEM, bool ARG>
 __global__ __launch_bounds__(256) void rba_reduce_up4_kernel(const float* __restrict__ low, const float* __restrict__ prob,
                                                              float* __restrict__ rba, float* __restrict__ sem,
                                                              int32_t* __restrict__ argmax, int Q, int K, int h, int w,
-                                                             int crop_h, int crop_w, int wq /* ceil(crop_w/4) */) {
+                                                             int crop_h, int crop_w, int wq /* ceil(crop_w/4) */, int mode) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;   // low-res column == group of 4 output columns
   const int y = blockIdx.y;                              // output row
   if (j >= wq) return;
@@ -158,35 +199,32 @@ __global__ __launch_bounds__(256) void rba_reduce_up4_kernel(const float* __rest
   const int64_t oplane = (int64_t)crop_h * crop_w;
   const int64_t p0 = (int64_t)y * crop_w + 4 * j;
   if (4 * j + 3 < crop_w && (crop_w & 3) == 0) {
-    rba_epilogue<KMAX, 4, SEM, ARG>(acc, K, rba, sem, argmax, p0, oplane);
+    rba_epilogue<KMAX, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, oplane);
   } else {  // ragged right edge / unaligned rows: scalar stores
+    float r[4];
+    rba_score<KMAX, 4>(acc, K, mode, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (4 * j + i >= crop_w) break;
-      float r = 0.f, bv = acc[0][i];
+      float bv = acc[0][i];
       int b = 0;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-          r -= rba_tanh(acc[k][i]);
           if (acc[k][i] > bv) { bv = acc[k][i]; b = k; }
           if (SEM) sem[(int64_t)k * oplane + p0 + i] = acc[k][i];
         }
       }
-      rba[p0 + i] = r;
+      rba[p0 + i] = r[i];
       if (ARG) argmax[p0 + i] = b;
     }
   }
 }
 
-// Fast path: K is a compile-time constant (no per-class guards -> straight-line v_pk_fma with SGPR operands),
-// a ring of U prefetched mask planes keeps U x 1 KiB loads in flight per wave (the compiler otherwise waits
-// vmcnt(0) after every load), and the grid is persistent: `tiles` tiles of 256*VEC pixels are strided over a
-// grid sized to whole multiples of the resident-wave capacity, so no partially filled last round.
 template <int K, int VEC, bool SEM, bool ARG, int U, int WPS>
 __global__ __launch_bounds__(256, WPS) void rba_reduce_fast_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
                                                                  float* __restrict__ rba, float* __restrict__ sem,
-                                                                 int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles) {
+                                                                 int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode) {
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * VEC;
     if (p0 >= HW) continue;
@@ -231,13 +269,13 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_fast_kernel(const float* 
         }
       }
     }
-    rba_epilogue<K, VEC, SEM, ARG>(acc, K, rba, sem, argmax, p0, HW);
+    rba_epilogue<K, VEC, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
   }
 }
 
 template <int K, int VEC, int U, int WPS>
 int launch_reduce_fast(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q,
-                       int64_t HW, hipStream_t st) {
+                       int64_t HW, hipStream_t st, int mode = 0) {
   const int64_t per_block = 256 * (int64_t)VEC;
   const int64_t tiles = (HW + per_block - 1) / per_block;
   if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -250,7 +288,7 @@ int launch_reduce_fast(const float* mask, const float* prob, float* rba, float* 
     grid = (tiles + rounds - 1) / rounds;
   }
 #define RBA_L(S, A) \
-  hipLaunchKernelGGL((rba_reduce_fast_kernel<K, VEC, S, A, U, WPS>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW, (int)tiles)
+  hipLaunchKernelGGL((rba_reduce_fast_kernel<K, VEC, S, A, U, WPS>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW, (int)tiles, mode)
   if (sem && argmax) RBA_L(true, true);
   else if (sem) RBA_L(true, false);
   else if (argmax) RBA_L(false, true);
@@ -373,12 +411,12 @@ int launch_reduce_mfma(const float* mask, const float* prob, float* rba, int Q, 
 
 template <int KMAX, int VEC>
 int launch_reduce(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K,
-                  int64_t HW, hipStream_t st) {
+                  int64_t HW, hipStream_t st, int mode = 0) {
   const int threads = 256;
   const int64_t per_block = (int64_t)threads * VEC;
   const unsigned blocks = (unsigned)((HW + per_block - 1) / per_block);
 #define RBA_L(S, A) \
-  hipLaunchKernelGGL((rba_reduce_kernel<KMAX, VEC, S, A>), dim3(blocks), dim3(threads), 0, st, mask, prob, rba, sem, argmax, Q, K, HW)
+  hipLaunchKernelGGL((rba_reduce_kernel<KMAX, VEC, S, A>), dim3(blocks), dim3(threads), 0, st, mask, prob, rba, sem, argmax, Q, K, HW, mode)
   if (sem && argmax) RBA_L(true, true);
   else if (sem) RBA_L(true, false);
   else if (argmax) RBA_L(false, true);
@@ -389,12 +427,12 @@ int launch_reduce(const float* mask, const float* prob, float* rba, float* sem, 
 
 template <int KMAX>
 int launch_up4(const float* low, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K, int h, int w,
-               int crop_h, int crop_w, hipStream_t st) {
+               int crop_h, int crop_w, hipStream_t st, int mode) {
   const int wq = (crop_w + 3) / 4;
   const int threads = wq >= 256 ? 256 : (wq >= 128 ? 128 : 64);
   dim3 grid((wq + threads - 1) / threads, crop_h);
 #define RBA_L(S, A) \
-  hipLaunchKernelGGL((rba_reduce_up4_kernel<KMAX, S, A>), grid, dim3(threads), 0, st, low, prob, rba, sem, argmax, Q, K, h, w, crop_h, crop_w, wq)
+  hipLaunchKernelGGL((rba_reduce_up4_kernel<KMAX, S, A>), grid, dim3(threads), 0, st, low, prob, rba, sem, argmax, Q, K, h, w, crop_h, crop_w, wq, mode)
   if (sem && argmax) RBA_L(true, true);
   else if (sem) RBA_L(true, false);
   else if (argmax) RBA_L(false, true);
@@ -405,27 +443,29 @@ int launch_up4(const float* low, const float* prob, float* rba, float* sem, int3
 
 }  // namespace
 
-extern "C" int rba_hip_version(void) { return 100; }
+extern "C" int rba_hip_version(void) { return 110; }
 
 extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
-                              int Q, int K, int64_t HW, void* stream) {
-  RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 160 && HW >= 0);
+                              int Q, int K, int64_t HW, int score_mode, void* stream) {
+  RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 160 && HW >= 0 && score_mode >= 0 && score_mode <= 2);
+  const int mode = score_mode;
   if (HW == 0) return 0;
   RBA_CHECK_ARG(mask && cls_prob && rba);
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (HW % 4 == 0) && ((((uintptr_t)mask | (uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
-  if (K == 19 && vec4) return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st);
-  if (K == 20 && vec4) return launch_reduce_fast<20, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st);
-  if (K <= 32 && vec4) return launch_reduce<32, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
-  if (K <= 32) return launch_reduce<32, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
-  if (K <= 80) return launch_reduce<80, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
-  return launch_reduce<160, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st);
+  if (K == 19 && vec4) return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st, mode);
+  if (K == 20 && vec4) return launch_reduce_fast<20, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st, mode);
+  if (K <= 32 && vec4) return launch_reduce<32, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
+  if (K <= 32) return launch_reduce<32, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
+  if (K <= 80) return launch_reduce<80, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
+  return launch_reduce<160, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
 }
 
 extern "C" int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_prob, float* rba, float* sem_seg,
-                                  int32_t* argmax, int Q, int K, int h, int w, int crop_h, int crop_w, void* stream) {
-  RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 32 && h >= 1 && w >= 1);
+                                  int32_t* argmax, int Q, int K, int h, int w, int crop_h, int crop_w, int score_mode,
+                                  void* stream) {
+  RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 32 && h >= 1 && w >= 1 && score_mode >= 0 && score_mode <= 2);
   RBA_CHECK_ARG(crop_h >= 0 && crop_w >= 0 && crop_h <= 4 * h && crop_w <= 4 * w && crop_h <= 65535);
   if (crop_h == 0 || crop_w == 0) return 0;
   RBA_CHECK_ARG(mask_lowres && cls_prob && rba);
@@ -433,8 +473,8 @@ extern "C" int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_pro
   hipStream_t st = (hipStream_t)stream;
   // vector stores need 16 B aligned rows; the kernel falls back to scalar stores when crop_w % 4 != 0
   RBA_CHECK_ARG((((uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
-  if (K == 19) return launch_up4<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st);
-  return launch_up4<32>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st);
+  if (K == 19) return launch_up4<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st, score_mode);
+  return launch_up4<32>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st, score_mode);
 }
 
 // LDS-staged matrix-pipe variant.  Bandwidth probes (profiles/r01_k1_bandwidth_probes.txt) show this buffer streams at

@@ -1,5 +1,13 @@
 """The evaluator-facing functions of the reference's ``evaluate_ood.py`` with the same names, arguments and
-outputs: ``get_model`` (:108-124), ``get_logits`` (:127-140), ``get_RbA`` (:143-150), ``get_energy`` (:152-159)."""
+outputs: ``get_model`` (:108-124), ``get_logits`` (:127-140), ``get_RbA`` (:143-150), ``get_energy`` (:152-159), and its
+command line (``python -m rba_amd.evaluate_ood --models_folder ckpts/ --datasets_folder ... --score_func rba``, same flags,
+same ``results/<model>/results.pkl``), extended with image sharding when launched through torchrun."""
+import argparse
+import os
+import pickle
+from pathlib import Path
+
+import numpy as np
 import torch
 
 from .arch import arch_from_cfg
@@ -44,6 +52,119 @@ def get_RbA(model, x, **kwargs):
 
 
 def get_energy(model, x, **kwargs):
+    """-logsumexp_k(sem_seg) (evaluate_ood.py:152-159)."""
+    if hasattr(model, "rba_scores"):
+        return model.rba_scores([{"image": x[0].to(model.device)}], score="energy")[0]
     with torch.no_grad():
         out = model([{"image": x[0].to(model.device)}])
     return -torch.logsumexp(out[0]["sem_seg"], dim=0)
+
+
+def get_neg_logit_sum(model, x, **kwargs):
+    """-sum_k sem_seg (support.py:115-132)."""
+    if hasattr(model, "rba_scores"):
+        return model.rba_scores([{"image": x[0].to(model.device)}], score="neg_logit_sum")[0]
+    with torch.no_grad():
+        out = model([{"image": x[0].to(model.device)}])
+    return -out[0]["sem_seg"].sum(dim=0)
+
+
+# ------------------------------------------------------------------------------------------------- command line
+SCORE_FUNCS = {"rba": get_RbA, "pebal": get_energy, "energy": get_energy, "neg_logit_sum": get_neg_logit_sum}
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="OOD Evaluation (rba_amd)")
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--out_path", type=str, default="results")
+    p.add_argument("--verbose", type=lambda v: str(v).lower() not in ("0", "false", "no", ""), default=True)
+    p.add_argument("--datasets_folder", type=str, default="./")
+    p.add_argument("--models_folder", type=str, default="ckpts/")
+    p.add_argument("--store_anomaly_scores", action="store_true",
+                   help="store every score map as anomaly_scores/<model>/<dataset>/score_<i>.npy")
+    p.add_argument("--model_mode", type=str, default="all", choices=["all", "selective"])
+    p.add_argument("--selected_models", nargs="*", type=str, default=[])
+    p.add_argument("--dataset_mode", type=str, default="all", choices=["all", "selective"])
+    p.add_argument("--selected_datasets", nargs="*", type=str, default=[])
+    p.add_argument("--score_func", type=str, default="rba", choices=sorted(SCORE_FUNCS))
+    p.add_argument("--upper_limit", type=int, default=1300)
+    return p
+
+
+def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, world=1):
+    """Score this rank's shard of `dataset` (image i -> rank i mod world), pool the labelled pixels of all ranks over
+    RCCL and return {"auroc","aupr","fpr95"} (reference :195-235; single process there)."""
+    from . import distributed as D
+    from .metrics import select_labelled
+    score_func = SCORE_FUNCS[args.score_func]
+    n = min(len(dataset), args.upper_limit)
+    scores, labels = [], []
+    for i in D.shard_indices(n, rank, world):
+        x, y = dataset[i]
+        s = score_func(model, x[None])
+        if args.store_anomaly_scores:
+            vis = os.path.join("anomaly_scores", model_name, dataset_name)
+            os.makedirs(vis, exist_ok=True)
+            np.save(os.path.join(vis, f"score_{i}.npy"), s.cpu().numpy())
+        ss, yy = select_labelled(s, y.to(s.device))
+        scores.append(ss)
+        labels.append(yy)
+    dev = model.device
+    s_all = torch.cat(scores) if scores else torch.empty(0, device=dev)
+    y_all = torch.cat(labels) if labels else torch.empty(0, dtype=torch.bool, device=dev)
+    return D.pooled_ood_metrics(s_all, y_all)
+
+
+def main(argv=None):
+    from pprint import pprint
+    from . import distributed as D
+    from .datasets import available_datasets, get_dataset
+    args = build_parser().parse_args(argv)
+    rank, world, local = D.init_from_env()
+    device = torch.device(args.device, local) if args.device == "cuda" else torch.device(args.device)
+    names = args.selected_datasets if args.dataset_mode == "selective" else ["road_anomaly", "fishyscapes_laf"]
+    if not names:
+        raise ValueError("Selective Mode is chosen but number of selected datasets is 0")
+    unknown = [n for n in names if n not in available_datasets()]
+    if unknown:
+        raise ValueError(f"unknown datasets {unknown}; available: {available_datasets()}")
+    models = sorted(m for m in os.listdir(args.models_folder) if os.path.isdir(os.path.join(args.models_folder, m)))
+    if args.model_mode == "selective":
+        models = [m for m in models if m in args.selected_models]
+    if not models:
+        raise ValueError("Number of models chosen is 0, either the models folder is empty or no models were selected")
+    for model_name in models:
+        exp = os.path.join(args.models_folder, model_name)
+        store = os.path.join(args.out_path, model_name)
+        if os.path.exists(os.path.join(store, "results.pkl")):
+            if rank == 0:
+                print(f"Skipping {model_name} because results already exist, if you want to re-run, delete the results.pkl file")
+            continue
+        model_path = os.path.join(exp, "model_final.pth")
+        if not os.path.exists(model_path):
+            model_path = os.path.join(exp, "model_final.pkl")
+            if not os.path.exists(model_path):
+                model_path = os.path.join("model_logs", model_name, "model_final.pkl")      # reference fallback (:271-273)
+                if not os.path.exists(model_path):
+                    if rank == 0:
+                        print("Model path does not exist, skipping")
+                    continue
+        model = get_model(os.path.join(exp, "config.yaml"), model_path, device=device)
+        results = {}
+        for name in names:
+            results[name] = run_evaluations(model, get_dataset(name, args.datasets_folder), model_name, name, args, rank, world)
+        if rank == 0:
+            if args.verbose:
+                pprint(results)
+            Path(store).mkdir(exist_ok=True, parents=True)
+            with open(os.path.join(store, "results.pkl"), "wb") as f:
+                pickle.dump(results, f)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

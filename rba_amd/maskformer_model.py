@@ -56,15 +56,15 @@ class MaskFormer(nn.Module):
         outputs = self.sem_seg_head(features)
         return outputs["pred_logits"], outputs["pred_masks"], sizes, tuple(batch.shape[-2:])
 
-    def _post(self, mask_cls, mask_pred, image_size, padded, want_sem_seg, want_argmax):
+    def _post(self, mask_cls, mask_pred, image_size, padded, want_sem_seg, want_argmax, score="rba"):
         """Up-sample (:294-299), semantic inference (:381-386), crop (:330-332), RbA (evaluate_ood.py:150)."""
         prob = F.softmax(mask_cls, dim=-1)[..., :-1].contiguous()
         H, W = padded
         exact4 = mask_pred.shape[-2] * 4 == H and mask_pred.shape[-1] * 4 == W
         if self.fused_upsample and exact4 and prob.shape[1] <= 32:
-            return ops.rba_reduce_up4(mask_pred.contiguous(), prob, image_size, want_sem_seg, want_argmax)
+            return ops.rba_reduce_up4(mask_pred.contiguous(), prob, image_size, want_sem_seg, want_argmax, score)
         up = ops.resample_bilinear(mask_pred.contiguous(), (H, W))
-        rba, sem, arg = ops.rba_reduce(up, prob, want_sem_seg, want_argmax)
+        rba, sem, arg = ops.rba_reduce(up, prob, want_sem_seg, want_argmax, score)
         h, w = image_size
         if (h, w) != (H, W):
             rba = rba[:h, :w].contiguous()
@@ -93,11 +93,12 @@ class MaskFormer(nn.Module):
         return results
 
     @torch.no_grad()
-    def rba_scores(self, batched_inputs, return_argmax=False):
-        """Fast path: RbA maps (and optional int32 argmax maps) without materialising sem_seg."""
+    def rba_scores(self, batched_inputs, return_argmax=False, score="rba"):
+        """Fast path: anomaly-score maps (and optional int32 argmax maps) without materialising sem_seg.
+        score: "rba" (evaluate_ood.py:143-150), "energy" (:152-159) or "neg_logit_sum" (support.py:115-132)."""
         mask_cls, mask_pred, sizes, padded = self.predict(batched_inputs)
         out = []
         for i in range(len(batched_inputs)):
-            rba, _, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, False, return_argmax)
+            rba, _, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, False, return_argmax, score)
             out.append((rba, arg) if return_argmax else rba)
         return out

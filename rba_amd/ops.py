@@ -33,7 +33,16 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
-def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False):
+SCORE_MODES = {"rba": 0, "energy": 1, "neg_logit_sum": 2}
+
+
+def _mode(score):
+    if score not in SCORE_MODES:
+        raise RbaHipError(f"unknown score {score!r}; choose from {sorted(SCORE_MODES)}")
+    return SCORE_MODES[score]
+
+
+def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False, score="rba"):
     """K1.  mask_pred [Q,H,W] full-resolution mask logits, cls_prob [Q,K] -> (rba [H,W], sem_seg [K,H,W] | None,
     argmax int32 [H,W] | None).  maskformer_model.py:381-386 + evaluate_ood.py:150 + support.py:385-388."""
     lib = _lib.load()
@@ -47,12 +56,12 @@ def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False):
     rba = torch.empty((H, W), dtype=torch.float32, device=dev)
     sem = torch.empty((K, H, W), dtype=torch.float32, device=dev) if want_sem_seg else None
     arg = torch.empty((H, W), dtype=torch.int32, device=dev) if want_argmax else None
-    _lib.check(lib.rba_reduce_f32(_p(mask_pred), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, H * W, _stream()),
-               "rba_reduce_f32")
+    _lib.check(lib.rba_reduce_f32(_p(mask_pred), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, H * W, _mode(score),
+                                  _stream()), "rba_reduce_f32")
     return rba, sem, arg
 
 
-def rba_reduce_up4(mask_lowres, cls_prob, crop_hw, want_sem_seg=False, want_argmax=False):
+def rba_reduce_up4(mask_lowres, cls_prob, crop_hw, want_sem_seg=False, want_argmax=False, score="rba"):
     """K1 fused with the x4 upsample (maskformer_model.py:294-299) and the crop (:330-332).
     mask_lowres [Q,h,w]; outputs are [crop_h, crop_w] of the virtual [4h,4w] map."""
     lib = _lib.load()
@@ -66,7 +75,7 @@ def rba_reduce_up4(mask_lowres, cls_prob, crop_hw, want_sem_seg=False, want_argm
     sem = torch.empty((K, ch, cw), dtype=torch.float32, device=dev) if want_sem_seg else None
     arg = torch.empty((ch, cw), dtype=torch.int32, device=dev) if want_argmax else None
     _lib.check(lib.rba_reduce_up4_f32(_p(mask_lowres), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, h, w, ch, cw,
-                                      _stream()), "rba_reduce_up4_f32")
+                                      _mode(score), _stream()), "rba_reduce_up4_f32")
     return rba, sem, arg
 
 

@@ -1,0 +1,66 @@
+"""CPU: dataset readers on synthetic on-disk datasets with the reference's layouts (datasets/README.md:91-122)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from rba_amd import datasets as DS
+
+
+def make_road_anomaly(root, n=3, h=24, w=40):
+    d = os.path.join(root, "RoadAnomaly", "RoadAnomaly_jpg")
+    os.makedirs(os.path.join(d, "frames"))
+    rng = np.random.RandomState(0)
+    names, imgs, labs = [], [], []
+    for i in range(n):
+        name = f"scene{i}.png"          # PNG payload under the listed name: lossless, so the check below is exact
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(d, "frames", name))
+        lab = rng.choice([0, 2], size=(h, w), p=[0.9, 0.1]).astype(np.uint8)
+        os.makedirs(os.path.join(d, "frames", name[:-4] + ".labels"))
+        Image.fromarray(np.stack([lab, lab, lab], -1)).save(os.path.join(d, "frames", name[:-4] + ".labels", "labels_semantic.png"))
+        names.append(name); imgs.append(img); labs.append(lab)
+    with open(os.path.join(d, "frame_list.json"), "w") as f:
+        json.dump(names, f)
+    return imgs, labs
+
+
+def make_fs_laf(root, n=2, h=16, w=32):
+    d = os.path.join(root, "Fishyscapes")
+    os.makedirs(os.path.join(d, "fishyscapes_lostandfound"))
+    os.makedirs(os.path.join(d, "laf_images"))
+    rng = np.random.RandomState(1)
+    imgs, labs = [], []
+    for i in range(n):
+        stem = f"04_Maurener_Weg_8_00000{i}_000030_"
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        lab = rng.choice([0, 1, 255], size=(h, w), p=[0.8, 0.1, 0.1]).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(d, "laf_images", stem + "leftImg8bit.png"))
+        Image.fromarray(lab).save(os.path.join(d, "fishyscapes_lostandfound", f"{i:04d}_" + stem + "labels.png"))
+        imgs.append(img); labs.append(lab)
+    return imgs, labs
+
+
+def test_road_anomaly(tmp_path):
+    imgs, labs = make_road_anomaly(str(tmp_path))
+    ds = DS.get_dataset("road_anomaly", str(tmp_path))
+    assert len(ds) == 3
+    for i in range(3):
+        x, y = ds[i]
+        assert x.dtype == torch.uint8 and x.shape == (3, 24, 40) and y.dtype == torch.int64 and y.shape == (24, 40)
+        assert np.array_equal(x.numpy().transpose(1, 2, 0), imgs[i])
+        assert np.array_equal(y.numpy(), (labs[i] == 2).astype(np.int64))       # 2 -> 1 (road_anomaly.py:38-39)
+
+
+def test_fishyscapes_laf(tmp_path):
+    imgs, labs = make_fs_laf(str(tmp_path))
+    ds = DS.get_dataset("fishyscapes_laf", str(tmp_path))
+    assert len(ds) == 2
+    for i in range(2):
+        x, y = ds[i]
+        assert np.array_equal(x.numpy().transpose(1, 2, 0), imgs[i]) and np.array_equal(y.numpy(), labs[i].astype(np.int64))
+    with pytest.raises(KeyError):
+        DS.get_dataset("cityscapes", str(tmp_path))

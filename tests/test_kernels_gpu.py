@@ -68,6 +68,26 @@ def test_k1_shapes(ops, Q, K, H, W):
     assert bad == 0
 
 
+@pytest.mark.parametrize("Q,K,H,W", [(100, 19, 32, 64), (9, 7, 5, 6)])
+def test_k1_score_modes(ops, Q, K, H, W):
+    """energy (evaluate_ood.py:152-159) and negative logit sum (support.py:115-132) epilogues"""
+    g = torch.Generator().manual_seed(7)
+    mp = torch.randn(Q, H, W, generator=g) * 5
+    prob = F.softmax(torch.randn(Q, K + 1, generator=g) * 3, -1)[:, :-1].contiguous()
+    sem_r, _, _ = ref_ops.rba_reduce_ordered(mp, prob)
+    want = {"rba": -sem_r.tanh().sum(0), "energy": -torch.logsumexp(sem_r, dim=0), "neg_logit_sum": -sem_r.sum(0)}
+    low = torch.randn(Q, H // 4 + 1, W // 4 + 1, generator=g) * 5
+    up = ref_ops.upsample_bilinear(low[None], (4 * low.shape[1], 4 * low.shape[2]))[0]
+    sem_u, _, _ = ref_ops.rba_reduce_ordered(up, prob)
+    want_u = {"rba": -sem_u.tanh().sum(0), "energy": -torch.logsumexp(sem_u, dim=0), "neg_logit_sum": -sem_u.sum(0)}
+    for score in want:
+        got, _, _ = ops.rba_reduce(dev(mp), dev(prob), score=score)
+        assert maxerr(got, want[score]) < 3e-5, score
+        if K <= 32:
+            got_u, _, _ = ops.rba_reduce_up4(dev(low), dev(prob), (H, W), score=score)
+            assert maxerr(got_u, want_u[score][:H, :W]) < 3e-5, score
+
+
 def test_k1_empty_and_errors(ops):
     from rba_amd._lib import RbaHipError
     prob = torch.full((4, 19), 0.01).cuda()

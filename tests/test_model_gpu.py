@@ -121,3 +121,45 @@ def test_full_size_swin_b_1dl_1024x2048(golden):
 def test_full_size_swin_b_9dl_720x1280(golden):
     """BASELINE config C5 (9 decoder layers, 3-level MSDeformAttn, 720 -> 736 padding)."""
     _full_size(golden, "g5_swin_b_9dl_720x1280", "swin_b_9dl", 1e-4)
+
+
+def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
+    """`python -m rba_amd.evaluate_ood` flow: models folder (config.yaml + model_final.pth) x datasets on disk ->
+    results/<model>/results.pkl = {dataset: {auroc, aupr, fpr95}} (evaluate_ood.py:238-288), checked against the oracle."""
+    import pickle
+    import yaml
+    from oracle import ref_metrics
+    from rba_amd import evaluate_ood as E
+    from tests.test_datasets_cpu import make_fs_laf, make_road_anomaly
+    a = A.complete(A.ARCHS["tiny1"])
+    sd = A.seeded_weights(a, 0)
+    mdir = tmp_path / "ckpts" / "tiny"
+    mdir.mkdir(parents=True)
+    cfg = {"MODEL": {"SWIN": {"EMBED_DIM": 32, "DEPTHS": [2, 2, 2, 2], "NUM_HEADS": [1, 2, 4, 8], "WINDOW_SIZE": 6},
+                     "SEM_SEG_HEAD": {"CONVS_DIM": 64, "MASK_DIM": 64, "TRANSFORMER_ENC_LAYERS": 2,
+                                      "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res5"]},
+                     "MASK_FORMER": {"HIDDEN_DIM": 64, "NHEADS": 2, "NUM_OBJECT_QUERIES": 16, "DIM_FEEDFORWARD": 128,
+                                     "DEC_LAYERS": 2}}}
+    (mdir / "config.yaml").write_text(yaml.safe_dump(cfg))
+    torch.save({"model": sd}, mdir / "model_final.pth")
+    data = tmp_path / "data"
+    ra_imgs, ra_labs = make_road_anomaly(str(data))
+    fs_imgs, fs_labs = make_fs_laf(str(data))
+    monkeypatch.chdir(tmp_path)
+    argv = ["--models_folder", str(tmp_path / "ckpts"), "--datasets_folder", str(data), "--out_path", str(tmp_path / "results"),
+            "--verbose", "false"]
+    E.main(argv)
+    with open(tmp_path / "results" / "tiny" / "results.pkl", "rb") as f:
+        res = pickle.load(f)
+    assert sorted(res) == ["fishyscapes_laf", "road_anomaly"]
+    # oracle: CPU forward + sklearn metrics over the same images / labels
+    for name, imgs, labs in (("road_anomaly", ra_imgs, [(l == 2).astype(np.int64) for l in ra_labs]),
+                             ("fishyscapes_laf", fs_imgs, [l.astype(np.int64) for l in fs_labs])):
+        scores = np.stack([ref_model.forward(torch.from_numpy(im.transpose(2, 0, 1).copy()), sd, a)["rba"].numpy() for im in imgs])
+        want = ref_metrics.evaluate_ood(scores, np.stack(labs)[:, None])
+        for k in want:
+            assert abs(res[name][k] - want[k]) < 2e-3, (name, k, res[name][k], want[k])     # rank statistics of scores that agree to ~1e-6
+    # second run: results exist -> skipped, file untouched
+    mtime = (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns
+    E.main(argv)
+    assert (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns == mtime
