@@ -21,6 +21,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
+            if local >= torch.cuda.device_count():
+                raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} visible GPU(s)")
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
