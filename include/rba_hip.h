@@ -23,6 +23,8 @@
  *   rba_mask_logits_f32         <- torch.einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479)
  *   rba_swin_window_attn_f32    <- WindowAttention core + window_partition/reverse + roll + pad
  *                                  (backbone/swin.py:44-71, 131-171, 251-284)
+ *   rba_add_layer_norm_f32      <- `x = x + proj(...)` followed by nn.LayerNorm (swin.py:284-293 and the post-norm layers
+ *                                  of msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58,106-118,171-175)
  *   rba_group_norm_f32          <- GroupNorm(32) [+ ReLU] behind Detectron2's Conv2d(norm=get_norm("GN"), activation)
  *                                  (pixel_decoder/msdeformattn.py:222-235, 278-297)
  */
@@ -99,6 +101,12 @@ int rba_swin_bias_fragments_f32(const float* bias, float* frag, int nH, int ws, 
 int64_t rba_group_norm_workspace_bytes(int B, int C, int HW, int G);
 int rba_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* workspace,
                        int B, int C, int HW, int G, float eps, int relu, void* stream);
+
+/* Fused residual add + LayerNorm over rows of length C (C % 4 == 0, C <= 8192):
+ *   s = x (+ t) (+ t_bias[c]);  sum_out = s (optional, may alias x);  y = (s - mean) * rstd * gamma + beta.
+ * t, t_bias, sum_out may be NULL.  (swin.py:284-293, msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58) */
+int rba_add_layer_norm_f32(const float* x, const float* t, const float* t_bias, const float* gamma, const float* beta,
+                           float* sum_out, float* y, int64_t rows, int C, float eps, void* stream);
 
 #ifdef __cplusplus
 }

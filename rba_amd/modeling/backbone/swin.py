@@ -62,18 +62,21 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x, H, W):
-        """x [B, H*W, C] (swin.py:235-295)."""
+    def forward(self, x, H, W, pending=None):
+        """x [B, H*W, C] residual stream; ``pending`` = (t, bias) not yet added to it (the previous block's fc2 output).
+        Returns (x, pending) with this block's fc2 output pending (reference dataflow: swin.py:235-295).  The residual
+        adds and projection biases are folded into the fused add+LayerNorm kernel."""
         a = self.attn
-        y = F.layer_norm(x, (x.shape[-1],), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        t, tb = pending if pending is not None else (None, None)
+        x, y = ops.add_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, t, tb, inplace_sum=True)
         qkv = F.linear(y, a.qkv.weight, a.qkv.bias)
         bias, bias_frag = a.gathered_bias()
         y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size,
                                  bias_frag=bias_frag)
-        x = x + F.linear(y, a.proj.weight, a.proj.bias)
-        y = F.layer_norm(x, (x.shape[-1],), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        t = F.linear(y, a.proj.weight)                                   # proj bias rides in the fused add+LN
+        x, y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, t, a.proj.bias, inplace_sum=True)
         y = F.gelu(F.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
-        return x + F.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
+        return x, (F.linear(y, self.mlp.fc2.weight), self.mlp.fc2.bias)
 
 
 class PatchMerging(nn.Module):
@@ -90,7 +93,7 @@ class PatchMerging(nn.Module):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
         x = x.reshape(B, -1, 4 * C)
-        x = F.layer_norm(x, (4 * C,), self.norm.weight, self.norm.bias, self.norm.eps)
+        _, x = ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return F.linear(x, self.reduction.weight)
 
 
@@ -118,8 +121,8 @@ class PatchEmbed(nn.Module):
             x = F.pad(x, (0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
         x = F.conv2d(x, self.proj.weight, self.proj.bias, stride=ps)
         Wh, Ww = x.shape[2], x.shape[3]
-        x = x.flatten(2).transpose(1, 2)
-        return F.layer_norm(x, (x.shape[-1],), self.norm.weight, self.norm.bias, self.norm.eps), Wh, Ww
+        x = x.flatten(2).transpose(1, 2).contiguous()
+        return ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)[1], Wh, Ww
 
 
 @BACKBONE_REGISTRY.register()
@@ -147,10 +150,12 @@ class D2SwinTransformer(nn.Module):
         x, Wh, Ww = self.patch_embed(x)
         outs = {}
         for i, layer in enumerate(self.layers):
+            pending = None
             for blk in layer.blocks:
-                x = blk(x, Wh, Ww)
+                x, pending = blk(x, Wh, Ww, pending)
             norm = getattr(self, f"norm{i}")
-            y = F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+            t, tb = pending if pending is not None else (None, None)
+            x, y = ops.add_layer_norm(x, norm.weight, norm.bias, norm.eps, t, tb, inplace_sum=True)
             outs[f"res{i + 2}"] = y.view(-1, Wh, Ww, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
             if layer.downsample is not None:
                 x = layer.downsample(x, Wh, Ww)

@@ -42,9 +42,9 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index):
         """msdeformattn.py:131-140 (dropout = identity)."""
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index)
-        src = self.norm1(src + src2)
-        src2 = self.linear2(F.relu(self.linear1(src)))
-        return self.norm2(src + src2)
+        _, src = ops.add_layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps, src2.contiguous())
+        src2 = F.linear(F.relu(self.linear1(src)), self.linear2.weight)
+        return ops.add_layer_norm(src, self.norm2.weight, self.norm2.bias, self.norm2.eps, src2, self.linear2.bias)[1]
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):

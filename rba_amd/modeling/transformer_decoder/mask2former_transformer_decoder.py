@@ -35,7 +35,7 @@ class _MHAParams(nn.Module):
         k = F.linear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
         v = F.linear(value, w[2 * E:], b[2 * E:]).view(B, S, nH, E // nH)
         o = ops.masked_xattn(q, k, v, mask_logits)
-        return F.linear(o, self.out_proj.weight, self.out_proj.bias)
+        return F.linear(o, self.out_proj.weight)            # out_proj.bias is added inside the caller's fused add+LN
 
 
 class SelfAttentionLayer(nn.Module):
@@ -46,7 +46,9 @@ class SelfAttentionLayer(nn.Module):
 
     def forward(self, tgt, query_pos):
         qk = tgt + query_pos
-        return self.norm(tgt + self.self_attn(qk, qk, tgt))          # forward_post :48-58
+        t2 = self.self_attn(qk, qk, tgt)
+        return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
+                                  self.self_attn.out_proj.bias)[1]          # forward_post :48-58
 
 
 class CrossAttentionLayer(nn.Module):
@@ -57,7 +59,8 @@ class CrossAttentionLayer(nn.Module):
 
     def forward(self, tgt, memory, mask_logits, pos, query_pos):
         t2 = self.multihead_attn(tgt + query_pos, memory + pos, memory, mask_logits)
-        return self.norm(tgt + t2)                                    # forward_post :106-118
+        return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
+                                  self.multihead_attn.out_proj.bias)[1]     # forward_post :106-118
 
 
 class FFNLayer(nn.Module):
@@ -68,7 +71,9 @@ class FFNLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))   # forward_post :171-175
+        t2 = F.linear(F.relu(self.linear1(tgt)), self.linear2.weight)
+        return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
+                                  self.linear2.bias)[1]                     # forward_post :171-175
 
 
 class MLP(nn.Module):
@@ -113,7 +118,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True):
         """output [B,Q,C] -> class logits [B,Q,K+1], mask logits [B,Q,H/4,W/4], attention-mask logits [B,Q,h*w]
         (reference :472-489; the threshold itself happens inside K3)."""
-        dec = self.decoder_norm(output)
+        dec = ops.add_layer_norm(output.contiguous(), self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)[1]
         outputs_class = self.class_embed(dec)
         mask_embed = self.mask_embed(dec)
         outputs_mask = ops.mask_logits(mask_embed.contiguous(), mask_features)

@@ -225,3 +225,31 @@ def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     _lib.check(lib.rba_group_norm_f32(_p(x), _p(weight), _p(bias), _p(y), _p(ws), B, C, h * w, num_groups, float(eps),
                                       int(bool(relu)), _stream()), "rba_group_norm_f32")
     return y
+
+
+def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None, inplace_sum=False):
+    """y = LayerNorm(x + residual + residual_bias) over the last dim.  Returns (s, y) where s = the summed tensor
+    (x itself when there is nothing to add; written in place over x when inplace_sum, else a new tensor)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(weight, "weight", dim=1)
+    _chk(bias, "bias", dim=1)
+    C = x.shape[-1]
+    if weight.numel() != C or bias.numel() != C:
+        raise RbaHipError("weight / bias must match the last dimension")
+    rows = x.numel() // C if C else 0
+    if residual is not None:
+        _chk(residual, "residual")
+        if tuple(residual.shape) != tuple(x.shape):
+            raise RbaHipError("residual must have x's shape")
+    if residual_bias is not None:
+        _chk(residual_bias, "residual_bias", dim=1)
+        if residual_bias.numel() != C:
+            raise RbaHipError("residual_bias must have C elements")
+    has_sum = residual is not None or residual_bias is not None
+    s = x if (not has_sum or inplace_sum) else torch.empty_like(x)
+    y = torch.empty_like(x)
+    _lib.check(lib.rba_add_layer_norm_f32(_p(x), _p(residual), _p(residual_bias), _p(weight), _p(bias),
+                                          _p(s) if has_sum else 0, _p(y), rows, C, float(eps), _stream()),
+               "rba_add_layer_norm_f32")
+    return s, y

@@ -230,8 +230,10 @@ def test_k5_swin_block_golden(ops, golden):
     H, W, Wh, Ww = (int(v) for v in g["bl_hw"])
     x = dev(T(g["bl_x"]))
     with torch.no_grad():
+        pending = None
         for blk in layer.blocks:
-            x = blk(x, H, W)
+            x, pending = blk(x, H, W, pending)
+        x = x + pending[0] + pending[1]
         down = layer.downsample(x, H, W)
     assert maxerr(x, T(g["bl_out"])) < 2e-5
     assert maxerr(down, T(g["bl_down"])) < 2e-5
@@ -281,3 +283,24 @@ def test_group_norm(ops, B, C, h, w, relu):
     assert maxerr(out, ref) < 2e-5
     ref32 = F.group_norm(x, 32, wt, bs, 1e-5)       # what the reference runs on CPU
     assert maxerr(out, F.relu(ref32) if relu else ref32) < 2e-5
+
+
+# ----------------------------------------------------------------------------------- add + LayerNorm
+@pytest.mark.parametrize("rows,C", [(1000, 128), (77, 256), (33, 512), (9, 1024), (5, 2048), (3, 3072), (2, 6144), (130, 64),
+                                    (7, 32), (4, 192), (6, 1536)])
+def test_add_layer_norm(ops, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x, t = torch.randn(rows, C, generator=g) * 2 + 0.5, torch.randn(rows, C, generator=g)
+    tb, w, b = (torch.randn(C, generator=g) for _ in range(3))
+    s_ref = x + t + tb
+    y_ref = F.layer_norm(s_ref, (C,), w, b, 1e-5)
+    s, y = ops.add_layer_norm(dev(x), dev(w), dev(b), 1e-5, residual=dev(t), residual_bias=dev(tb))
+    assert maxerr(s, s_ref) < 1e-6 and maxerr(y, y_ref) < 5e-6
+    xs = dev(x)
+    s2, y2 = ops.add_layer_norm(xs, dev(w), dev(b), 1e-5, residual=dev(t), residual_bias=dev(tb), inplace_sum=True)
+    assert s2.data_ptr() == xs.data_ptr() and torch.equal(s2, s) and torch.equal(y2, y)
+    s3, y3 = ops.add_layer_norm(dev(x), dev(w), dev(b), 1e-5)                      # plain LayerNorm
+    assert maxerr(y3, F.layer_norm(x, (C,), w, b, 1e-5)) < 5e-6 and maxerr(s3, x) == 0
+    x3 = x.view(1, rows, C)
+    _, y4 = ops.add_layer_norm(dev(x3), dev(w), dev(b), 1e-5, residual=dev(t.view(1, rows, C)))
+    assert y4.shape == (1, rows, C) and maxerr(y4, F.layer_norm(x3 + t.view(1, rows, C), (C,), w, b, 1e-5)) < 5e-6
