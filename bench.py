@@ -39,7 +39,7 @@ def parse():
                     help="fullres: materialise the x4-upsampled mask logits and run the HBM-bound K1 the metric names; "
                          "up4: K1 reads the low-res logits and upsamples on the fly (less traffic, compute bound)")
     ap.add_argument("--graph", type=int, default=0, help="replay the forward from a captured hipGraph (0 = eager)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="images per GPU per step, each on its own HIP stream (concurrent kernels fill under-occupied "
                          "stage-3/4 launches: +7..10 %% images/s at 2-3, but K1's live timing then includes contention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,20 +109,27 @@ def main():
     side_streams = [torch.cuda.Stream() for _ in range(S - 1)]
     k1_probe = {}
 
-    def forward_once(record=True, src=None):
-        mask_cls, mask_pred, sizes, padded = model.predict([{"image": static_in if src is None else src}])
+    def predict_part(src):
+        """image -> (class probabilities [Q,K], low-res mask logits [Q,H/4,W/4]); everything up to the decoder heads"""
+        mask_cls, mask_pred, sizes, padded = model.predict([{"image": src}])
         prob = torch.softmax(mask_cls[0], dim=-1)[..., :-1].contiguous()
+        return prob, mask_pred[0].contiguous(), sizes[0], padded
+
+    def post_part(prob, low, size, padded, record=True):
+        """x4 mask upsample + K1 (or the fused up4 K1); HIP events bracket exactly the K1 launch"""
         if args.k1 == "up4":
-            low = mask_pred[0].contiguous()
-            ev = _timed(record, lambda: ops.rba_reduce_up4(low, prob, sizes[0]))
+            ev = _timed(record, lambda: ops.rba_reduce_up4(low, prob, size))
         else:
-            up = ops.resample_bilinear(mask_pred[0].contiguous(), padded)
+            up = ops.resample_bilinear(low, padded)
             ev = _timed(record, lambda: ops.rba_reduce(up, prob))
         rba = ev[2][0]
-        if args.k1 != "up4" and sizes[0] != padded:
-            rba = rba[: sizes[0][0], : sizes[0][1]]
+        if args.k1 != "up4" and size != padded:
+            rba = rba[: size[0], : size[1]]
         k1_probe["ev"] = ev[:2] if record else None
         return rba
+
+    def forward_once(record=True, src=None):
+        return post_part(*predict_part(static_in if src is None else src), record=record)
 
     def _timed(record, fn):
         """HIP events on the launch stream around exactly the K1 launch (torch's current stream IS that stream)."""
@@ -162,17 +169,23 @@ def main():
             graph.replay()
             return static_out
         main = torch.cuda.current_stream()
-        for j, st in enumerate(side_streams):                           # images 1..S-1 of this step, concurrently
+        parts = []
+        for j, st in enumerate(side_streams):                           # images 1..S-1 of this step: forwards overlap
             st.wait_stream(main)
             with torch.cuda.stream(st), torch.no_grad():
                 static_ins[j + 1].copy_(images[(i + j + 1) % len(images)], non_blocking=True)
-                forward_once(src=static_ins[j + 1])
-                k1_events.append(k1_probe["ev"])
+                parts.append(predict_part(static_ins[j + 1]))
         with torch.no_grad():
-            r = forward_once()
-        k1_events.append(k1_probe["ev"])
-        for st in side_streams:
-            main.wait_stream(st)
+            p0 = predict_part(static_in)
+            for st in side_streams:
+                main.wait_stream(st)                                    # join: from here on the GPU runs one stream
+            r = post_part(*p0)
+            k1_events.append(k1_probe["ev"])
+            for pt in parts:                                            # K1 of every image runs alone on the main stream
+                for t_ in pt[:2]:
+                    t_.record_stream(main)
+                post_part(*pt)
+                k1_events.append(k1_probe["ev"])
         return r
 
     def barrier():
