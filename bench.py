@@ -260,7 +260,8 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "images/sec @1024x2048 Swin-B-1dl (RbA inference hot path)",
+            "metric": ("images/sec @1024x2048 Swin-B-1dl (RbA inference hot path)" if (args.arch, h, w) == ("swin_b_1dl", 1024, 2048)
+                       else f"images/sec @{h}x{w} {args.arch} (RbA inference hot path)"),
             "value": world * args.steps * S / elapsed,
             "unit": "images/s",
             "n_gpus": world,

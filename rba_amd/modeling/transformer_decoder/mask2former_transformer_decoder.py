@@ -107,6 +107,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.level_embed = nn.Embedding(self.num_feature_levels, d)
         self.class_embed = nn.Linear(d, a["num_classes"] + 1)
         self.mask_embed = MLP(d, d, a["mask_dim"], 3)
+        # inference-only shortcut, exact: intermediate heads evaluate mask logits only where the attention mask samples them
+        # (aux_outputs then carry pred_logits only)
+        self.sparse_intermediate_heads = True
+        self._plan_cache, self._gather_by_level = {}, {}
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # v1 checkpoints call query_feat "static_query" (reference :237-258)
@@ -115,13 +119,45 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 state_dict[k.replace("static_query", "query_feat")] = state_dict.pop(k)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True):
-        """output [B,Q,C] -> class logits [B,Q,K+1], mask logits [B,Q,H/4,W/4], attention-mask logits [B,Q,h*w]
-        (reference :472-489; the threshold itself happens inside K3)."""
+    def _sparse_plan(self, feat_hw, target_hw, device):
+        """For an even integer down-sampling factor f the align_corners=False bilinear sample of target cell (y, x) is
+        0.5*(0.5*v[r0,c0] + 0.5*v[r0,c1]) + 0.5*(0.5*v[r1,c0] + 0.5*v[r1,c1]) with r0 = f*y + f/2 - 1, r1 = r0 + 1 (same for
+        columns): exactly 2x2 source pixels.  Returns the flat source indices [4, h*w] or None when the factor is not an
+        even integer (then the dense path is used)."""
+        key = (tuple(feat_hw), tuple(target_hw), device)
+        if key not in self._plan_cache:
+            (H, W), (h, w) = feat_hw, target_hw
+            plan = None
+            if h > 0 and w > 0 and H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and 4 * h * w < H * W:
+                fy, fx = H // h, W // w
+                r0 = torch.arange(h, device=device) * fy + fy // 2 - 1
+                c0 = torch.arange(w, device=device) * fx + fx // 2 - 1
+                idx = [((r0 + dr)[:, None] * W + (c0 + dc)[None, :]).reshape(-1) for dr in (0, 1) for dc in (0, 1)]
+                plan = torch.stack(idx).contiguous()
+            self._plan_cache[key] = plan
+        return self._plan_cache[key]
+
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True, need_masks=True):
+        """output [B,Q,C] -> class logits [B,Q,K+1], mask logits [B,Q,H/4,W/4] (None unless need_masks), attention-mask
+        logits [B,Q,h*w] (reference :472-489; the threshold itself happens inside K3).  When only the attention mask is
+        consumed (every call but the last) the mask logits are evaluated just at the 2x2 source pixels each attention
+        cell interpolates -- the same arithmetic on 4*h*w instead of H*W/16 columns."""
         dec = ops.add_layer_norm(output.contiguous(), self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)[1]
         outputs_class = self.class_embed(dec)
-        mask_embed = self.mask_embed(dec)
-        outputs_mask = ops.mask_logits(mask_embed.contiguous(), mask_features)
+        mask_embed = self.mask_embed(dec).contiguous()
+        plan = None
+        if need_attn_mask and not need_masks and self.sparse_intermediate_heads:
+            plan = self._sparse_plan(mask_features.shape[-2:], attn_mask_target_size, mask_features.device)
+        if plan is not None:
+            B, C = mask_features.shape[:2]
+            lvl = tuple(attn_mask_target_size)
+            if lvl not in self._gather_by_level:          # mask_features is the same tensor for every layer: gather once per level
+                self._gather_by_level[lvl] = mask_features.flatten(2).index_select(2, plan.reshape(-1)).contiguous()   # [B,C,4hw]
+            cols = self._gather_by_level[lvl]
+            v = ops.mask_logits(mask_embed, cols).view(B, -1, 4, plan.shape[1])
+            attn_logits = 0.5 * (0.5 * v[:, :, 0] + 0.5 * v[:, :, 1]) + 0.5 * (0.5 * v[:, :, 2] + 0.5 * v[:, :, 3])
+            return outputs_class, None, attn_logits.contiguous()
+        outputs_mask = ops.mask_logits(mask_embed, mask_features)
         attn_logits = None
         if need_attn_mask:
             attn_logits = ops.resample_bilinear(outputs_mask, attn_mask_target_size).flatten(2)
@@ -142,7 +178,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         output = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
         mask_features = mask_features.contiguous()
         predictions_class, predictions_mask = [], []
-        cls, msk, attn_logits = self.forward_prediction_heads(output, mask_features, size_list[0], self.num_layers > 0)
+        self._gather_by_level = {}
+        cls, msk, attn_logits = self.forward_prediction_heads(output, mask_features, size_list[0], self.num_layers > 0,
+                                                              need_masks=self.num_layers == 0)
         predictions_class.append(cls)
         predictions_mask.append(msk)
         for i in range(self.num_layers):
@@ -152,12 +190,12 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             output = self.transformer_ffn_layers[i](output)
             last = i == self.num_layers - 1
             cls, msk, attn_logits = self.forward_prediction_heads(
-                output, mask_features, size_list[(i + 1) % self.num_feature_levels], need_attn_mask=not last)
+                output, mask_features, size_list[(i + 1) % self.num_feature_levels], need_attn_mask=not last, need_masks=last)
             predictions_class.append(cls)
             predictions_mask.append(msk)
         return {
             "pred_logits": predictions_class[-1],
             "pred_masks": predictions_mask[-1],
-            "aux_outputs": [{"pred_logits": a, "pred_masks": b}
+            "aux_outputs": [({"pred_logits": a, "pred_masks": b} if b is not None else {"pred_logits": a})
                             for a, b in zip(predictions_class[:-1], predictions_mask[:-1])],
         }

@@ -163,3 +163,18 @@ def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
     mtime = (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns
     E.main(argv)
     assert (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns == mtime
+
+
+@pytest.mark.parametrize("name", ["tiny1", "tiny3"])
+def test_sparse_intermediate_heads_are_exact(name):
+    """evaluating the intermediate mask logits only at the 2x2 source pixels of each attention-mask cell gives
+    bit-identical results to the dense einsum + bilinear down-sample"""
+    model, a, _ = build(name, 1)
+    g = torch.Generator().manual_seed(5)
+    image = torch.randint(0, 256, (3, 60, 90), generator=g, dtype=torch.uint8)
+    pred = model.sem_seg_head.predictor
+    assert pred.sparse_intermediate_heads
+    cls_s, msk_s, _, _ = model.predict([{"image": image}])
+    pred.sparse_intermediate_heads = False
+    cls_d, msk_d, _, _ = model.predict([{"image": image}])
+    assert torch.equal(cls_s, cls_d) and torch.equal(msk_s, msk_d)
