@@ -73,9 +73,12 @@ int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes
  * q [B,Q,nH,hd] (already includes the in_proj bias, NOT yet scaled), k,v [B,S,nH,hd];
  * mask_logits [B,Q,S] or NULL: key s is blocked for query q (all heads) iff sigmoid(mask_logits) < 0.5,
  * except that a row with every key blocked attends to all keys.  out [B,Q,nH*hd].
- * scale = hd^-0.5 applied to q.  hd must be 32. */
+ * scale = hd^-0.5 applied to q.  hd must be 32.
+ * workspace: rba_masked_xattn_workspace_bytes(B,Q,S,nH) bytes of scratch enables the split-key matrix-pipe path
+ * (partial (m,l,O) per key range + merge); NULL selects the one-workgroup-per-(query,head) kernel. */
+int64_t rba_masked_xattn_workspace_bytes(int B, int Q, int S, int nH);
 int rba_masked_xattn_f32(const float* q, const float* k, const float* v, const float* mask_logits, float* out,
-                         int B, int Q, int S, int nH, int hd, void* stream);
+                         float* workspace, int B, int Q, int S, int nH, int hd, void* stream);
 
 /* K4.  Mask logits: out[b,q,n] = sum_c embed[b,q,c] * feat[b,c,n]   (embed [B,Q,C], feat [B,C,N], out [B,Q,N]). */
 int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,

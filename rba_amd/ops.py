@@ -133,8 +133,10 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def masked_xattn(q, k, v, mask_logits=None):
-    """K3.  q [B,Q,nH,hd] (unscaled), k, v [B,S,nH,hd], mask_logits [B,Q,S] | None -> [B,Q,nH*hd]."""
+def masked_xattn(q, k, v, mask_logits=None, split_keys=None):
+    """K3.  q [B,Q,nH,hd] (unscaled), k, v [B,S,nH,hd], mask_logits [B,Q,S] | None -> [B,Q,nH*hd].
+    split_keys: use the split-key matrix-pipe path (needs a scratch buffer, allocated here); None = automatic
+    (it wins from about a thousand keys; below that its three launches cost more than they save)."""
     lib = _lib.load()
     _chk(q, "q", dim=4)
     _chk(k, "k", dim=4)
@@ -148,7 +150,12 @@ def masked_xattn(q, k, v, mask_logits=None):
         if tuple(mask_logits.shape) != (B, Q, S):
             raise RbaHipError("mask_logits must be [B,Q,S]")
     out = torch.empty((B, Q, nH * hd), dtype=torch.float32, device=q.device)
-    _lib.check(lib.rba_masked_xattn_f32(_p(q), _p(k), _p(v), _p(mask_logits), _p(out), B, Q, S, nH, hd, _stream()),
+    ws = None
+    if split_keys is None:
+        split_keys = S >= 1024
+    if split_keys:
+        ws = torch.empty(max(lib.rba_masked_xattn_workspace_bytes(B, Q, S, nH) // 4, 4), dtype=torch.float32, device=q.device)
+    _lib.check(lib.rba_masked_xattn_f32(_p(q), _p(k), _p(v), _p(mask_logits), _p(out), _p(ws), B, Q, S, nH, hd, _stream()),
                "rba_masked_xattn_f32")
     return out
 

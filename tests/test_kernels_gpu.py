@@ -191,8 +191,10 @@ def test_k2_errors(ops):
 
 
 # ----------------------------------------------------------------------------------- K3
-@pytest.mark.parametrize("B,Q,S,nH", [(1, 100, 2048, 8), (2, 16, 77, 2), (1, 5, 1, 1), (1, 100, 920, 8)])
-def test_k3_masked_xattn(ops, B, Q, S, nH):
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("B,Q,S,nH", [(1, 100, 2048, 8), (2, 16, 77, 2), (1, 5, 1, 1), (1, 100, 920, 8), (1, 100, 14720, 8),
+                                      (1, 100, 100, 8), (1, 37, 301, 3)])
+def test_k3_masked_xattn(ops, B, Q, S, nH, split):
     g = torch.Generator().manual_seed(Q + S)
     q, k, v = (torch.randn(B, n, nH, 32, generator=g) for n in (Q, S, S))
     ml = torch.randn(B, Q, S, generator=g) * 3
@@ -201,10 +203,14 @@ def test_k3_masked_xattn(ops, B, Q, S, nH):
         ml[:, 1] = 5.0
     blocked = ref_ops.attn_mask_from_logits(ml.clone())
     ref = ref_ops.attention_core(q, k, v, blocked)
-    out = ops.masked_xattn(dev(q), dev(k), dev(v), dev(ml))
+    if S > 300:
+        ml[:, 2, : S - 150] = -5.0     # everything but the last chunk blocked: exercises the -inf running max across chunks
+    blocked = ref_ops.attn_mask_from_logits(ml.clone())
+    ref = ref_ops.attention_core(q, k, v, blocked)
+    out = ops.masked_xattn(dev(q), dev(k), dev(v), dev(ml), split_keys=split)
     assert maxerr(out, ref) < 5e-6
     ref0 = ref_ops.attention_core(q, k, v, None)
-    assert maxerr(ops.masked_xattn(dev(q), dev(k), dev(v), None), ref0) < 5e-6
+    assert maxerr(ops.masked_xattn(dev(q), dev(k), dev(v), None, split_keys=split), ref0) < 5e-6
 
 
 # ----------------------------------------------------------------------------------- K4
