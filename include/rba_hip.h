@@ -23,6 +23,8 @@
  *   rba_mask_logits_f32         <- torch.einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479)
  *   rba_swin_window_attn_f32    <- WindowAttention core + window_partition/reverse + roll + pad
  *                                  (backbone/swin.py:44-71, 131-171, 251-284)
+ *   rba_skinny_linear_f32       <- nn.Linear / in_proj / MLP on the decoder's [100, B, 256] query tensors
+ *                                  (mask2former_transformer_decoder.py:25-212)
  *   rba_add_layer_norm_f32      <- `x = x + proj(...)` followed by nn.LayerNorm (swin.py:284-293 and the post-norm layers
  *                                  of msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58,106-118,171-175)
  *   rba_group_norm_f32          <- GroupNorm(32) [+ ReLU] behind Detectron2's Conv2d(norm=get_norm("GN"), activation)
@@ -110,6 +112,12 @@ int rba_group_norm_f32(const float* x, const float* gamma, const float* beta, fl
  * t, t_bias, sum_out may be NULL.  (swin.py:284-293, msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58) */
 int rba_add_layer_norm_f32(const float* x, const float* t, const float* t_bias, const float* gamma, const float* beta,
                            float* sum_out, float* y, int64_t rows, int C, float eps, void* stream);
+
+/* Skinny linear layer: out[m,n] = act(sum_k x[m,k] * weight[n,k] + bias[n]), x [M,K] with M <= 128, weight [N,K]
+ * (nn.Linear layout), bias [N] or NULL, relu != 0 applies max(.,0).  K % 32 == 0.  For the decoder's 100-query GEMMs
+ * (mask2former_transformer_decoder.py:25-212). */
+int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias, float* out, int M, int N, int K,
+                          int relu, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,14 @@ from ...registry import TRANSFORMER_DECODER_REGISTRY
 from .position_encoding import PositionEmbeddingSine
 
 
+def _qlinear(x, weight, bias=None, relu=False):
+    """Linear layer on the query tensor [B, Q, C] (<= 128 rows): the skinny MFMA kernel; anything larger -> library GEMM."""
+    if x.numel() // x.shape[-1] <= 128 and x.shape[-1] % 32 == 0:
+        return ops.skinny_linear(x.contiguous(), weight, bias, relu)
+    y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y
+
+
 class _MHAParams(nn.Module):
     """Parameter holder with nn.MultiheadAttention's names: in_proj_weight, in_proj_bias, out_proj.{weight,bias}."""
 
@@ -31,11 +39,11 @@ class _MHAParams(nn.Module):
         B, Q, _ = query.shape
         S = key.shape[1]
         w, b = self.in_proj_weight, self.in_proj_bias
-        q = F.linear(query, w[:E], b[:E]).view(B, Q, nH, E // nH)
+        q = _qlinear(query, w[:E], b[:E]).view(B, Q, nH, E // nH)
         k = F.linear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
         v = F.linear(value, w[2 * E:], b[2 * E:]).view(B, S, nH, E // nH)
         o = ops.masked_xattn(q, k, v, mask_logits)
-        return F.linear(o, self.out_proj.weight)            # out_proj.bias is added inside the caller's fused add+LN
+        return _qlinear(o, self.out_proj.weight)            # out_proj.bias is added inside the caller's fused add+LN
 
 
 class SelfAttentionLayer(nn.Module):
@@ -71,7 +79,7 @@ class FFNLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt):
-        t2 = F.linear(F.relu(self.linear1(tgt)), self.linear2.weight)
+        t2 = _qlinear(_qlinear(tgt, self.linear1.weight, self.linear1.bias, relu=True), self.linear2.weight)
         return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
                                   self.linear2.bias)[1]                     # forward_post :171-175
 
@@ -85,7 +93,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = _qlinear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)
         return x
 
 
@@ -143,7 +151,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         consumed (every call but the last) the mask logits are evaluated just at the 2x2 source pixels each attention
         cell interpolates -- the same arithmetic on 4*h*w instead of H*W/16 columns."""
         dec = ops.add_layer_norm(output.contiguous(), self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)[1]
-        outputs_class = self.class_embed(dec)
+        outputs_class = _qlinear(dec, self.class_embed.weight, self.class_embed.bias)
         mask_embed = self.mask_embed(dec).contiguous()
         plan = None
         if need_attn_mask and not need_masks and self.sparse_intermediate_heads:

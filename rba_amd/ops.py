@@ -260,3 +260,23 @@ def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None,
                                           _p(s) if has_sum else 0, _p(y), rows, C, float(eps), _stream()),
                "rba_add_layer_norm_f32")
     return s, y
+
+
+def skinny_linear(x, weight, bias=None, relu=False):
+    """F.linear(x, weight, bias) [+ ReLU] for x with at most 128 rows (the decoder's 100 queries): [..., K] -> [..., N]."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(weight, "weight", dim=2)
+    K = x.shape[-1]
+    N = weight.shape[0]
+    M = x.numel() // K if K else 0
+    if weight.shape[1] != K or K % 32 or M > 128:
+        raise RbaHipError("skinny_linear needs weight [N,K], K % 32 == 0 and at most 128 rows")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+        if bias.numel() != N:
+            raise RbaHipError("bias must have N elements")
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_skinny_linear_f32(_p(x), _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), _stream()),
+               "rba_skinny_linear_f32")
+    return out

@@ -310,3 +310,19 @@ def test_add_layer_norm(ops, rows, C):
     x3 = x.view(1, rows, C)
     _, y4 = ops.add_layer_norm(dev(x3), dev(w), dev(b), 1e-5, residual=dev(t.view(1, rows, C)))
     assert y4.shape == (1, rows, C) and maxerr(y4, F.layer_norm(x3 + t.view(1, rows, C), (C,), w, b, 1e-5)) < 5e-6
+
+
+# ----------------------------------------------------------------------------------- skinny linear
+@pytest.mark.parametrize("M,N,K,relu,has_bias", [(100, 2048, 256, True, True), (100, 256, 2048, False, False), (100, 20, 256, False, True),
+                                                  (16, 64, 64, False, True), (1, 5, 32, True, True), (128, 256, 256, False, True),
+                                                  (37, 129, 96, True, False)])
+def test_skinny_linear(ops, M, N, K, relu, has_bias):
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) if has_bias else None
+    ref = F.linear(x.double(), w.double(), b.double() if has_bias else None)
+    ref = F.relu(ref) if relu else ref
+    out = ops.skinny_linear(dev(x), dev(w), dev(b) if has_bias else None, relu)
+    assert out.shape == (M, N) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
+    out3 = ops.skinny_linear(dev(x.view(1, M, K)), dev(w), dev(b) if has_bias else None, relu)
+    assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
