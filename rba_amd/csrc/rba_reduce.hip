@@ -7,6 +7,7 @@
 // probabilities are wave-uniform (scalar loads -> SGPR operands of the FMAs), K accumulators per pixel
 // live in VGPRs, nothing but rba (and optionally sem_seg / argmax) is written.  Algorithmic bytes per
 // launch: 4*Q*HW + 4*Q*K + 4*HW (+ 4*K*HW with sem_seg, + 4*HW with argmax).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/rba_hip.h"
 
@@ -443,7 +444,11 @@ int launch_up4(const float* low, const float* prob, float* rba, float* sem, int3
 
 }  // namespace
 
-extern "C" int rba_hip_version(void) { return 110; }
+// defined further down (matrix-pipe K1 with wave-private LDS transposition)
+template <int KX, int U>
+int launch_reduce_mfma_wl(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int bpc, hipStream_t st);
+
+extern "C" int rba_hip_version(void) { return 120; }
 
 extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
                               int Q, int K, int64_t HW, int score_mode, void* stream) {
@@ -454,6 +459,18 @@ extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* r
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (HW % 4 == 0) && ((((uintptr_t)mask | (uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
+  // opt-in (RBA_K1_VARIANT=mfma, A/B hook): score-only RbA with 16 <= K <= 20 on the matrix pipe (wave-private LDS
+  // transposition).  Inside the pipeline it measured 195 us against 172 us for the VALU kernel below, so it is not the default.
+  static const bool k1_mfma = getenv("RBA_K1_VARIANT") && getenv("RBA_K1_VARIANT")[0] == 'm';
+  if (k1_mfma && vec4 && mode == 0 && !sem_seg && !argmax && K >= 16 && K <= 20 && Q <= 800) {
+    switch (K - 16) {
+      case 0: return launch_reduce_mfma_wl<0, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
+      case 1: return launch_reduce_mfma_wl<1, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
+      case 2: return launch_reduce_mfma_wl<2, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
+      case 3: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
+      default: return launch_reduce_mfma_wl<4, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
+    }
+  }
   if (K == 19 && vec4) return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st, mode);
   if (K == 20 && vec4) return launch_reduce_fast<20, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st, mode);
   if (K <= 32 && vec4) return launch_reduce<32, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
@@ -578,6 +595,209 @@ int launch_reduce_mfma_lds(const float* mask, const float* prob, float* rba, int
   return rba_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K1 on the matrix pipe with wave-private LDS transposition ("wl").  Diagnosis (profiles/r01_k1_bandwidth_probes.txt):
+// the VALU kernel is VALU-bound -- 76 fp32 FMAs + 4 sigmoids per lane per plane cost ~165 us whether or not they depend
+// on the loaded data, while its load pattern alone streams in 128 us.  So the contraction moves to the matrix pipe, but
+// the loads keep the good pattern (one wave-load = 1 KiB of ONE plane, ring of 2): a wave takes planes q..q+3 one at a
+// time, writes sigmoid(mask) for its 256 pixels into a 4 KiB wave-private LDS tile [4 planes][256 px] (no workgroup
+// barrier: LDS ops of one wave complete in order), then reads the MFMA B operand back transposed -- lane (k = lane/16,
+// j = lane%16) reads plane k, pixel 16 g + j -- and issues 16 v_mfma_f32_16x16x4_f32 (16 pixel groups x 4 queries, classes
+// 0..15 on the rows).  Classes 16..18 stay on VALU with scalar-register probabilities (the plane index is wave-uniform).
+template <int KX, int U>
+__global__ __launch_bounds__(256, 4) void rba_reduce_mfma_wl_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                    float* __restrict__ rba, int Q, int K, int64_t HW, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int QP = (Q + 3) & ~3;
+  float* Pm = lds;                                                    // [QP][16] classes 0..15 (zero rows beyond Q)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
+  float* Sw = lds + QP * 16 + wave * 1024;                            // this wave's [4][256] tile
+  for (int i = threadIdx.x; i < QP * 16; i += 256) {
+    const int q = i >> 4, c = i & 15;
+    Pm[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 4 + wave) * 256 + 4 * lane;   // this lane's 4 pixels (load side)
+    const bool active = p0 < HW;
+    const float* mp = mask + (active ? p0 : 0);
+    f32x4_m acc[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = (f32x4_m){0.f, 0.f, 0.f, 0.f};
+    float ex[KX > 0 ? KX : 1][4];
+#pragma unroll
+    for (int e = 0; e < (KX > 0 ? KX : 1); ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ex[e][i] = 0.f;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+    for (int q0 = 0; q0 < QP; q0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u;
+        const f32x4 m4 = buf[u % U];
+        const int qn = q + U < Q ? q + U : Q - 1;
+        buf[u % U] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+        f32x4 sg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sg[i] = rba_sigmoid(m4[i]);
+        *reinterpret_cast<f32x4*>(Sw + u * 256 + 4 * lane) = sg;
+        if (KX > 0 && q < Q) {                                        // wave-uniform
+          const float* pq = prob + q * K + 16;
+#pragma unroll
+          for (int e = 0; e < KX; ++e) {
+            const float pe = pq[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[e][i] = fmaf(pe, sg[i], ex[e][i]);
+          }
+        }
+      }
+      const float a = Pm[(q0 + kk) * 16 + l15];
+      const float* sb = Sw + kk * 256 + l15;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[16 * g], acc[g], 0, 0, 0);
+    }
+    // acc[g][r] = sem[class 4 kk + r][pixel 16 g + l15]: tanh-sum over the lane's 4 classes, then over the 4 lane groups
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsum += rba_tanh(acc[g][r]);
+      tsum += __shfl_xor(tsum, 16, RBA_WAVE);
+      tsum += __shfl_xor(tsum, 32, RBA_WAVE);
+      if (kk == 0) Sw[16 * g + l15] = tsum;                           // re-use the tile: totals by pixel
+    }
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(Sw + 4 * lane);   // same wave wrote it: in-order LDS, no barrier needed
+    float r4[4] = {t4[0], t4[1], t4[2], t4[3]};
+    if (KX > 0) {
+#pragma unroll
+      for (int e = 0; e < KX; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r4[i] += rba_tanh(ex[e][i]);
+    }
+    if (active) *reinterpret_cast<f32x4*>(rba + p0) = (f32x4){-r4[0], -r4[1], -r4[2], -r4[3]};
+  }
+}
+
+template <int KX, int U>
+int launch_reduce_mfma_wl(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int bpc, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256LL * bpc;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  const size_t shm = ((size_t)((Q + 3) & ~3) * 16 + 4 * 1024) * sizeof(float);
+  if (shm > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_mfma_wl_kernel<KX, U>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, Q, K, HW, (int)tiles);
+  return rba_launch_status();
+}
+
+// "wl2": as wl, but software-pipelined inside the wave: the 16 MFMAs of plane group n-1 (B operands preloaded from LDS tile
+// (n-1)&1) are issued four at a time between the sigmoid/VALU work of the four planes of group n (written to tile n&1), so the
+// matrix pipe runs under the VALU work instead of after it.
+template <int KX, int U>
+__global__ __launch_bounds__(256, 4) void rba_reduce_mfma_wl2_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                     float* __restrict__ rba, int Q, int K, int64_t HW, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int QP = (Q + 3) & ~3;
+  float* Pm = lds;                                                    // [QP + 4][16], zero rows beyond Q
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
+  float* Sw = lds + (QP + 4) * 16 + wave * 2048;                      // this wave's two [4][256] tiles
+  for (int i = threadIdx.x; i < (QP + 4) * 16; i += 256) {
+    const int q = i >> 4, c = i & 15;
+    Pm[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  __syncthreads();
+  const int G = QP / 4;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 4 + wave) * 256 + 4 * lane;
+    const bool active = p0 < HW;
+    const float* mp = mask + (active ? p0 : 0);
+    f32x4_m acc[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = (f32x4_m){0.f, 0.f, 0.f, 0.f};
+    float ex[KX > 0 ? KX : 1][4];
+#pragma unroll
+    for (int e = 0; e < (KX > 0 ? KX : 1); ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ex[e][i] = 0.f;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+    // n = 0 .. G: iteration n does the VALU work of group n (if n < G) and the MFMAs of group n-1 (if n > 0)
+    for (int n = 0; n <= G; ++n) {
+      float a = 0.f, b[16];
+      const bool do_mma = n > 0, do_valu = n < G;
+      if (do_mma) {
+        a = Pm[((n - 1) * 4 + kk) * 16 + l15];
+        const float* sb = Sw + ((n - 1) & 1) * 1024 + kk * 256 + l15;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) b[g] = sb[16 * g];
+      }
+      float* sw = Sw + (n & 1) * 1024;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (do_valu) {
+          const int q = n * 4 + u;
+          const f32x4 m4 = buf[u % U];
+          const int qn = q + U < Q ? q + U : Q - 1;
+          buf[u % U] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+          f32x4 sg;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sg[i] = rba_sigmoid(m4[i]);
+          *reinterpret_cast<f32x4*>(sw + u * 256 + 4 * lane) = sg;
+          if (KX > 0 && q < Q) {
+            const float* pq = prob + q * K + 16;
+#pragma unroll
+            for (int e = 0; e < KX; ++e) {
+              const float pe = pq[e];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ex[e][i] = fmaf(pe, sg[i], ex[e][i]);
+            }
+          }
+        }
+        if (do_mma) {
+#pragma unroll
+          for (int g = 4 * u; g < 4 * u + 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[g], 0, 0, 0);
+        }
+      }
+    }
+    float* st = Sw;                                                    // totals by pixel, re-using tile 0
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsum += rba_tanh(acc[g][r]);
+      tsum += __shfl_xor(tsum, 16, RBA_WAVE);
+      tsum += __shfl_xor(tsum, 32, RBA_WAVE);
+      if (kk == 0) st[16 * g + l15] = tsum;
+    }
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + 4 * lane);
+    float r4[4] = {t4[0], t4[1], t4[2], t4[3]};
+    if (KX > 0) {
+#pragma unroll
+      for (int e = 0; e < KX; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r4[i] += rba_tanh(ex[e][i]);
+    }
+    if (active) *reinterpret_cast<f32x4*>(rba + p0) = (f32x4){-r4[0], -r4[1], -r4[2], -r4[3]};
+  }
+}
+
+template <int KX, int U>
+int launch_reduce_mfma_wl2(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int bpc, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256LL * bpc;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  const size_t shm = ((size_t)(((Q + 3) & ~3) + 4) * 16 + 4 * 2048) * sizeof(float);
+  if (shm > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_mfma_wl2_kernel<KX, U>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, Q, K, HW, (int)tiles);
+  return rba_launch_status();
+}
+
 // Bandwidth probes (tuning only): same plane-by-plane access pattern as the fast kernel, trivial math.
 template <int VEC, int U, int WPS, int TPB>
 __global__ __launch_bounds__(TPB, (WPS * 256 + TPB - 1) / TPB) void rba_bw_probe_kernel(const float* __restrict__ mask, float* __restrict__ rba,
@@ -649,6 +869,71 @@ __global__ __launch_bounds__(256) void rba_bw_probe4_kernel(const float* __restr
     if (kk == 0) *reinterpret_cast<f32x4*>(rba + p) = acc;
   }
 }
+// probe: K1's loads + K1's VALU work, but the VALU work does not depend on the loaded data (DEP = false) or does (DEP = true)
+template <int U, int WPS, bool DEP, int WORK = 0>
+__global__ __launch_bounds__(256, WPS) void rba_valu_probe_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                  float* __restrict__ rba, int Q, int64_t HW, int tiles) {
+  constexpr int K = 19, VEC = 4;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * VEC;
+    if (p0 >= HW) continue;
+    float acc[K][VEC];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+    const float* mp = mask + p0;
+    float buf[U][VEC];
+    float fake[VEC] = {0.1f * threadIdx.x, 0.2f, 0.3f, 0.4f};
+    float sink = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec<VEC>(mp + (int64_t)(u < Q ? u : Q - 1) * HW, buf[u]);
+    for (int q0 = 0; q0 + U <= Q; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        float s[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          s[i] = WORK == 1 ? (DEP ? buf[u][i] : fake[i]) : rba_sigmoid(DEP ? buf[u][i] : fake[i]);
+          if (!DEP) { sink += buf[u][i]; fake[i] += 1e-3f; }
+        }
+        const int qn = q + U < Q ? q + U : Q - 1;
+        load_vec<VEC>(mp + (int64_t)qn * HW, buf[u]);
+        const float* pq = prob + q * K;
+        if (WORK == 2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[0][i] += s[i];
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float pk = pq[k];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(pk, s[i], acc[k][i]);
+          }
+        }
+      }
+    }
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { r[i] = sink; }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] += acc[k][i];
+    store_vec<VEC>(rba + p0, r);
+  }
+}
+template <int U, int WPS, bool DEP, int WORK = 0>
+int launch_valu_probe(const float* mask, const float* prob, float* rba, int Q, int64_t HW, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  const int64_t cap = 256LL * WPS;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  hipLaunchKernelGGL((rba_valu_probe_kernel<U, WPS, DEP, WORK>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, Q, HW, (int)tiles);
+  return rba_launch_status();
+}
+
 // Tuning hook (not part of the public ABI in include/rba_hip.h): K = 19 score-only variants of the fast kernel.
 extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, float* rba, int Q, int64_t HW, int variant,
                                    void* stream) {
@@ -670,6 +955,18 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
     case 12: return launch_reduce_fast<19, 4, 1, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
     case 13: return launch_reduce_fast<19, 4, 1, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
     case 14: return launch_reduce_fast<19, 4, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 82: return launch_valu_probe<2, 4, true, 1>(mask, cls_prob, rba, Q, HW, st);
+    case 83: return launch_valu_probe<2, 4, true, 2>(mask, cls_prob, rba, Q, HW, st);
+    case 80: return launch_valu_probe<2, 4, false>(mask, cls_prob, rba, Q, HW, st);
+    case 81: return launch_valu_probe<2, 4, true>(mask, cls_prob, rba, Q, HW, st);
+    case 90: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 91: return launch_reduce_mfma_wl<3, 1>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 92: return launch_reduce_mfma_wl<3, 4>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 93: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, 19, HW, 3, st);
+    case 94: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 95: return launch_reduce_mfma_wl2<3, 2>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 96: return launch_reduce_mfma_wl2<3, 2>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 97: return launch_reduce_mfma_wl2<3, 4>(mask, cls_prob, rba, Q, 19, HW, 4, st);
     case 50: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 8, st);
     case 51: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 4, st);
     case 52: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 6, st);

@@ -19,7 +19,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 mask = torch.randn(Q, H, W, device="cuda", generator=g) * 5
 prob = torch.softmax(torch.randn(Q, 20, device="cuda", generator=g) * 3, -1)[:, :19].contiguous()
 ref = None
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 12, 13, 14]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 94, 95, 96, 97]
 times = {v: [] for v in variants}
 outs = {}
 st = torch.cuda.current_stream().cuda_stream
