@@ -178,3 +178,43 @@ def test_sparse_intermediate_heads_are_exact(name):
     pred.sparse_intermediate_heads = False
     cls_d, msk_d, _, _ = model.predict([{"image": image}])
     assert torch.equal(cls_s, cls_d) and torch.equal(msk_s, msk_d)
+
+
+def test_batch_of_different_sizes_and_float_input(golden):
+    """ImageList semantics (maskformer_model.py:255-257): each image is normalised, then zero-padded bottom/right to the
+    common size (multiple of 32); every image's outputs are cropped back to its own size.  NOTE: padding an image to a
+    LARGER common size changes its result (the network sees more zero border), exactly as in the reference -- so the oracle
+    is run on the identically padded input."""
+    import torch.nn.functional as F
+    from oracle import ref_ops
+    model, a, sd = build("tiny1", 0)
+    g = torch.Generator().manual_seed(9)
+    im0 = torch.randint(0, 256, (3, 60, 90), generator=g, dtype=torch.uint8)
+    im1 = torch.randint(0, 256, (3, 33, 70), generator=g, dtype=torch.uint8).float()        # float input, 0..255
+    outs = model([{"image": im0}, {"image": im1}], return_argmax=True)
+    assert outs[0]["sem_seg"].shape == (19, 60, 90) and outs[1]["sem_seg"].shape == (19, 33, 70)
+    ref0 = ref_model.forward(im0, sd, a)                                                       # common size 64 x 96 = im0's own pad
+    assert maxerr(outs[0]["rba"], ref0["rba"]) < 1e-4 and maxerr(outs[0]["sem_seg"], ref0["sem_seg"]) < 1e-4
+    # oracle for im1 inside a 64 x 96 canvas: normalise, pad, run the padded tensor through the oracle stages
+    mean = torch.tensor(ref_model.PIXEL_MEAN).view(-1, 1, 1); std = torch.tensor(ref_model.PIXEL_STD).view(-1, 1, 1)
+    x = F.pad((im1 - mean) / std, (0, 96 - 70, 0, 64 - 33))[None]
+    feats = ref_model.swin_backbone(x, sd, a)
+    mf, ms = ref_model.pixel_decoder(feats, sd, a)
+    cls, masks = ref_model.transformer_decoder(ms, mf, sd, a)
+    sem = ref_ops.semantic_inference(cls[0], ref_ops.upsample_bilinear(masks, (64, 96))[0])[:, :33, :70]
+    assert maxerr(outs[1]["sem_seg"], sem) < 1e-4 and maxerr(outs[1]["rba"], ref_ops.rba_score(sem)) < 1e-4
+
+
+def test_requested_output_resolution(golden):
+    """batched_inputs[i]["height"/"width"]: sem_seg_postprocess resizes the cropped result (maskformer_model.py:312-313, 330-332)."""
+    from oracle import ref_ops
+    g = golden("g4_tiny1_60x90")
+    model, a, sd = build("tiny1", 0)
+    image = T(g["image"])
+    out = model([{"image": image, "height": 120, "width": 200}])[0]
+    assert out["sem_seg"].shape == (19, 120, 200)
+    want = ref_ops.upsample_bilinear(T(g["sem_seg"])[None], (120, 200))[0]
+    assert maxerr(out["sem_seg"], want) < 1e-4
+    assert maxerr(out["rba"], ref_ops.rba_score(want)) < 1e-4
+    with pytest.raises(NotImplementedError):
+        model([{"image": image}], return_aux=True)
