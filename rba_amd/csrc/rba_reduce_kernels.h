@@ -1,0 +1,429 @@
+// Shared K1 templates (rba_reduce.hip = the shipped entry points, rba_reduce_tune.hip = probes and experimental variants).
+#pragma once
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/rba_hip.h"
+
+namespace rba_k1 {
+
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> { using type = f32x4; };
+template <>
+struct VecT<2> { using type = f32x2; };
+template <>
+struct VecT<1> { using type = float; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+  using T = typename VecT<VEC>::type;
+  const T t = __builtin_nontemporal_load(reinterpret_cast<const T*>(p));   // streamed once: keep it out of L2's way
+  if constexpr (VEC == 1) v[0] = t;
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = t[i];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+  using T = typename VecT<VEC>::type;
+  T t;
+  if constexpr (VEC == 1) t = v[0];
+  else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) t[i] = v[i];
+  }
+  *reinterpret_cast<T*>(p) = t;
+}
+
+// epilogue shared by both kernels: tanh-sum, optional sem_seg / argmax stores for VEC pixels at p0
+// score modes (the reference's interchangeable anomaly_score_func's on the same sem_seg):
+//   0  RbA               -sum_k tanh(sem_k)        evaluate_ood.py:143-150
+//   1  energy            -logsumexp_k(sem_k)       evaluate_ood.py:152-159
+//   2  neg. logit sum    -sum_k sem_k              support.py:115-132
+template <int KMAX, int VEC>
+__device__ __forceinline__ void rba_score(const float (&acc)[KMAX][VEC], int K, int mode, float (&r)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) r[i] = 0.f;
+  if (mode == 0) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] -= rba_tanh(acc[k][i]);
+  } else if (mode == 2) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] -= acc[k][i];
+  } else {
+    float mx[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) mx[i] = acc[0][i];
+#pragma unroll
+    for (int k = 1; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) mx[i] = fmaxf(mx[i], acc[k][i]);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r[i] += expf(acc[k][i] - mx[i]);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = -(mx[i] + logf(r[i]));
+  }
+}
+
+// epilogue shared by both kernels: score, optional sem_seg / argmax stores for VEC pixels at p0
+template <int KMAX, int VEC, bool SEM, bool ARG>
+__device__ __forceinline__ void rba_epilogue(float (&acc)[KMAX][VEC], int K, int mode, float* rba, float* sem, int32_t* argmax,
+                                             int64_t p0, int64_t plane) {
+  float r[VEC];
+  rba_score<KMAX, VEC>(acc, K, mode, r);
+  int best[VEC];
+  float bestv[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { best[i] = 0; bestv[i] = acc[0][i]; }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < K) {
+      if (ARG) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+          if (acc[k][i] > bestv[i]) { bestv[i] = acc[k][i]; best[i] = k; }
+      }
+      if (SEM) store_vec<VEC>(sem + (int64_t)k * plane + p0, acc[k]);
+    }
+  }
+  store_vec<VEC>(rba + p0, r);
+  if (ARG) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) argmax[p0 + i] = best[i];
+  }
+}
+
+// One thread owns VEC consecutive pixels.  KMAX = compile-time bound on K (== K on the fast path).
+template <int KMAX, int VEC, bool SEM, bool ARG>
+__global__ __launch_bounds__(256) void rba_reduce_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                         float* __restrict__ rba, float* __restrict__ sem,
+                                                         int32_t* __restrict__ argmax, int Q, int K, int64_t HW, int mode) {
+  const int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (p0 >= HW) return;
+  float acc[KMAX][VEC];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+
+  const float* mp = mask + p0;
+#pragma unroll 4
+  for (int q = 0; q < Q; ++q) {
+    float m[VEC], s[VEC];
+    load_vec<VEC>(mp + (int64_t)q * HW, m);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = rba_sigmoid(m[i]);
+    const float* pq = prob + q * K;   // wave-uniform -> s_load
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const float pk = pq[k];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(pk, s[i], acc[k][i]);
+      }
+    }
+  }
+  rba_epilogue<KMAX, VEC, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
+}
+
+// x4 upsample fused in front: thread owns 4 consecutive output pixels of one output row, i.e. output
+// columns 4*j .. 4*j+3 which interpolate low-res columns j-1, j, j+1 and rows (i0, i1) of the low-res map.
+template <int KMAX, bool SEM, bool ARG>
+__global__ __launch_bounds__(256) void rba_reduce_up4_kernel(const float* __restrict__ low, const float* __restrict__ prob,
+                                                             float* __restrict__ rba, float* __restrict__ sem,
+                                                             int32_t* __restrict__ argmax, int Q, int K, int h, int w,
+                                                             int crop_h, int crop_w, int wq /* ceil(crop_w/4) */, int mode) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;   // low-res column == group of 4 output columns
+  const int y = blockIdx.y;                              // output row
+  if (j >= wq) return;
+  const BilinearTap ty = bilinear_tap(y, 0.25f, h);
+  // output x = 4j+r, r=0..3: src = j + (r+0.5)/4 - 0.5 -> taps (j-1,j) for r<2, (j,j+1) for r>=2, clamped
+  BilinearTap tx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tx[r] = bilinear_tap(4 * j + r, 0.25f, w);
+  const int jm = j > 0 ? j - 1 : 0, jp = j < w - 1 ? j + 1 : w - 1;
+
+  float acc[KMAX][4];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
+
+  const float* r0 = low + (int64_t)ty.i0 * w;
+  const float* r1 = low + (int64_t)ty.i1 * w;
+  const int64_t plane = (int64_t)h * w;
+#pragma unroll 2
+  for (int q = 0; q < Q; ++q) {
+    const float a0 = r0[jm], a1 = r0[j], a2 = r0[jp];
+    const float b0 = r1[jm], b1 = r1[j], b2 = r1[jp];
+    r0 += plane; r1 += plane;
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // ATen order: l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).  Columns: r<2 -> (j-1, j), r>=2 -> (j, j+1);
+      // at a clamped border ATen's (i0,i1,l1) is (0,1,0) resp. (w-1,w-1,l1): jm/jp clamping gives the same value.
+      const float v00 = r < 2 ? a0 : a1, v01 = r < 2 ? a1 : a2;
+      const float v10 = r < 2 ? b0 : b1, v11 = r < 2 ? b1 : b2;
+      const float top = tx[r].l0 * v00 + tx[r].l1 * v01;
+      const float bot = tx[r].l0 * v10 + tx[r].l1 * v11;
+      s[r] = rba_sigmoid(ty.l0 * top + ty.l1 * bot);
+    }
+    const float* pq = prob + q * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const float pk = pq[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[k][i] = fmaf(pk, s[i], acc[k][i]);
+      }
+    }
+  }
+  const int64_t oplane = (int64_t)crop_h * crop_w;
+  const int64_t p0 = (int64_t)y * crop_w + 4 * j;
+  if (4 * j + 3 < crop_w && (crop_w & 3) == 0) {
+    rba_epilogue<KMAX, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, oplane);
+  } else {  // ragged right edge / unaligned rows: scalar stores
+    float r[4];
+    rba_score<KMAX, 4>(acc, K, mode, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (4 * j + i >= crop_w) break;
+      float bv = acc[0][i];
+      int b = 0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          if (acc[k][i] > bv) { bv = acc[k][i]; b = k; }
+          if (SEM) sem[(int64_t)k * oplane + p0 + i] = acc[k][i];
+        }
+      }
+      rba[p0 + i] = r[i];
+      if (ARG) argmax[p0 + i] = b;
+    }
+  }
+}
+
+template <int K, int VEC, bool SEM, bool ARG, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_fast_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                 float* __restrict__ rba, float* __restrict__ sem,
+                                                                 int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode) {
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * VEC;
+    if (p0 >= HW) continue;
+    float acc[K][VEC];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+    const float* mp = mask + p0;
+    float buf[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec<VEC>(mp + (int64_t)(u < Q ? u : Q - 1) * HW, buf[u]);
+    const int Qmain = Q / U * U;
+    for (int q0 = 0; q0 < Qmain; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        float s[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = rba_sigmoid(buf[u][i]);
+        const int qn = q + U < Q ? q + U : Q - 1;          // clamped prefetch (re-reads the last plane from L2)
+        load_vec<VEC>(mp + (int64_t)qn * HW, buf[u]);
+        const float* pq = prob + q * K;                    // wave-uniform -> scalar loads, SGPR operands
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float pk = pq[k];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(pk, s[i], acc[k][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                          // tail: Q % U planes, already in the ring
+      const int q = Qmain + u;
+      if (q < Q) {
+        const float* pq = prob + q * K;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float si = rba_sigmoid(buf[u][i]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k][i] = fmaf(pq[k], si, acc[k][i]);
+        }
+      }
+    }
+    rba_epilogue<K, VEC, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
+  }
+}
+
+template <int K, int VEC, int U, int WPS>
+int launch_reduce_fast(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q,
+                       int64_t HW, hipStream_t st, int mode = 0) {
+  const int64_t per_block = 256 * (int64_t)VEC;
+  const int64_t tiles = (HW + per_block - 1) / per_block;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  // 256 CUs x WPS resident 256-thread blocks (WPS waves per SIMD); round the grid so that every block
+  // gets the same number of tiles when possible
+  const int64_t cap = 256 * WPS;
+  int64_t grid = tiles;
+  if (tiles > cap) {
+    const int64_t rounds = (tiles + cap - 1) / cap;
+    grid = (tiles + rounds - 1) / rounds;
+  }
+#define RBA_L(S, A) \
+  hipLaunchKernelGGL((rba_reduce_fast_kernel<K, VEC, S, A, U, WPS>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW, (int)tiles, mode)
+  if (sem && argmax) RBA_L(true, true);
+  else if (sem) RBA_L(true, false);
+  else if (argmax) RBA_L(false, true);
+  else RBA_L(false, false);
+#undef RBA_L
+  return rba_launch_status();
+}
+
+typedef float f32x4_m __attribute__((ext_vector_type(4)));
+
+template <int KMAX, int VEC>
+int launch_reduce(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K,
+                  int64_t HW, hipStream_t st, int mode = 0) {
+  const int threads = 256;
+  const int64_t per_block = (int64_t)threads * VEC;
+  const unsigned blocks = (unsigned)((HW + per_block - 1) / per_block);
+#define RBA_L(S, A) \
+  hipLaunchKernelGGL((rba_reduce_kernel<KMAX, VEC, S, A>), dim3(blocks), dim3(threads), 0, st, mask, prob, rba, sem, argmax, Q, K, HW, mode)
+  if (sem && argmax) RBA_L(true, true);
+  else if (sem) RBA_L(true, false);
+  else if (argmax) RBA_L(false, true);
+  else RBA_L(false, false);
+#undef RBA_L
+  return rba_launch_status();
+}
+
+template <int KMAX>
+int launch_up4(const float* low, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K, int h, int w,
+               int crop_h, int crop_w, hipStream_t st, int mode) {
+  const int wq = (crop_w + 3) / 4;
+  const int threads = wq >= 256 ? 256 : (wq >= 128 ? 128 : 64);
+  dim3 grid((wq + threads - 1) / threads, crop_h);
+#define RBA_L(S, A) \
+  hipLaunchKernelGGL((rba_reduce_up4_kernel<KMAX, S, A>), grid, dim3(threads), 0, st, low, prob, rba, sem, argmax, Q, K, h, w, crop_h, crop_w, wq, mode)
+  if (sem && argmax) RBA_L(true, true);
+  else if (sem) RBA_L(true, false);
+  else if (argmax) RBA_L(false, true);
+  else RBA_L(false, false);
+#undef RBA_L
+  return rba_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// K1 on the matrix pipe with wave-private LDS transposition ("wl").  Diagnosis (profiles/r01_k1_bandwidth_probes.txt):
+// the VALU kernel is VALU-bound -- 76 fp32 FMAs + 4 sigmoids per lane per plane cost ~165 us whether or not they depend
+// on the loaded data, while its load pattern alone streams in 128 us.  So the contraction moves to the matrix pipe, but
+// the loads keep the good pattern (one wave-load = 1 KiB of ONE plane, ring of 2): a wave takes planes q..q+3 one at a
+// time, writes sigmoid(mask) for its 256 pixels into a 4 KiB wave-private LDS tile [4 planes][256 px] (no workgroup
+// barrier: LDS ops of one wave complete in order), then reads the MFMA B operand back transposed -- lane (k = lane/16,
+// j = lane%16) reads plane k, pixel 16 g + j -- and issues 16 v_mfma_f32_16x16x4_f32 (16 pixel groups x 4 queries, classes
+// 0..15 on the rows).  Classes 16..18 stay on VALU with scalar-register probabilities (the plane index is wave-uniform).
+template <int KX, int U>
+__global__ __launch_bounds__(256, 4) void rba_reduce_mfma_wl_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                    float* __restrict__ rba, int Q, int K, int64_t HW, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int QP = (Q + 3) & ~3;
+  float* Pm = lds;                                                    // [QP][16] classes 0..15 (zero rows beyond Q)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
+  float* Sw = lds + QP * 16 + wave * 1024;                            // this wave's [4][256] tile
+  for (int i = threadIdx.x; i < QP * 16; i += 256) {
+    const int q = i >> 4, c = i & 15;
+    Pm[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 4 + wave) * 256 + 4 * lane;   // this lane's 4 pixels (load side)
+    const bool active = p0 < HW;
+    const float* mp = mask + (active ? p0 : 0);
+    f32x4_m acc[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = (f32x4_m){0.f, 0.f, 0.f, 0.f};
+    float ex[KX > 0 ? KX : 1][4];
+#pragma unroll
+    for (int e = 0; e < (KX > 0 ? KX : 1); ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ex[e][i] = 0.f;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+    for (int q0 = 0; q0 < QP; q0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u;
+        const f32x4 m4 = buf[u % U];
+        const int qn = q + U < Q ? q + U : Q - 1;
+        buf[u % U] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+        f32x4 sg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sg[i] = rba_sigmoid(m4[i]);
+        *reinterpret_cast<f32x4*>(Sw + u * 256 + 4 * lane) = sg;
+        if (KX > 0 && q < Q) {                                        // wave-uniform
+          const float* pq = prob + q * K + 16;
+#pragma unroll
+          for (int e = 0; e < KX; ++e) {
+            const float pe = pq[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[e][i] = fmaf(pe, sg[i], ex[e][i]);
+          }
+        }
+      }
+      const float a = Pm[(q0 + kk) * 16 + l15];
+      const float* sb = Sw + kk * 256 + l15;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sb[16 * g], acc[g], 0, 0, 0);
+    }
+    // acc[g][r] = sem[class 4 kk + r][pixel 16 g + l15]: tanh-sum over the lane's 4 classes, then over the 4 lane groups
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsum += rba_tanh(acc[g][r]);
+      tsum += __shfl_xor(tsum, 16, RBA_WAVE);
+      tsum += __shfl_xor(tsum, 32, RBA_WAVE);
+      if (kk == 0) Sw[16 * g + l15] = tsum;                           // re-use the tile: totals by pixel
+    }
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(Sw + 4 * lane);   // same wave wrote it: in-order LDS, no barrier needed
+    float r4[4] = {t4[0], t4[1], t4[2], t4[3]};
+    if (KX > 0) {
+#pragma unroll
+      for (int e = 0; e < KX; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r4[i] += rba_tanh(ex[e][i]);
+    }
+    if (active) *reinterpret_cast<f32x4*>(rba + p0) = (f32x4){-r4[0], -r4[1], -r4[2], -r4[3]};
+  }
+}
+
+template <int KX, int U>
+int launch_reduce_mfma_wl(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int bpc, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256LL * bpc;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  const size_t shm = ((size_t)((Q + 3) & ~3) * 16 + 4 * 1024) * sizeof(float);
+  if (shm > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_mfma_wl_kernel<KX, U>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, Q, K, HW, (int)tiles);
+  return rba_launch_status();
+}
+
+
+}  // namespace rba_k1

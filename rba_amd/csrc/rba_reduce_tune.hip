@@ -1,0 +1,528 @@
+// K1 tuning translation unit: bandwidth probes of the access pattern, VALU-isolation probes and the experimental kernel variants
+// (matrix-pipe, LDS-staged, lockstep ...) behind rba_reduce_f32_tune, used by tools/k1_sweep.py.  Nothing here is on the product
+// path; results are recorded in profiles/r01_k1_variant_sweep.txt and profiles/r01_k1_bandwidth_probes.txt.
+#include "rba_reduce_kernels.h"
+
+using namespace rba_k1;
+
+// Score-only fast path on the matrix pipe (16 <= K <= 20).  The contraction sem[k,p] = sum_q P[q,k] s[q,p] is a
+// [K x Q] . [Q x pixels] product: classes 0..15 are the 16 rows of v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma
+// chain = ascending q, 100 % of the tile used), the K-16 remaining classes stay on VALU.  VALU is left with the
+// sigmoids only, so it no longer competes with the HBM stream for issue time, and ~40 VGPRs allow 8 waves/SIMD of
+// loads in flight.  One wave = 64 consecutive pixels x all queries; per step it loads ONE float4 per lane =
+// 4 planes (q0 + lane/16) x 64 pixels (four 256-B segments), runs 4 MFMAs (one per float4 component: B column j is
+// pixel 4j+i) and 4*KX VALU FMAs.  A operand P[q][class] and the extra-class probabilities come from an 8 KB LDS table.
+
+template <int KX, int U>
+__global__ __launch_bounds__(256) void rba_reduce_mfma_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                              float* __restrict__ rba, int Q, int K, int64_t HW,
+                                                              int64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int QP = (Q + 3) & ~3;
+  float* Pm = lds;                 // [QP][16]  classes 0..15
+  float* Px = lds + QP * 16;       // [QP][4]   classes 16..19 (zero padded)
+  for (int i = threadIdx.x; i < QP * 16; i += 256) {
+    const int q = i >> 4, c = i & 15;
+    Pm[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < QP * 4; i += 256) {
+    const int q = i >> 2, c = 16 + (i & 3);
+    Px[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int steps = QP / 4;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t p = tile * 64 + 4 * l15;
+    const bool active = p < HW;                          // HW % 4 == 0: a lane's 4 pixels are in or out together
+    const float* mp = mask + (active ? p : 0);
+    f32x4_m acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_m){0.f, 0.f, 0.f, 0.f};
+    float ex[KX > 0 ? KX : 1][4];
+#pragma unroll
+    for (int e = 0; e < (KX > 0 ? KX : 1); ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ex[e][i] = 0.f;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int q = 4 * u + kk;
+      q = q < Q ? q : Q - 1;
+      buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)q * HW));
+    }
+    for (int t0 = 0; t0 < steps; t0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u;
+        if (t < steps) {
+          const f32x4 m4 = buf[u];
+          int qn = 4 * (t + U) + kk;                     // clamped prefetch; padded queries have P = 0
+          qn = qn < Q ? qn : Q - 1;
+          buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+          const float a = Pm[(4 * t + kk) * 16 + l15];
+          float sg[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sg[i] = rba_sigmoid(m4[i]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sg[i], acc[i], 0, 0, 0);
+          if (KX > 0) {
+            const float4 px = *reinterpret_cast<const float4*>(Px + (4 * t + kk) * 4);
+            const float pe[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+            for (int e = 0; e < KX; ++e)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ex[e][i] = fmaf(pe[e], sg[i], ex[e][i]);
+          }
+        }
+      }
+    }
+    // lane holds sem[class = 4*kk + r][pixel = p + i] in acc[i][r]; tanh-sum over its 4 classes, then over kk
+    float r4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsum += rba_tanh(acc[i][r]);
+      tsum += __shfl_xor(tsum, 16, RBA_WAVE);
+      tsum += __shfl_xor(tsum, 32, RBA_WAVE);
+      r4[i] = tsum;
+    }
+    if (KX > 0) {
+#pragma unroll
+      for (int e = 0; e < KX; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = ex[e][i];                              // partial over queries q = kk (mod 4)
+          v += __shfl_xor(v, 16, RBA_WAVE);
+          v += __shfl_xor(v, 32, RBA_WAVE);
+          r4[i] += rba_tanh(v);
+        }
+    }
+    if (active && kk == 0) *reinterpret_cast<f32x4*>(rba + p) = (f32x4){-r4[0], -r4[1], -r4[2], -r4[3]};
+  }
+}
+
+template <int KX, int U>
+int launch_reduce_mfma(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int wps, hipStream_t st) {
+  const int64_t ntiles = (HW + 63) / 64;
+  const int64_t nblk_needed = (ntiles + 3) / 4;
+  int64_t grid = 256LL * wps;                           // persistent: wps blocks (4 waves) per CU
+  if (grid > nblk_needed) grid = nblk_needed;
+  const size_t shm = (size_t)((Q + 3) & ~3) * 20 * sizeof(float);
+  if (shm > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_mfma_kernel<KX, U>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, Q, K, HW, ntiles);
+  return rba_launch_status();
+}
+
+
+// LDS-staged matrix-pipe variant.  Bandwidth probes (profiles/r01_k1_bandwidth_probes.txt) show this buffer streams at
+// 7.0 TB/s when every wave has ONE 1 KiB load of ONE plane in flight at 8 waves/SIMD, and loses 10-25 % for every
+// additional plane concurrently in flight.  So: wave w of a 4-wave block loads 1 KiB (256 px) of plane 4t+w, applies
+// the sigmoid to its own 4 values and parks them in LDS [4 planes][256 px]; after one barrier each wave reads the MFMA
+// B fragments of its 64-pixel quarter (lane (k,j): 4 pixels of plane 4t+k, one ds_read_b128) and runs 4 MFMAs.
+// ~45 VGPRs -> 8 waves/SIMD.  LDS is double buffered, one barrier per 4 queries.
+template <int KX>
+__global__ __launch_bounds__(256, 8) void rba_reduce_mfma_lds_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                     float* __restrict__ rba, int Q, int K, int64_t HW,
+                                                                     int64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int QP = (Q + 3) & ~3;
+  float* Pm = lds;                     // [QP][16]
+  float* Px = lds + QP * 16;           // [QP][4]
+  float* Sb = lds + QP * 20;           // [2][4][256]
+  for (int i = threadIdx.x; i < QP * 16; i += 256) {
+    const int q = i >> 4, c = i & 15;
+    Pm[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < QP * 4; i += 256) {
+    const int q = i >> 2, c = 16 + (i & 3);
+    Px[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
+  const int steps = QP / 4;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // load side: this lane streams pixels pl..pl+3 of planes wave, wave+4, ...
+    const int64_t pl = tile * 256 + 4 * lane;
+    const float* mp = mask + (pl < HW ? pl : 0);
+    // compute side: this lane owns output pixels pc..pc+3 (within the wave's 64-pixel quarter)
+    const int64_t pc = tile * 256 + 64 * wave + 4 * l15;
+    f32x4_m acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4_m){0.f, 0.f, 0.f, 0.f};
+    float ex[KX > 0 ? KX : 1][4];
+#pragma unroll
+    for (int e = 0; e < (KX > 0 ? KX : 1); ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ex[e][i] = 0.f;
+    f32x4 cur = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(wave < Q ? wave : Q - 1) * HW));
+    for (int t = 0; t < steps; ++t) {
+      f32x4 sg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sg[i] = rba_sigmoid(cur[i]);
+      int qn = 4 * (t + 1) + wave;
+      qn = qn < Q ? qn : Q - 1;
+      cur = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));   // next plane, in flight over the barrier
+      float* sb = Sb + (t & 1) * 1024;
+      *reinterpret_cast<f32x4*>(sb + wave * 256 + 4 * lane) = sg;
+      __syncthreads();
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb + kk * 256 + 64 * wave + 4 * l15);
+      const float a = Pm[(4 * t + kk) * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b4[i], acc[i], 0, 0, 0);
+      if (KX > 0) {
+        const float4 px = *reinterpret_cast<const float4*>(Px + (4 * t + kk) * 4);
+        const float pe[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+        for (int e = 0; e < KX; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ex[e][i] = fmaf(pe[e], b4[i], ex[e][i]);
+      }
+    }
+    float r4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsum += rba_tanh(acc[i][r]);
+      tsum += __shfl_xor(tsum, 16, RBA_WAVE);
+      tsum += __shfl_xor(tsum, 32, RBA_WAVE);
+      r4[i] = tsum;
+    }
+    if (KX > 0) {
+#pragma unroll
+      for (int e = 0; e < KX; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = ex[e][i];
+          v += __shfl_xor(v, 16, RBA_WAVE);
+          v += __shfl_xor(v, 32, RBA_WAVE);
+          r4[i] += rba_tanh(v);
+        }
+    }
+    if (pc < HW && kk == 0) *reinterpret_cast<f32x4*>(rba + pc) = (f32x4){-r4[0], -r4[1], -r4[2], -r4[3]};
+    __syncthreads();     // the next tile's first LDS write must not overtake this tile's last reads
+  }
+}
+
+template <int KX>
+int launch_reduce_mfma_lds(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int bpc, hipStream_t st) {
+  const int64_t ntiles = (HW + 255) / 256;
+  int64_t grid = 256LL * bpc;
+  if (grid > ntiles) grid = ntiles;
+  const size_t shm = ((size_t)((Q + 3) & ~3) * 20 + 2 * 1024) * sizeof(float);
+  if (shm > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_mfma_lds_kernel<KX>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, Q, K, HW, ntiles);
+  return rba_launch_status();
+}
+
+// "wl2": as wl, but software-pipelined inside the wave: the 16 MFMAs of plane group n-1 (B operands preloaded from LDS tile
+// (n-1)&1) are issued four at a time between the sigmoid/VALU work of the four planes of group n (written to tile n&1), so the
+// matrix pipe runs under the VALU work instead of after it.
+template <int KX, int U>
+__global__ __launch_bounds__(256, 4) void rba_reduce_mfma_wl2_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                     float* __restrict__ rba, int Q, int K, int64_t HW, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int QP = (Q + 3) & ~3;
+  float* Pm = lds;                                                    // [QP + 4][16], zero rows beyond Q
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
+  float* Sw = lds + (QP + 4) * 16 + wave * 2048;                      // this wave's two [4][256] tiles
+  for (int i = threadIdx.x; i < (QP + 4) * 16; i += 256) {
+    const int q = i >> 4, c = i & 15;
+    Pm[i] = (q < Q && c < K) ? prob[q * K + c] : 0.f;
+  }
+  __syncthreads();
+  const int G = QP / 4;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 4 + wave) * 256 + 4 * lane;
+    const bool active = p0 < HW;
+    const float* mp = mask + (active ? p0 : 0);
+    f32x4_m acc[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = (f32x4_m){0.f, 0.f, 0.f, 0.f};
+    float ex[KX > 0 ? KX : 1][4];
+#pragma unroll
+    for (int e = 0; e < (KX > 0 ? KX : 1); ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ex[e][i] = 0.f;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+    // n = 0 .. G: iteration n does the VALU work of group n (if n < G) and the MFMAs of group n-1 (if n > 0)
+    for (int n = 0; n <= G; ++n) {
+      float a = 0.f, b[16];
+      const bool do_mma = n > 0, do_valu = n < G;
+      if (do_mma) {
+        a = Pm[((n - 1) * 4 + kk) * 16 + l15];
+        const float* sb = Sw + ((n - 1) & 1) * 1024 + kk * 256 + l15;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) b[g] = sb[16 * g];
+      }
+      float* sw = Sw + (n & 1) * 1024;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (do_valu) {
+          const int q = n * 4 + u;
+          const f32x4 m4 = buf[u % U];
+          const int qn = q + U < Q ? q + U : Q - 1;
+          buf[u % U] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+          f32x4 sg;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sg[i] = rba_sigmoid(m4[i]);
+          *reinterpret_cast<f32x4*>(sw + u * 256 + 4 * lane) = sg;
+          if (KX > 0 && q < Q) {
+            const float* pq = prob + q * K + 16;
+#pragma unroll
+            for (int e = 0; e < KX; ++e) {
+              const float pe = pq[e];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ex[e][i] = fmaf(pe, sg[i], ex[e][i]);
+            }
+          }
+        }
+        if (do_mma) {
+#pragma unroll
+          for (int g = 4 * u; g < 4 * u + 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[g], acc[g], 0, 0, 0);
+        }
+      }
+    }
+    float* st = Sw;                                                    // totals by pixel, re-using tile 0
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tsum += rba_tanh(acc[g][r]);
+      tsum += __shfl_xor(tsum, 16, RBA_WAVE);
+      tsum += __shfl_xor(tsum, 32, RBA_WAVE);
+      if (kk == 0) st[16 * g + l15] = tsum;
+    }
+    const f32x4 t4 = *reinterpret_cast<const f32x4*>(st + 4 * lane);
+    float r4[4] = {t4[0], t4[1], t4[2], t4[3]};
+    if (KX > 0) {
+#pragma unroll
+      for (int e = 0; e < KX; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r4[i] += rba_tanh(ex[e][i]);
+    }
+    if (active) *reinterpret_cast<f32x4*>(rba + p0) = (f32x4){-r4[0], -r4[1], -r4[2], -r4[3]};
+  }
+}
+
+template <int KX, int U>
+int launch_reduce_mfma_wl2(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int bpc, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256LL * bpc;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  const size_t shm = ((size_t)(((Q + 3) & ~3) + 4) * 16 + 4 * 2048) * sizeof(float);
+  if (shm > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_mfma_wl2_kernel<KX, U>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, Q, K, HW, (int)tiles);
+  return rba_launch_status();
+}
+
+// Bandwidth probes (tuning only): same plane-by-plane access pattern as the fast kernel, trivial math.
+template <int VEC, int U, int WPS, int TPB>
+__global__ __launch_bounds__(TPB, (WPS * 256 + TPB - 1) / TPB) void rba_bw_probe_kernel(const float* __restrict__ mask, float* __restrict__ rba,
+                                                                          int Q, int64_t HW, int tiles) {
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * TPB + threadIdx.x) * VEC;
+    if (p0 >= HW) continue;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    const float* mp = mask + p0;
+    float buf[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec<VEC>(mp + (int64_t)(u < Q ? u : Q - 1) * HW, buf[u]);
+    for (int q0 = 0; q0 + U <= Q; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += buf[u][i];
+        const int qn = q0 + u + U < Q ? q0 + u + U : Q - 1;
+        load_vec<VEC>(mp + (int64_t)qn * HW, buf[u]);
+      }
+    }
+    store_vec<VEC>(rba + p0, acc);
+  }
+}
+template <int VEC, int U, int WPS, int TPB>
+int launch_bw_probe(const float* mask, float* rba, int Q, int64_t HW, hipStream_t st) {
+  const int64_t per_block = TPB * (int64_t)VEC;
+  const int64_t tiles = (HW + per_block - 1) / per_block;
+  const int64_t cap = 256LL * WPS * 256 / TPB;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  hipLaunchKernelGGL((rba_bw_probe_kernel<VEC, U, WPS, TPB>), dim3((unsigned)grid), dim3(TPB), 0, st, mask, rba, Q, HW, (int)tiles);
+  return rba_launch_status();
+}
+// plane-major probe: the whole grid sweeps plane 0, then plane 1, ... (what a [Q,HW] -> [HW] reduction would look like
+// if accumulators lived in memory); only to see the raw streaming rate of this buffer
+__global__ __launch_bounds__(256) void rba_bw_linear_kernel(const float* __restrict__ mask, float* __restrict__ rba, int64_t n4) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(mask);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    acc += __builtin_nontemporal_load(m4 + i);
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) rba[0] = acc.x;
+}
+
+// probe of the MFMA kernel's load pattern: lane group g = lane/16 reads plane q0+g, 64 px per wave per load
+template <int U>
+__global__ __launch_bounds__(256) void rba_bw_probe4_kernel(const float* __restrict__ mask, float* __restrict__ rba, int Q, int64_t HW,
+                                                           int64_t ntiles) {
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
+    const int64_t p = tile * 64 + 4 * l15;
+    const float* mp = mask + p;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(4 * u + kk) * HW));
+    for (int t0 = 0; t0 < Q / 4; t0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc += buf[u];
+        int qn = 4 * (t0 + u + U) + kk;
+        qn = qn < Q ? qn : Q - 1;
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+      }
+    }
+    if (kk == 0) *reinterpret_cast<f32x4*>(rba + p) = acc;
+  }
+}
+// probe: K1's loads + K1's VALU work, but the VALU work does not depend on the loaded data (DEP = false) or does (DEP = true)
+template <int U, int WPS, bool DEP, int WORK = 0>
+__global__ __launch_bounds__(256, WPS) void rba_valu_probe_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                  float* __restrict__ rba, int Q, int64_t HW, int tiles) {
+  constexpr int K = 19, VEC = 4;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * VEC;
+    if (p0 >= HW) continue;
+    float acc[K][VEC];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[k][i] = 0.f;
+    const float* mp = mask + p0;
+    float buf[U][VEC];
+    float fake[VEC] = {0.1f * threadIdx.x, 0.2f, 0.3f, 0.4f};
+    float sink = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_vec<VEC>(mp + (int64_t)(u < Q ? u : Q - 1) * HW, buf[u]);
+    for (int q0 = 0; q0 + U <= Q; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        float s[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          s[i] = WORK == 1 ? (DEP ? buf[u][i] : fake[i]) : rba_sigmoid(DEP ? buf[u][i] : fake[i]);
+          if (!DEP) { sink += buf[u][i]; fake[i] += 1e-3f; }
+        }
+        const int qn = q + U < Q ? q + U : Q - 1;
+        load_vec<VEC>(mp + (int64_t)qn * HW, buf[u]);
+        const float* pq = prob + q * K;
+        if (WORK == 2) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[0][i] += s[i];
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float pk = pq[k];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[k][i] = fmaf(pk, s[i], acc[k][i]);
+          }
+        }
+      }
+    }
+    float r[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { r[i] = sink; }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) r[i] += acc[k][i];
+    store_vec<VEC>(rba + p0, r);
+  }
+}
+template <int U, int WPS, bool DEP, int WORK = 0>
+int launch_valu_probe(const float* mask, const float* prob, float* rba, int Q, int64_t HW, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  const int64_t cap = 256LL * WPS;
+  int64_t grid = tiles;
+  if (tiles > cap) { const int64_t rounds = (tiles + cap - 1) / cap; grid = (tiles + rounds - 1) / rounds; }
+  hipLaunchKernelGGL((rba_valu_probe_kernel<U, WPS, DEP, WORK>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, Q, HW, (int)tiles);
+  return rba_launch_status();
+}
+
+// Tuning hook (not part of the public ABI in include/rba_hip.h): K = 19 score-only variants of the fast kernel.
+extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, float* rba, int Q, int64_t HW, int variant,
+                                   void* stream) {
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    case 0: return launch_reduce_fast<19, 4, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 1: return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 2: return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 3: return launch_reduce_fast<19, 4, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 4: return launch_reduce_fast<19, 2, 4, 8>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 5: return launch_reduce_fast<19, 2, 8, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 6: return launch_reduce_fast<19, 4, 6, 3>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 7: return launch_reduce_fast<19, 4, 8, 2>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 8: return launch_reduce<19, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, 19, HW, st);
+    case 9: return launch_reduce_fast<19, 2, 4, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 10: return launch_reduce_fast<19, 4, 2, 3>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 11: return launch_reduce_fast<19, 1, 8, 8>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 12: return launch_reduce_fast<19, 4, 1, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 13: return launch_reduce_fast<19, 4, 1, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 14: return launch_reduce_fast<19, 4, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 82: return launch_valu_probe<2, 4, true, 1>(mask, cls_prob, rba, Q, HW, st);
+    case 83: return launch_valu_probe<2, 4, true, 2>(mask, cls_prob, rba, Q, HW, st);
+    case 80: return launch_valu_probe<2, 4, false>(mask, cls_prob, rba, Q, HW, st);
+    case 81: return launch_valu_probe<2, 4, true>(mask, cls_prob, rba, Q, HW, st);
+    case 90: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 91: return launch_reduce_mfma_wl<3, 1>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 92: return launch_reduce_mfma_wl<3, 4>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 93: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, 19, HW, 3, st);
+    case 94: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 95: return launch_reduce_mfma_wl2<3, 2>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 96: return launch_reduce_mfma_wl2<3, 2>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 97: return launch_reduce_mfma_wl2<3, 4>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 50: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 51: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 52: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 6, st);
+    case 53: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 16, st);
+    case 54: return launch_reduce_mfma_lds<3>(mask, cls_prob, rba, Q, 19, HW, 32, st);
+    case 40: { hipLaunchKernelGGL(rba_bw_probe4_kernel<2>, dim3(256 * 4), dim3(256), 0, st, mask, rba, Q, HW, (HW + 63) / 64); return rba_launch_status(); }
+    case 41: { hipLaunchKernelGGL(rba_bw_probe4_kernel<2>, dim3(256 * 8), dim3(256), 0, st, mask, rba, Q, HW, (HW + 63) / 64); return rba_launch_status(); }
+    case 42: { hipLaunchKernelGGL(rba_bw_probe4_kernel<1>, dim3(256 * 8), dim3(256), 0, st, mask, rba, Q, HW, (HW + 63) / 64); return rba_launch_status(); }
+    case 43: { hipLaunchKernelGGL(rba_bw_probe4_kernel<4>, dim3(256 * 2), dim3(256), 0, st, mask, rba, Q, HW, (HW + 63) / 64); return rba_launch_status(); }
+    case 44: return launch_bw_probe<4, 2, 2, 256>(mask, rba, Q, HW, st);
+    case 45: return launch_bw_probe<4, 2, 6, 256>(mask, rba, Q, HW, st);
+    case 46: return launch_bw_probe<4, 2, 8, 256>(mask, rba, Q, HW, st);
+    case 47: return launch_bw_probe<4, 1, 8, 256>(mask, rba, Q, HW, st);
+    case 48: return launch_bw_probe<4, 4, 4, 256>(mask, rba, Q, HW, st);
+    case 49: return launch_bw_probe<4, 1, 4, 256>(mask, rba, Q, HW, st);
+    case 30: return launch_bw_probe<4, 2, 4, 256>(mask, rba, Q, HW, st);
+    case 31: return launch_bw_probe<4, 4, 8, 256>(mask, rba, Q, HW, st);
+    case 32: return launch_bw_probe<4, 8, 8, 256>(mask, rba, Q, HW, st);
+    case 33: return launch_bw_probe<4, 4, 8, 512>(mask, rba, Q, HW, st);
+    case 34: return launch_bw_probe<4, 4, 8, 1024>(mask, rba, Q, HW, st);
+    case 35: return launch_bw_probe<2, 8, 8, 256>(mask, rba, Q, HW, st);
+    case 36: { hipLaunchKernelGGL(rba_bw_linear_kernel, dim3(2048), dim3(256), 0, st, mask, rba, (int64_t)Q * HW / 4); return rba_launch_status(); }
+    case 37: { hipLaunchKernelGGL(rba_bw_linear_kernel, dim3(8192), dim3(256), 0, st, mask, rba, (int64_t)Q * HW / 4); return rba_launch_status(); }
+    case 20: return launch_reduce_mfma<3, 2>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 21: return launch_reduce_mfma<3, 4>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 22: return launch_reduce_mfma<3, 2>(mask, cls_prob, rba, Q, 19, HW, 6, st);
+    case 23: return launch_reduce_mfma<3, 4>(mask, cls_prob, rba, Q, 19, HW, 4, st);
+    case 24: return launch_reduce_mfma<3, 1>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 25: return launch_reduce_mfma<3, 3>(mask, cls_prob, rba, Q, 19, HW, 8, st);
+    case 26: return launch_reduce_mfma<3, 4>(mask, cls_prob, rba, Q, 19, HW, 6, st);
+    case 27: return launch_reduce_mfma<3, 2>(mask, cls_prob, rba, Q, 19, HW, 16, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
