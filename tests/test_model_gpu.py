@@ -218,3 +218,15 @@ def test_requested_output_resolution(golden):
     assert maxerr(out["rba"], ref_ops.rba_score(want)) < 1e-4
     with pytest.raises(NotImplementedError):
         model([{"image": image}], return_aux=True)
+
+
+def test_c1_random_tensor_256x512_vs_oracle():
+    """BASELINE config C1's input (torch.randn(1,3,256,512), seed 0) through the product vs the CPU oracle (Swin-B 1dl; see
+    tests/test_oracle_golden.py::test_c1_plumbing_cpu_forward_256x512 for why not ResNet-50)."""
+    model, a, sd = build("swin_b_1dl", 0)
+    x = torch.randn(3, 256, 512, generator=torch.Generator().manual_seed(0))
+    out = model([{"image": x}], return_argmax=True)[0]
+    ref = ref_model.forward(x, sd, a)
+    assert maxerr(out["sem_seg"], ref["sem_seg"]) < 1e-4 and maxerr(out["rba"], ref["rba"]) < 1e-4
+    bad, flips = argmax_bad(out["argmax"], ref["sem_seg"])
+    assert bad == 0, (bad, flips)

@@ -160,3 +160,17 @@ def test_end_to_end_full_size(golden, fixture, arch_name):
     flips = o["argmax"][ys, xs].numpy() != g["argmax_s"]
     assert not (flips & ((top2[-1] - top2[-2]) > 1e-4)).any()
     assert abs(o["rba"].double().sum().item() - g["rba_stats"][0]) < 1e-5 * h * w
+
+
+def test_c1_plumbing_cpu_forward_256x512():
+    """BASELINE config C1 ("CPU reference forward + RbA score, 1x256x512 random tensor, 1 decoder layer, 100 queries"): the
+    CPU path end to end.  The ResNet-50 of that config is Detectron2 code that is not in the container, so the
+    plumbing is exercised with the Swin-B 1dl architecture."""
+    a = A.complete(A.ARCHS["swin_b_1dl"])
+    sd = A.seeded_weights(a, 0)
+    x = torch.randn(3, 256, 512, generator=torch.Generator().manual_seed(0))
+    o = ref_model.forward(x, sd, a)
+    assert o["pred_logits"].shape == (100, 20) and o["pred_masks"].shape == (100, 64, 128)
+    assert o["sem_seg"].shape == (19, 256, 512) and o["rba"].shape == (256, 512) and o["argmax"].shape == (256, 512)
+    assert torch.isfinite(o["rba"]).all() and float(o["rba"].max()) <= 0.0 and float(o["rba"].min()) > -19.0
+    assert float(o["sem_seg"].min()) >= 0.0
