@@ -25,6 +25,8 @@
  *                                  (backbone/swin.py:44-71, 131-171, 251-284)
  *   rba_skinny_linear_f32       <- nn.Linear / in_proj / MLP on the decoder's [100, B, 256] query tensors
  *                                  (mask2former_transformer_decoder.py:25-212)
+ *   rba_split_linear_f32        <- nn.Linear on the backbone's token tensors: qkv / proj / Mlp.fc1(+GELU) / Mlp.fc2 /
+ *                                  PatchMerging.reduction (backbone/swin.py:44-71, 131-171, 319-343)
  *   rba_add_layer_norm_f32      <- `x = x + proj(...)` followed by nn.LayerNorm (swin.py:284-293 and the post-norm layers
  *                                  of msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58,106-118,171-175)
  *   rba_group_norm_f32          <- GroupNorm(32) [+ ReLU] behind Detectron2's Conv2d(norm=get_norm("GN"), activation)
@@ -118,6 +120,15 @@ int rba_add_layer_norm_f32(const float* x, const float* t, const float* t_bias, 
  * (mask2former_transformer_decoder.py:25-212). */
 int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias, float* out, int M, int N, int K,
                           int relu, void* stream);
+
+/* fp32-accurate Linear on the bf16 matrix pipe: every fp32 value is the exact sum of three bf16 values, and six
+ * bf16 x bf16 MFMAs (exact products, fp32 accumulation) reproduce the fp32 product to < 2^-24 relative.
+ * rba_split_weight_bf16x3: weight [elems] fp32 -> planes [3][elems] bf16 (6*elems bytes), once per weight load; elems % 4 == 0.
+ * rba_split_linear_f32:    out[m,n] = act(sum_k x[m,k] * weight[n,k] + bias[n]); x [M,K], planes of weight [N,K], bias [N] or
+ *                          NULL; N % 128 == 0, K % 32 == 0; act 0 = none, 1 = exact (erf) GELU. */
+int rba_split_weight_bf16x3(const float* weight, void* planes, int64_t elems, void* stream);
+int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N, int K,
+                         int act, void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,14 +69,14 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn
         t, tb = pending if pending is not None else (None, None)
         x, y = ops.add_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, t, tb, inplace_sum=True)
-        qkv = F.linear(y, a.qkv.weight, a.qkv.bias)
+        qkv = ops.linear(y, a.qkv)
         bias, bias_frag = a.gathered_bias()
         y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size,
                                  bias_frag=bias_frag)
-        t = F.linear(y, a.proj.weight)                                   # proj bias rides in the fused add+LN
+        t = ops.linear(y, a.proj, use_bias=False)                        # proj bias rides in the fused add+LN
         x, y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, t, a.proj.bias, inplace_sum=True)
-        y = F.gelu(F.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
-        return x, (F.linear(y, self.mlp.fc2.weight), self.mlp.fc2.bias)
+        y = ops.linear(y, self.mlp.fc1, gelu=True)                       # exact GELU in the GEMM epilogue
+        return x, (ops.linear(y, self.mlp.fc2, use_bias=False), self.mlp.fc2.bias)
 
 
 class PatchMerging(nn.Module):
@@ -94,7 +94,7 @@ class PatchMerging(nn.Module):
         x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
         x = x.reshape(B, -1, 4 * C)
         _, x = ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
-        return F.linear(x, self.reduction.weight)
+        return ops.linear(x, self.reduction)
 
 
 class BasicLayer(nn.Module):

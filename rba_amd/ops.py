@@ -280,3 +280,65 @@ def skinny_linear(x, weight, bias=None, relu=False):
     _lib.check(lib.rba_skinny_linear_f32(_p(x), _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), _stream()),
                "rba_skinny_linear_f32")
     return out
+
+
+def split_weight(weight):
+    """fp32 weight [N,K] -> three bf16 planes [3,N,K] whose sum is exactly `weight` (done once per weight load)."""
+    lib = _lib.load()
+    _chk(weight, "weight", dim=2)
+    if weight.numel() % 4:
+        raise RbaHipError("split_weight needs numel % 4 == 0")
+    planes = torch.empty((3,) + tuple(weight.shape), dtype=torch.bfloat16, device=weight.device)
+    _lib.check(lib.rba_split_weight_bf16x3(_p(weight), _p(planes), weight.numel(), _stream()), "rba_split_weight_bf16x3")
+    return planes
+
+
+def split_linear_supported(N, K):
+    return N % 128 == 0 and K % 32 == 0 and N >= 128 and K >= 32
+
+
+def split_linear_pays(M, N, K, gelu=False):
+    """Where the bf16x6 kernel beats hipBLASLt's fp32 GEMM on MI355X (tools/gemm_sweep.py, profiles/r01_split_linear.txt):
+    always when the exact GELU is fused into its epilogue; otherwise from K = 256 up when the 128 x 128 tiles fill the chip."""
+    if not split_linear_supported(N, K):
+        return False
+    tiles = ((M + 127) // 128) * (N // 128)
+    return tiles >= 256 if gelu else (K >= 256 and tiles >= 256)
+
+
+def linear(x, lin, use_bias=True, gelu=False):
+    """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU] for an ``nn.Linear`` on a token tensor, through the bf16x6
+    kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise."""
+    w = lin.weight
+    N, K = w.shape
+    M = x.numel() // K if K else 0
+    bias = lin.bias if use_bias else None
+    if x.is_cuda and x.dtype == torch.float32 and split_linear_pays(M, N, K, gelu):
+        key = (w.data_ptr(), w._version, w.device)
+        cache = getattr(lin, "_rba_planes", None)
+        if cache is None or cache[0] != key:
+            cache = (key, split_weight(w.detach().contiguous()))
+            lin._rba_planes = cache
+        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu)
+    y = torch.nn.functional.linear(x, w, bias)
+    return torch.nn.functional.gelu(y) if gelu else y
+
+
+def split_linear(x, planes, bias=None, gelu=False):
+    """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(planes, "planes", dtype=torch.bfloat16, dim=3)
+    K = x.shape[-1]
+    N = planes.shape[1]
+    M = x.numel() // K if K else 0
+    if planes.shape[0] != 3 or planes.shape[2] != K or not split_linear_supported(N, K):
+        raise RbaHipError("split_linear needs planes [3,N,K] with N % 128 == 0 and K % 32 == 0")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+        if bias.numel() != N:
+            raise RbaHipError("bias must have N elements")
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_split_linear_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, int(bool(gelu)), _stream()),
+               "rba_split_linear_f32")
+    return out

@@ -326,3 +326,72 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
     assert out.shape == (M, N) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
     out3 = ops.skinny_linear(dev(x.view(1, M, K)), dev(w), dev(b) if has_bias else None, relu)
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
+
+
+# ----------------------------------------------------------------------------------- bf16x6 (split-bf16) linear
+@pytest.mark.parametrize("M,N,K,gelu,has_bias", [(128, 128, 32, False, True), (1000, 256, 128, False, True), (777, 128, 256, True, True),
+                                                 (4096, 384, 512, False, False), (130, 256, 1024, True, True), (1, 128, 64, False, True),
+                                                 (2048, 512, 2048, False, True), (3600, 1024, 96, True, False)])
+def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias):
+    """Six bf16 MFMAs per product reproduce the fp32 Linear: error against fp64 at the level of an fp32 GEMM's own rounding."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) if has_bias else None
+    ref = F.linear(x.double(), w.double(), b.double() if has_bias else None)
+    ref = F.gelu(ref) if gelu else ref
+    planes = ops.split_weight(dev(w))
+    assert planes.shape == (3, N, K) and planes.dtype == torch.bfloat16
+    assert torch.equal(planes.float().sum(0).cpu(), w), "the three bf16 planes must sum to the fp32 weight exactly"
+    out = ops.split_linear(dev(x), planes, dev(b) if has_bias else None, gelu=gelu)
+    fp32 = F.linear(dev(x), dev(w), dev(b) if has_bias else None)
+    fp32 = F.gelu(fp32) if gelu else fp32
+    tol = 2e-5 * (K / 256) ** 0.5 + 2e-6
+    assert out.shape == (M, N) and maxerr(out, ref) < tol
+    if not gelu:                                                             # (the epilogue's erff is ocml's, torch's differs by ulps)
+        assert maxerr(out, ref) < 2.0 * maxerr(fp32, ref) + 1e-6, "not worse than the fp32 GEMM it replaces"
+    out3 = ops.split_linear(dev(x.view(1, M, K)), planes, dev(b) if has_bias else None, gelu=gelu)
+    assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
+
+
+def test_split_linear_extreme_values(ops):
+    """Exactness of the split over the exponent range, zeros, and values whose low planes vanish."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 64, generator=g) * torch.logspace(-12, 12, 64).view(1, 64)
+    x[:, 7] = 0.0
+    w = torch.zeros(128, 64)
+    w[torch.arange(128), torch.arange(128) % 64] = 1.0                       # a selection matrix: output must equal the input
+    out = ops.split_linear(dev(x), ops.split_weight(dev(w)))
+    assert torch.equal(out.cpu(), x[:, torch.arange(128) % 64])
+    w2 = torch.randn(128, 64, generator=g).bfloat16().float()               # weights exactly representable in bf16
+    p2 = ops.split_weight(dev(w2))
+    assert torch.equal(p2[0].float().cpu(), w2) and not p2[1:].float().any()
+
+
+def test_split_linear_dispatch_and_errors(ops):
+    from rba_amd._lib import RbaHipError
+    lin = torch.nn.Linear(512, 2048).cuda()
+    x = torch.randn(2, 16384, 512, device="cuda")
+    assert ops.split_linear_pays(32768, 2048, 512, gelu=True) and not ops.split_linear_pays(100, 2048, 512, gelu=True)
+    y = ops.linear(x, lin, gelu=True)
+    assert getattr(lin, "_rba_planes", None) is not None, "bf16x6 path not taken"
+    assert maxerr(y, F.gelu(F.linear(x.double(), lin.weight.double(), lin.bias.double()))) < 3e-5
+    planes_before = lin._rba_planes[1]
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                                 # new weights -> planes are re-split
+    y2 = ops.linear(x, lin, use_bias=False)
+    assert lin._rba_planes[1] is not planes_before
+    assert maxerr(y2, F.linear(x.double(), lin.weight.double())) < 3e-5
+    small = torch.nn.Linear(96, 100).cuda()                                   # unsupported shape -> hipBLASLt, same result contract
+    assert maxerr(ops.linear(x[..., :96].contiguous(), small), F.linear(x[..., :96].double(), small.weight.double(), small.bias.double())) < 3e-5
+    planes = ops.split_weight(lin.weight.detach())
+    with pytest.raises(RbaHipError):
+        ops.split_linear(x.cpu(), planes)
+    with pytest.raises(RbaHipError):
+        ops.split_linear(x[..., :256], planes)                                # non-contiguous / wrong K
+    with pytest.raises(RbaHipError):
+        ops.split_linear(x, planes.float())
+    with pytest.raises(RbaHipError):
+        ops.split_weight(torch.randn(101, 3, device="cuda"))                     # numel % 4 != 0
+    with pytest.raises(RbaHipError):
+        ops.split_linear(x[..., :96].contiguous(), ops.split_weight(torch.randn(100, 96, device="cuda")))   # N % 128 != 0
+    assert ops.split_linear(x[:0], planes).shape == (0, 16384, 2048)
