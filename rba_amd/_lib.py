@@ -28,7 +28,7 @@ SIGNATURES = {
     "rba_swin_bias_fragments_elems": [_i, _i],
     "rba_swin_bias_fragments_f32": [_vp, _vp, _i, _i, _vp],
     "rba_skinny_linear_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "rba_split_weight_bf16x3": [_vp, _vp, _i64, _vp],
+    "rba_split_weight_bf16x3": [_vp, _vp, _i, _i, _vp],
     "rba_split_linear_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_add_layer_norm_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_float, _vp],
     "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],

@@ -54,13 +54,25 @@ __device__ __forceinline__ void split4(const float4 x, uint2& p0, uint2& p1, uin
   p2 = make_uint2(pack_bf16(s0, s1), pack_bf16(s2, s3));
 }
 
-__global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restrict__ planes, int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    uint2 p0, p1, p2;
-    split4(reinterpret_cast<const float4*>(w)[i], p0, p1, p2);
-    planes[i] = p0;
-    planes[n4 + i] = p1;
-    planes[2 * n4 + i] = p2;
+// Weight planes in global memory are packed as the LDS image of the pipelined kernels, one 12 KB block per (128-row n tile,
+// 16-wide k stage):  [N/128][K/16][3 planes][128 rows][2 half-slots][8] bf16, the 8-element half h of row r in half-slot
+// h ^ ((r >> 3) & 1).  A workgroup stages one block with three fully coalesced 1 KB-per-wave loads per thread and stores
+// (or DMAs) it to LDS at the same linear offset; a row-major [N][K] layout costs 32 half-used cache lines per wave-load,
+// which made the texture-address unit the bottleneck of the first version (2x slower).
+__global__ void split_weight_kernel(const float* __restrict__ w, u32x4_t* __restrict__ packed, int N, int K) {
+  const int Kc = K >> 3, S = K >> 4;                              // 8-element chunks per row, stages
+  const int64_t total = (int64_t)N * Kc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / Kc), c = (int)(i - (int64_t)n * Kc);
+    const float4* src = reinterpret_cast<const float4*>(w + (int64_t)n * K + c * 8);
+    uint2 p0, p1, p2, q0, q1, q2;
+    split4(src[0], p0, p1, p2);
+    split4(src[1], q0, q1, q2);
+    const int nt = n >> 7, r = n & 127, st = c >> 1, slot = (c & 1) ^ ((r >> 3) & 1);
+    u32x4_t* dst = packed + ((int64_t)nt * S + st) * 768 + r * 2 + slot;
+    dst[0] = (u32x4_t){p0.x, p0.y, q0.x, q0.y};
+    dst[256] = (u32x4_t){p1.x, p1.y, q1.x, q1.y};
+    dst[512] = (u32x4_t){p2.x, p2.y, q2.x, q2.y};
   }
 }
 
@@ -90,18 +102,22 @@ __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __
     r = r < M ? r : M - 1;
     a_src[i] = A + (int64_t)r * K + a_c4 * 4;
   }
-  const int w_ch = tid & 3, w_r = tid >> 2;                       // W: plane p, rows w_r + 64 i (i < 2), 16 B chunk w_ch
-  const int Kq = K >> 3;                                          // uint4 per row
-  const u32x4_t* w_src[6];                                        // j = 2 p + i
+  // W: the 32-wide stage is two consecutive packed 12 KB blocks = 1536 x 16 B, six per thread, linear index tid + 256 j
+  const u32x4_t* w_src = Wp + (int64_t)nt * (K >> 4) * 768 + tid;
+  int w_dst[6];                                                   // element index into Ws viewed as [3][BN][ROWQ]
 #pragma unroll
-  for (int j = 0; j < 6; ++j) w_src[j] = Wp + ((int64_t)(j >> 1) * N + n0 + w_r + 64 * (j & 1)) * Kq + w_ch;
+  for (int j = 0; j < 6; ++j) {
+    const int lin = tid + 256 * j, blk = lin / 768, within = lin - blk * 768;
+    const int p = within >> 8, r = (within & 255) >> 1, slot = within & 1;
+    w_dst[j] = (p * BN + r) * ROWQ + 2 * blk + (slot ^ ((r >> 3) & 1));
+  }
 
   f32x4 pa[4];
   u32x4_t pw[6];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pa[i] = *reinterpret_cast<const f32x4*>(a_src[i]);
 #pragma unroll
-  for (int j = 0; j < 6; ++j) pw[j] = w_src[j][0];
+  for (int j = 0; j < 6; ++j) pw[j] = w_src[256 * j];
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -124,14 +140,14 @@ __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __
       reinterpret_cast<uint2*>(&As[2][row][0])[a_c4] = p2;
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) Ws[j >> 1][w_r + 64 * (j & 1)][w_ch] = pw[j];
+    for (int j = 0; j < 6; ++j) (&Ws[0][0][0])[w_dst[j]] = pw[j];
     __syncthreads();
     if (k0 + BK < K) {                             // prefetch the next stage into registers
       const int kn = k0 + BK;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pa[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kn);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) pw[j] = w_src[j][kn >> 3];
+      for (int j = 0; j < 6; ++j) pw[j] = w_src[(kn >> 4) * 768 + 256 * j];
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -180,9 +196,58 @@ __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __
 constexpr int BK2 = 16;                       // k extent of one pipelined stage
 
 struct StageRegs {
-  f32x4 a0, a1;                               // A[row][8 half .. 8 half + 7]
-  u32x4_t w0, w1, w2;                         // W planes 0..2: [row][8 half .. +7] bf16
+  f32x4 a0, a1;                               // A[row + 64 i][4 c .. 4 c + 3], i = 0, 1
+  u32x4_t w0, w1, w2;                         // packed W block, plane p, linear 16-B index t
 };
+
+// Staging maps of the 256 staging threads (t = 0..255) for one 16-wide stage:
+//   A: row = (t >> 2) + 64 i, 4-float chunk c = t & 3: a 4-lane quad reads 64 contiguous bytes of one row;
+//      its three 8-byte plane pieces go to row*32 + (((c >> 1) ^ ((row >> 3) & 1)) * 16 + (c & 1) * 8 of the plane image
+//   W: 16-byte piece t of each plane block, stored to the same linear offset.
+struct StageMap {
+  const float* a_src;                         // + s * 16 floats; second row at + 64 K
+  const u32x4_t* w_src;                       // + s * 768
+  int64_t a_row2;                             // element offset of the second row (0 when clamped onto the same row)
+  int a_dst0, a_dst1;                         // uint2 index into a plane image [128][4]
+};
+__device__ __forceinline__ StageMap make_stage_map(const float* A, const u32x4_t* Wp, int t, int m0, int nt, int M, int K) {
+  StageMap m;
+  const int c = t & 3, r0 = t >> 2, r1 = r0 + 64;
+  int g0 = m0 + r0, g1 = m0 + r1;
+  g0 = g0 < M ? g0 : M - 1;
+  g1 = g1 < M ? g1 : M - 1;
+  m.a_src = A + (int64_t)g0 * K + c * 4;
+  m.a_row2 = (int64_t)(g1 - g0) * K;
+  m.w_src = Wp + (int64_t)nt * (K >> 4) * 768 + t;
+  m.a_dst0 = r0 * 4 + (((c >> 1) ^ ((r0 >> 3) & 1)) << 1) + (c & 1);
+  m.a_dst1 = r1 * 4 + (((c >> 1) ^ ((r1 >> 3) & 1)) << 1) + (c & 1);
+  return m;
+}
+__device__ __forceinline__ void stage_load(StageRegs& r, const StageMap& m, int s) {
+  const float* ap = m.a_src + s * 16;
+  r.a0 = *reinterpret_cast<const f32x4*>(ap);
+  r.a1 = *reinterpret_cast<const f32x4*>(ap + m.a_row2);
+  const u32x4_t* wp = m.w_src + (int64_t)s * 768;
+  r.w0 = wp[0];
+  r.w1 = wp[256];
+  r.w2 = wp[512];
+}
+// As3 / Ws3: the three plane images of one stage buffer, [3][128][2] x 16 B each
+__device__ __forceinline__ void stage_store(const StageRegs& r, const StageMap& m, u32x4_t* As3, u32x4_t* Ws3, int t) {
+  uint2 p0, p1, p2, q0, q1, q2;
+  split4(make_float4(r.a0.x, r.a0.y, r.a0.z, r.a0.w), p0, p1, p2);
+  split4(make_float4(r.a1.x, r.a1.y, r.a1.z, r.a1.w), q0, q1, q2);
+  uint2* a2 = reinterpret_cast<uint2*>(As3);
+  a2[m.a_dst0] = p0;
+  a2[512 + m.a_dst0] = p1;
+  a2[1024 + m.a_dst0] = p2;
+  a2[m.a_dst1] = q0;
+  a2[512 + m.a_dst1] = q1;
+  a2[1024 + m.a_dst1] = q2;
+  Ws3[t] = r.w0;
+  Ws3[256 + t] = r.w1;
+  Ws3[512 + t] = r.w2;
+}
 
 // ---- v3: three unpadded, swizzled LDS stage buffers (24 KB each) and ONE barrier per 16-wide k stage, placed mid-stage.
 // Stage s computes from buffer s % 3; at its head the tile of stage s + 2 (global loads issued two stages earlier) is split
@@ -206,37 +271,10 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
   const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const int s_row = tid >> 1, s_half = tid & 1;
-  const int s_slot = s_half ^ ((s_row >> 3) & 1);
-  int ar = m0 + s_row;
-  ar = ar < M ? ar : M - 1;
-  const float* a_src = A + (int64_t)ar * K + s_half * 8;
-  const int Kq = K >> 3;
-  const u32x4_t* w_src = Wp + ((int64_t)(n0 + s_row)) * Kq + s_half;
-  const int64_t w_plane = (int64_t)N * Kq;
+  const StageMap smap = make_stage_map(A, Wp, tid, m0, nt, M, K);
   const int S = K / BK2, SL = S - 1;
-
-  auto gload = [&](StageRegs& r, int s) {
-    s = s < SL ? s : SL;
-    const float* ap = a_src + s * BK2;
-    r.a0 = *reinterpret_cast<const f32x4*>(ap);
-    r.a1 = *reinterpret_cast<const f32x4*>(ap + 4);
-    const u32x4_t* wp = w_src + s * 2;
-    r.w0 = wp[0];
-    r.w1 = wp[w_plane];
-    r.w2 = wp[2 * w_plane];
-  };
-  auto stash = [&](const StageRegs& r, int buf) {
-    uint2 p0, p1, p2, q0, q1, q2;
-    split4(make_float4(r.a0.x, r.a0.y, r.a0.z, r.a0.w), p0, p1, p2);
-    split4(make_float4(r.a1.x, r.a1.y, r.a1.z, r.a1.w), q0, q1, q2);
-    As[buf][0][s_row][s_slot] = (u32x4_t){p0.x, p0.y, q0.x, q0.y};
-    As[buf][1][s_row][s_slot] = (u32x4_t){p1.x, p1.y, q1.x, q1.y};
-    As[buf][2][s_row][s_slot] = (u32x4_t){p2.x, p2.y, q2.x, q2.y};
-    Ws[buf][0][s_row][s_slot] = r.w0;
-    Ws[buf][1][s_row][s_slot] = r.w1;
-    Ws[buf][2][s_row][s_slot] = r.w2;
-  };
+  auto gload = [&](StageRegs& r, int s) { stage_load(r, smap, s < SL ? s : SL); };
+  auto stash = [&](const StageRegs& r, int buf) { stage_store(r, smap, &As[buf][0][0][0], &Ws[buf][0][0][0], tid); };
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -309,17 +347,124 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
   }
 }
 
+
+// ---- wave-specialised variant: 8 waves per workgroup.  Waves 0-3 (one per SIMD) only read operand fragments and issue
+// MFMAs; waves 4-7 (their SIMD partners) only stage: global loads two stages ahead, the bf16 split, LDS stores.  A wave issues
+// in order, so in the 4-wave kernels every staging instruction sits between two MFMAs of the same wave (counters: LDS stores
+// 22 %, split VALU 18 % of wave time, the matrix pipe 39 % busy); here the staging stream runs beside an almost pure MFMA
+// stream.  Same three swizzled LDS stage buffers and one barrier per stage as the pipe kernel.
+template <int ACT>
+__global__ __launch_bounds__(512) void split_linear_ws_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                              int K, int MT, int NT) {
+  __shared__ u32x4_t As[STG][3][BM][2];
+  __shared__ u32x4_t Ws[STG][3][BN][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int nb = MT * NT;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int mt = bid / NT, nt = bid - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int S = K / BK2, SL = S - 1;
+
+  if (wave >= 4) {                                                // ---------------- staging waves
+    const int t = tid - 256;
+    const StageMap smap = make_stage_map(A, Wp, t, m0, nt, M, K);
+    auto gload = [&](StageRegs& r, int s) { stage_load(r, smap, s < SL ? s : SL); };
+    auto stash = [&](const StageRegs& r, int buf) { stage_store(r, smap, &As[buf][0][0][0], &Ws[buf][0][0][0], t); };
+    StageRegs rx, ry;
+    gload(rx, 0);
+    gload(ry, 1);
+    stash(rx, 0);
+    gload(rx, 2);
+    stash(ry, 1);
+    gload(ry, 3);
+    __syncthreads();
+    int wr = 2, s = 0;                                            // during stage s the tile of stage s + 2 goes to buffer (s + 2) % 3
+    for (; s + 2 <= S; s += 2) {
+      stash(rx, wr);
+      gload(rx, s + 4);
+      __syncthreads();
+      wr = wr == 2 ? 0 : wr + 1;
+      stash(ry, wr);
+      gload(ry, s + 5);
+      __syncthreads();
+      wr = wr == 2 ? 0 : wr + 1;
+    }
+    if (s < S) {
+      stash(rx, wr);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int fa_row = 64 * wm + l31, fb_row = 64 * wn + l31;
+  const int fa_slot = lh ^ ((fa_row >> 3) & 1), fb_slot = lh ^ ((fb_row >> 3) & 1);
+  bf16x8_t a[2][3], b[2][3], na[2], nb0[2];
+  auto rd_a = [&](int buf, int t, int p) { return __builtin_bit_cast(bf16x8_t, As[buf][p][fa_row + 32 * t][fa_slot]); };
+  auto rd_b = [&](int buf, int t, int p) { return __builtin_bit_cast(bf16x8_t, Ws[buf][p][fb_row + 32 * t][fb_slot]); };
+#define RBA_G(pa, pb)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)           \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { a[t][0] = rd_a(0, t, 0); b[t][0] = rd_b(0, t, 0); }
+  int cur = 0;
+  for (int s = 0; s < S; ++s) {
+    const int nxt = cur == 2 ? 0 : cur + 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t][1] = rd_a(cur, t, 1); b[t][1] = rd_b(cur, t, 1);
+      a[t][2] = rd_a(cur, t, 2); b[t][2] = rd_b(cur, t, 2);
+    }
+    RBA_G(0, 0) RBA_G(0, 1) RBA_G(1, 0)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { na[t] = rd_a(nxt, t, 0); nb0[t] = rd_b(nxt, t, 0); }   // stage s + 1: written during stage s - 1
+    RBA_G(1, 1) RBA_G(0, 2) RBA_G(2, 0)
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { a[t][0] = na[t]; b[t][0] = nb0[t]; }
+    cur = nxt;
+  }
+#undef RBA_G
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + 64 * wn + 32 * j + l31;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
+        float v = acc[i][j][r] + bv;
+        if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (row < M) C[(int64_t)row * N + col] = v;
+      }
+  }
+}
+
 }  // namespace
 
-extern "C" int rba_split_weight_bf16x3(const float* weight, void* planes, int64_t elems, void* stream) {
-  RBA_CHECK_ARG(elems >= 0 && (elems & 3) == 0);
-  if (elems == 0) return 0;
-  RBA_CHECK_ARG(weight && planes && (((uintptr_t)weight | (uintptr_t)planes) & 15) == 0);
+extern "C" int rba_split_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream) {
+  RBA_CHECK_ARG(N >= 0 && K >= 0 && (N % BN) == 0 && (K % BK) == 0);
+  if (N == 0 || K == 0) return 0;
+  RBA_CHECK_ARG(weight && packed && (((uintptr_t)weight | (uintptr_t)packed) & 15) == 0);
   rba_begin();
-  const int64_t n4 = elems >> 2;
-  const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  const int64_t total = (int64_t)N * (K >> 3);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, weight,
-                     reinterpret_cast<uint2*>(planes), n4);
+                     reinterpret_cast<u32x4_t*>(packed), N, K);
   return rba_launch_status();
 }
 
@@ -338,7 +483,11 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
   static const int forced = getenv("RBA_GEMM_VARIANT") ? atoi(getenv("RBA_GEMM_VARIANT")) : 0;   // tuning hook (tools/gemm_sweep.py)
   const bool short_k = forced ? forced == 1 : K <= 256;
 #define RBA_L(KERNEL, A) hipLaunchKernelGGL(KERNEL<A>, grid, block, 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
-  if (short_k) {
+  if (forced == 4) {
+#define RBA_L8(A) hipLaunchKernelGGL((split_linear_ws_kernel<A>), grid, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
+    if (act == 1) RBA_L8(1); else RBA_L8(0);
+#undef RBA_L8
+  } else if (short_k) {
     if (act == 1) RBA_L(split_linear_short_kernel, 1); else RBA_L(split_linear_short_kernel, 0);
   } else {
     if (act == 1) RBA_L(split_linear_pipe_kernel, 1); else RBA_L(split_linear_pipe_kernel, 0);

@@ -283,14 +283,25 @@ def skinny_linear(x, weight, bias=None, relu=False):
 
 
 def split_weight(weight):
-    """fp32 weight [N,K] -> three bf16 planes [3,N,K] whose sum is exactly `weight` (done once per weight load)."""
+    """fp32 weight [N,K] -> the three bf16 planes (hi, mid, lo; their sum is exactly `weight`) packed as the kernel's LDS
+    tiles: [N/128, K/16, 3, 128, 2, 8] bf16, the 8-element half h of row r in slot h ^ ((r >> 3) & 1).  Once per weight load."""
     lib = _lib.load()
     _chk(weight, "weight", dim=2)
-    if weight.numel() % 4:
-        raise RbaHipError("split_weight needs numel % 4 == 0")
-    planes = torch.empty((3,) + tuple(weight.shape), dtype=torch.bfloat16, device=weight.device)
-    _lib.check(lib.rba_split_weight_bf16x3(_p(weight), _p(planes), weight.numel(), _stream()), "rba_split_weight_bf16x3")
-    return planes
+    N, K = weight.shape
+    if not split_linear_supported(N, K):
+        raise RbaHipError("split_weight needs weight [N,K] with N % 128 == 0 and K % 32 == 0")
+    packed = torch.empty((N // 128, K // 16, 3, 128, 2, 8), dtype=torch.bfloat16, device=weight.device)
+    _lib.check(lib.rba_split_weight_bf16x3(_p(weight), _p(packed), N, K, _stream()), "rba_split_weight_bf16x3")
+    return packed
+
+
+def unpack_split_weight(packed):
+    """Inverse of split_weight's tiling: -> planes [3, N, K] bf16 (for inspection and tests)."""
+    nt, S = packed.shape[:2]
+    r = torch.arange(128, device=packed.device)
+    flip = ((r >> 3) & 1).bool()
+    un = torch.where(flip.view(1, 1, 1, 128, 1, 1), packed.flip(4), packed)          # slot -> half
+    return un.permute(2, 0, 3, 1, 4, 5).reshape(3, nt * 128, S * 16)
 
 
 def split_linear_supported(N, K):
@@ -328,12 +339,12 @@ def split_linear(x, planes, bias=None, gelu=False):
     """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe."""
     lib = _lib.load()
     _chk(x, "x")
-    _chk(planes, "planes", dtype=torch.bfloat16, dim=3)
+    _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
     K = x.shape[-1]
-    N = planes.shape[1]
+    N = planes.shape[0] * 128
     M = x.numel() // K if K else 0
-    if planes.shape[0] != 3 or planes.shape[2] != K or not split_linear_supported(N, K):
-        raise RbaHipError("split_linear needs planes [3,N,K] with N % 128 == 0 and K % 32 == 0")
+    if tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != K or not split_linear_supported(N, K):
+        raise RbaHipError("split_linear needs x [..., K] and split_weight(W) of a weight [N,K] with N % 128 == 0, K % 32 == 0")
     if bias is not None:
         _chk(bias, "bias", dim=1)
         if bias.numel() != N:

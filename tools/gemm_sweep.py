@@ -50,7 +50,7 @@ def main():
             print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  unsupported")
             continue
         planes = ops.split_weight(w)
-        assert torch.equal(planes.float().sum(0), w), "planes do not sum to the weight"
+        assert torch.equal(ops.unpack_split_weight(planes).float().sum(0), w), "planes do not sum to the weight"
         y = ops.split_linear(x, planes, b)
         y0 = F.linear(x, w, b)
         rows = torch.randperm(M, device=dev)[:512]
