@@ -123,9 +123,9 @@ int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias
 
 /* fp32-accurate Linear on the bf16 matrix pipe: every fp32 value is the exact sum of three bf16 values, and six
  * bf16 x bf16 MFMAs (exact products, fp32 accumulation) reproduce the fp32 product to < 2^-24 relative.
- * rba_split_weight_bf16x3: weight [N,K] fp32 -> `packed`, 6*N*K bytes: the three bf16 planes tiled as the kernel's LDS
- *                          image, [N/128][K/16][3][128][2][8] bf16 with the 8-element half h of row r in slot h ^ ((r >> 3) & 1).
- *                          Once per weight load.  N % 128 == 0, K % 32 == 0.
+ * rba_split_weight_bf16x3: weight [N,K] fp32 -> `packed`, 6*Np*K bytes (Np = N rounded up to 128, padding rows zero): the
+ *                          three bf16 planes tiled as the kernel's LDS image, [Np/128][K/16][3][128][2][8] bf16 with the
+ *                          8-element half h of row r in slot h ^ ((r >> 3) & 1).  Once per weight load.  K % 32 == 0.
  * rba_split_linear_f32:    out[m,n] = act(sum_k x[m,k] * weight[n,k] + bias[n]); x [M,K] fp32, `weight_packed` from
  *                          rba_split_weight_bf16x3 for the same (N, K), bias [N] or NULL; act 0 = none, 1 = exact (erf) GELU. */
 int rba_split_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream);

@@ -76,13 +76,16 @@ __device__ __forceinline__ void split4(const float4 x, uint2& p0, uint2& p1, uin
 // which made the texture-address unit the bottleneck of the first version (2x slower).
 __global__ void split_weight_kernel(const float* __restrict__ w, u32x4_t* __restrict__ packed, int N, int K) {
   const int Kc = K >> 3, S = K >> 4;                              // 8-element chunks per row, stages
-  const int64_t total = (int64_t)N * Kc;
+  const int Np = (N + BN - 1) / BN * BN;                          // rows N..Np-1 of the last tile are zero
+  const int64_t total = (int64_t)Np * Kc;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / Kc), c = (int)(i - (int64_t)n * Kc);
-    const float4* src = reinterpret_cast<const float4*>(w + (int64_t)n * K + c * 8);
-    uint2 p0, p1, p2, q0, q1, q2;
-    split4(src[0], p0, p1, p2);
-    split4(src[1], q0, q1, q2);
+    uint2 p0 = make_uint2(0u, 0u), p1 = p0, p2 = p0, q0 = p0, q1 = p0, q2 = p0;
+    if (n < N) {
+      const float4* src = reinterpret_cast<const float4*>(w + (int64_t)n * K + c * 8);
+      split4(src[0], p0, p1, p2);
+      split4(src[1], q0, q1, q2);
+    }
     const int nt = n >> 7, r = n & 127, st = c >> 1, slot = (c & 1) ^ ((r >> 3) & 1);
     u32x4_t* dst = packed + ((int64_t)nt * S + st) * 768 + r * 2 + slot;
     dst[0] = (u32x4_t){p0.x, p0.y, q0.x, q0.y};
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 64 * wn + 32 * j + l31;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __
         const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
         float v = acc[i][j][r] + bv;
         if (ACT == 1) v = gelu_erf(v);
-        if (row < M) C[(int64_t)row * N + col] = v;
+        if (row < M && col < N) C[(int64_t)row * N + col] = v;
       }
   }
 }
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 64 * wn + 32 * j + l31;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
         const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
         float v = acc[i][j][r] + bv;
         if (ACT == 1) v = gelu_erf(v);
-        if (row < M) C[(int64_t)row * N + col] = v;
+        if (row < M && col < N) C[(int64_t)row * N + col] = v;
       }
   }
 }
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(512) void split_linear_ws_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + 64 * wn + 32 * j + l31;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(512) void split_linear_ws_kernel(const float* __res
         const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
         float v = acc[i][j][r] + bv;
         if (ACT == 1) v = gelu_erf(v);
-        if (row < M) C[(int64_t)row * N + col] = v;
+        if (row < M && col < N) C[(int64_t)row * N + col] = v;
       }
   }
 }
@@ -478,11 +481,11 @@ __global__ __launch_bounds__(512) void split_linear_ws_kernel(const float* __res
 }  // namespace
 
 extern "C" int rba_split_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream) {
-  RBA_CHECK_ARG(N >= 0 && K >= 0 && (N % BN) == 0 && (K % BK) == 0);
+  RBA_CHECK_ARG(N >= 0 && K >= 0 && (K % BK) == 0);
   if (N == 0 || K == 0) return 0;
   RBA_CHECK_ARG(weight && packed && (((uintptr_t)weight | (uintptr_t)packed) & 15) == 0);
   rba_begin();
-  const int64_t total = (int64_t)N * (K >> 3);
+  const int64_t total = (int64_t)((N + BN - 1) / BN * BN) * (K >> 3);
   const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(split_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, weight,
                      reinterpret_cast<u32x4_t*>(packed), N, K);
@@ -491,12 +494,12 @@ extern "C" int rba_split_weight_bf16x3(const float* weight, void* packed, int N,
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {
-  RBA_CHECK_ARG(M >= 0 && N >= BN && (N % BN) == 0 && K >= BK && (K % BK) == 0 && (act == 0 || act == 1));
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= BK && (K % BK) == 0 && (act == 0 || act == 1));
   if (M == 0) return 0;
   RBA_CHECK_ARG(x && weight_planes && out);
   RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_planes | (uintptr_t)out) & 15) == 0);
   const int64_t MT = (M + BM - 1) / BM;
-  const int NT = N / BN;
+  const int NT = (N + BN - 1) / BN;
   RBA_CHECK_ARG(MT * NT < (int64_t)1 << 31 && M < (int64_t)1 << 31);
   rba_begin();
   const dim3 grid((unsigned)(MT * NT)), block(256);

@@ -289,14 +289,14 @@ def split_weight(weight):
     _chk(weight, "weight", dim=2)
     N, K = weight.shape
     if not split_linear_supported(N, K):
-        raise RbaHipError("split_weight needs weight [N,K] with N % 128 == 0 and K % 32 == 0")
-    packed = torch.empty((N // 128, K // 16, 3, 128, 2, 8), dtype=torch.bfloat16, device=weight.device)
+        raise RbaHipError("split_weight needs weight [N,K] with K % 32 == 0")
+    packed = torch.empty(((N + 127) // 128, K // 16, 3, 128, 2, 8), dtype=torch.bfloat16, device=weight.device)
     _lib.check(lib.rba_split_weight_bf16x3(_p(weight), _p(packed), N, K, _stream()), "rba_split_weight_bf16x3")
     return packed
 
 
 def unpack_split_weight(packed):
-    """Inverse of split_weight's tiling: -> planes [3, N, K] bf16 (for inspection and tests)."""
+    """Inverse of split_weight's tiling: -> planes [3, Np, K] bf16, Np = N rounded up to 128 (for inspection and tests)."""
     nt, S = packed.shape[:2]
     r = torch.arange(128, device=packed.device)
     flip = ((r >> 3) & 1).bool()
@@ -305,7 +305,7 @@ def unpack_split_weight(packed):
 
 
 def split_linear_supported(N, K):
-    return N % 128 == 0 and K % 32 == 0 and N >= 128 and K >= 32
+    return K % 32 == 0 and N >= 1 and K >= 32
 
 
 def split_linear_pays(M, N, K, gelu=False):
@@ -313,7 +313,7 @@ def split_linear_pays(M, N, K, gelu=False):
     always when the exact GELU is fused into its epilogue; otherwise from K = 256 up when the 128 x 128 tiles fill the chip."""
     if not split_linear_supported(N, K):
         return False
-    tiles = ((M + 127) // 128) * (N // 128)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     return tiles >= 256 if gelu else (K >= 256 and tiles >= 256)
 
 
@@ -330,21 +330,23 @@ def linear(x, lin, use_bias=True, gelu=False):
         if cache is None or cache[0] != key:
             cache = (key, split_weight(w.detach().contiguous()))
             lin._rba_planes = cache
-        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu)
+        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu, out_features=N)
     y = torch.nn.functional.linear(x, w, bias)
     return torch.nn.functional.gelu(y) if gelu else y
 
 
-def split_linear(x, planes, bias=None, gelu=False):
-    """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe."""
+def split_linear(x, planes, bias=None, gelu=False, out_features=None):
+    """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe.
+    ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
     lib = _lib.load()
     _chk(x, "x")
     _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
     K = x.shape[-1]
-    N = planes.shape[0] * 128
+    N = planes.shape[0] * 128 if out_features is None else int(out_features)
     M = x.numel() // K if K else 0
-    if tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != K or not split_linear_supported(N, K):
-        raise RbaHipError("split_linear needs x [..., K] and split_weight(W) of a weight [N,K] with N % 128 == 0, K % 32 == 0")
+    if (tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != K or not split_linear_supported(N, K)
+            or (N + 127) // 128 != planes.shape[0]):
+        raise RbaHipError("split_linear needs x [..., K] and split_weight(W) of a weight [N,K] with K % 32 == 0")
     if bias is not None:
         _chk(bias, "bias", dim=1)
         if bias.numel() != N:

@@ -331,7 +331,9 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
 # ----------------------------------------------------------------------------------- bf16x6 (split-bf16) linear
 @pytest.mark.parametrize("M,N,K,gelu,has_bias", [(128, 128, 32, False, True), (1000, 256, 128, False, True), (777, 128, 256, True, True),
                                                  (4096, 384, 512, False, False), (130, 256, 1024, True, True), (1, 128, 64, False, True),
-                                                 (2048, 512, 2048, False, True), (3600, 1024, 96, True, False)])
+                                                 (2048, 512, 2048, False, True), (3600, 1024, 96, True, False),
+                                                 (500, 192, 192, False, True), (900, 576, 192, True, True), (300, 100, 64, False, False),
+                                                 (257, 1, 32, False, True)])
 def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias):
     """Six bf16 MFMAs per product reproduce the fp32 Linear: error against fp64 at the level of an fp32 GEMM's own rounding."""
     g = torch.Generator().manual_seed(M + N + K)
@@ -340,18 +342,20 @@ def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias):
     ref = F.linear(x.double(), w.double(), b.double() if has_bias else None)
     ref = F.gelu(ref) if gelu else ref
     planes = ops.split_weight(dev(w))
-    assert planes.shape == (N // 128, K // 16, 3, 128, 2, 8) and planes.dtype == torch.bfloat16
+    Np = (N + 127) // 128 * 128
+    assert planes.shape == (Np // 128, K // 16, 3, 128, 2, 8) and planes.dtype == torch.bfloat16
     flat = ops.unpack_split_weight(planes)
-    assert flat.shape == (3, N, K)
-    assert torch.equal(flat.float().sum(0).cpu(), w), "the three bf16 planes must sum to the fp32 weight exactly"
-    out = ops.split_linear(dev(x), planes, dev(b) if has_bias else None, gelu=gelu)
+    assert flat.shape == (3, Np, K)
+    assert torch.equal(flat[:, :N].float().sum(0).cpu(), w), "the three bf16 planes must sum to the fp32 weight exactly"
+    assert not flat[:, N:].float().any(), "padding rows must be zero"
+    out = ops.split_linear(dev(x), planes, dev(b) if has_bias else None, gelu=gelu, out_features=N)
     fp32 = F.linear(dev(x), dev(w), dev(b) if has_bias else None)
     fp32 = F.gelu(fp32) if gelu else fp32
     tol = 2e-5 * (K / 256) ** 0.5 + 2e-6
     assert out.shape == (M, N) and maxerr(out, ref) < tol
     if not gelu:                                                             # (the epilogue's erff is ocml's, torch's differs by ulps)
         assert maxerr(out, ref) < 2.0 * maxerr(fp32, ref) + 1e-6, "not worse than the fp32 GEMM it replaces"
-    out3 = ops.split_linear(dev(x.view(1, M, K)), planes, dev(b) if has_bias else None, gelu=gelu)
+    out3 = ops.split_linear(dev(x.view(1, M, K)), planes, dev(b) if has_bias else None, gelu=gelu, out_features=N)
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
 
 
@@ -393,5 +397,7 @@ def test_split_linear_dispatch_and_errors(ops):
     with pytest.raises(RbaHipError):
         ops.split_linear(x, planes.float())
     with pytest.raises(RbaHipError):
-        ops.split_weight(torch.randn(100, 64, device="cuda"))                    # N % 128 != 0
+        ops.split_weight(torch.randn(128, 48, device="cuda"))                    # K % 32 != 0
+    with pytest.raises(RbaHipError):
+        ops.split_linear(x, planes, out_features=1000)                           # does not match the packed tiles
     assert ops.split_linear(x[:0], planes).shape == (0, 16384, 2048)

@@ -50,15 +50,15 @@ def main():
             print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}  unsupported")
             continue
         planes = ops.split_weight(w)
-        assert torch.equal(ops.unpack_split_weight(planes).float().sum(0), w), "planes do not sum to the weight"
-        y = ops.split_linear(x, planes, b)
+        assert torch.equal(ops.unpack_split_weight(planes)[:, :N].float().sum(0), w), "planes do not sum to the weight"
+        y = ops.split_linear(x, planes, b, out_features=N)
         y0 = F.linear(x, w, b)
         rows = torch.randperm(M, device=dev)[:512]
         ref = (x[rows].double() @ w.double().T + b.double())
         e_new = (y[rows].double() - ref).abs().max().item()
         e_old = (y0[rows].double() - ref).abs().max().item()
         t_old = timeit(lambda: F.linear(x, w, b))
-        t_new = timeit(lambda: ops.split_linear(x, planes, b))
+        t_new = timeit(lambda: ops.split_linear(x, planes, b, out_features=N))
         fl = 2.0 * M * N * K
         tot_a += t_old
         tot_b += t_new
