@@ -74,6 +74,41 @@ __device__ __forceinline__ void split4(const float4 x, uint2& p0, uint2& p1, uin
 // h ^ ((r >> 3) & 1).  A workgroup stages one block with three fully coalesced 1 KB-per-wave loads per thread and stores
 // (or DMAs) it to LDS at the same linear offset; a row-major [N][K] layout costs 32 half-used cache lines per wave-load,
 // which made the texture-address unit the bottleneck of the first version (2x slower).
+// Epilogue of one wave's 64 x 64 tile: lane holds D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] of each 32 x 32
+// MFMA tile.  The 16 values of a tile are formed in 16 distinct registers and stored back to back (a wave-store covers two
+// 128-byte row segments); interior tiles take a branch-free path.  (A store per `if (row < M)` block made the compiler put
+// s_waitcnt vmcnt(0) between consecutive stores -- the value register was reused -- serialising 64 memory round trips.)
+template <int ACT>
+__device__ __forceinline__ void store_tile(const f32x16_t (&acc)[2][2], const float* __restrict__ bias, float* __restrict__ C,
+                                           int M, int N, int row0, int col0, bool interior, int l31, int lh) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + 32 * j + l31;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16_t v = acc[i][j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v[r] += bv;
+        if (ACT == 1) v[r] = gelu_erf(v[r]);
+      }
+      const int rbase = row0 + 32 * i + 4 * lh;
+      float* dst = C + (int64_t)rbase * N + col;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
+      } else if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = 8 * (r >> 2) + (r & 3);
+          if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
+        }
+      }
+    }
+  }
+}
+
 __global__ void split_weight_kernel(const float* __restrict__ w, u32x4_t* __restrict__ packed, int N, int K) {
   const int Kc = K >> 3, S = K >> 4;                              // 8-element chunks per row, stages
   const int Np = (N + BN - 1) / BN * BN;                          // rows N..Np-1 of the last tile are zero
@@ -194,20 +229,7 @@ __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __
   }
 
   // ---- epilogue: lane holds D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] of each 32 x 32 tile
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + 64 * wn + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
-        float v = acc[i][j][r] + bv;
-        if (ACT == 1) v = gelu_erf(v);
-        if (row < M && col < N) C[(int64_t)row * N + col] = v;
-      }
-  }
+  store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
 }
 
 
@@ -349,20 +371,7 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
 #undef RBA_STAGE
 #undef RBA_G
 
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + 64 * wn + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
-        float v = acc[i][j][r] + bv;
-        if (ACT == 1) v = gelu_erf(v);
-        if (row < M && col < N) C[(int64_t)row * N + col] = v;
-      }
-  }
+  store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
 }
 
 
@@ -462,20 +471,7 @@ __global__ __launch_bounds__(512) void split_linear_ws_kernel(const float* __res
   }
 #undef RBA_G
 
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + 64 * wn + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
-        float v = acc[i][j][r] + bv;
-        if (ACT == 1) v = gelu_erf(v);
-        if (row < M && col < N) C[(int64_t)row * N + col] = v;
-      }
-  }
+  store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
 }
 
 }  // namespace

@@ -310,11 +310,12 @@ def split_linear_supported(N, K):
 
 def split_linear_pays(M, N, K, gelu=False):
     """Where the bf16x6 kernel beats hipBLASLt's fp32 GEMM on MI355X (tools/gemm_sweep.py, profiles/r01_split_linear.txt):
-    always when the exact GELU is fused into its epilogue; otherwise from K = 256 up when the 128 x 128 tiles fill the chip."""
-    if not split_linear_supported(N, K):
+    1.25-1.5x whenever its 128 x 128 tiles fill the chip (>= 256 tiles) and K >= 128; always when that holds and the exact
+    GELU is fused into its epilogue.  Below that (Swin stage 4 at one image: 128 tiles) hipBLASLt's smaller tiles win."""
+    if not split_linear_supported(N, K) or K < 128:
         return False
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    return tiles >= 256 if gelu else (K >= 256 and tiles >= 256)
+    return tiles >= 256
 
 
 def linear(x, lin, use_bias=True, gelu=False):
