@@ -268,6 +268,79 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_fast_kernel(const float* 
   }
 }
 
+// Explicitly packed formulation of the fast kernel (4 pixels per thread): accumulators and sigmoid values live in
+// float2 register pairs from the start, so every FMA is a v_pk_fma_f32 whose operands need no pairing moves
+// (the scalar formulation is SLP-vectorised by the compiler, which inserts 21 v_mov per two planes to build the pairs).
+// Same operations in the same order per element as rba_reduce_fast_kernel: bit-identical results.
+template <int K, bool SEM, bool ARG, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_pk_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                               float* __restrict__ rba, float* __restrict__ sem,
+                                                               int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode) {
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;
+    if (p0 >= HW) continue;
+    f32x2 a01[K], a23[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
+    const float* mp = mask + p0;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+    const int Qmain = Q / U * U;
+    for (int q0 = 0; q0 < Qmain; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        const f32x2 s01 = {rba_sigmoid(buf[u].x), rba_sigmoid(buf[u].y)};
+        const f32x2 s23 = {rba_sigmoid(buf[u].z), rba_sigmoid(buf[u].w)};
+        const int qn = q + U < Q ? q + U : Q - 1;
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+        const float* pq = prob + q * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const f32x2 pk = {pq[k], pq[k]};
+          a01[k] = __builtin_elementwise_fma(pk, s01, a01[k]);
+          a23[k] = __builtin_elementwise_fma(pk, s23, a23[k]);
+        }
+      }
+    }
+    float acc[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k][0] = a01[k].x; acc[k][1] = a01[k].y; acc[k][2] = a23[k].x; acc[k][3] = a23[k].y; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = Qmain + u;
+      if (q < Q) {
+        const float* pq = prob + q * K;
+        const float b[4] = {buf[u].x, buf[u].y, buf[u].z, buf[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float si = rba_sigmoid(b[i]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k][i] = fmaf(pq[k], si, acc[k][i]);
+        }
+      }
+    }
+    rba_epilogue<K, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
+  }
+}
+
+template <int K, bool SEM, bool ARG, int U, int WPS>
+int launch_reduce_pk(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int64_t HW, int mode,
+                     hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256 * WPS;
+  int64_t grid = tiles;
+  if (tiles > cap) {
+    const int64_t rounds = (tiles + cap - 1) / cap;
+    grid = (tiles + rounds - 1) / rounds;
+  }
+  hipLaunchKernelGGL((rba_reduce_pk_kernel<K, SEM, ARG, U, WPS>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW,
+                     (int)tiles, mode);
+  return rba_launch_status();
+}
+
 template <int K, int VEC, int U, int WPS>
 int launch_reduce_fast(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q,
                        int64_t HW, hipStream_t st, int mode = 0) {

@@ -460,6 +460,47 @@ int launch_valu_probe(const float* mask, const float* prob, float* rba, int Q, i
 }
 
 // Tuning hook (not part of the public ABI in include/rba_hip.h): K = 19 score-only variants of the fast kernel.
+
+// ---- VALU issue-rate probe: N dependent-free v_pk_fma_f32 per wave with the multiplier in an SGPR pair (as K1 uses it),
+// in a VGPR pair, and plain v_fma_f32; 8 waves per SIMD.  (variants 70-73 of tools/k1_sweep.py)
+template <int MODE>
+__global__ __launch_bounds__(256) void valu_rate_probe_kernel(const float* __restrict__ in, float* __restrict__ out, int iters) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f2){in[i], in[i + 16]};
+  const f2 x = {in[32 + (threadIdx.x & 7)], in[40 + (threadIdx.x & 7)]};
+  const float s0 = in[48], s1 = in[49];                         // wave-uniform -> SGPRs
+  const f2 vp = {in[50 + (threadIdx.x & 1)], in[52]};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (MODE == 0) {
+        f2 sp = {s0, s1};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "s"(sp), "v"(x));
+      } else if (MODE == 1) {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vp), "v"(x));
+      } else if (MODE == 2) {
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "s"(s0), "v"(x.x));
+      } else if (MODE == 3) {
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[i]) : "v"(vp), "v"(x));
+      } else if (MODE == 4) {
+        asm volatile("v_exp_f32 %0, %0" : "+v"(acc[i].x));
+      } else if (MODE == 5) {
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(acc[i].x));
+      } else if (MODE == 6) {
+        asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(x));
+      } else {
+        asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(x));
+      }
+    }
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += acc[i].x + acc[i].y;
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, float* rba, int Q, int64_t HW, int variant,
                                    void* stream) {
   rba_begin();
@@ -480,6 +521,19 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
     case 12: return launch_reduce_fast<19, 4, 1, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
     case 13: return launch_reduce_fast<19, 4, 1, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
     case 14: return launch_reduce_fast<19, 4, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
+    case 60: return launch_reduce_pk<19, false, false, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 61: return launch_reduce_pk<19, false, false, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 62: return launch_reduce_pk<19, false, false, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 63: return launch_reduce_pk<19, false, false, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 64: return launch_reduce_pk<19, false, false, 2, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 70: { hipLaunchKernelGGL(valu_rate_probe_kernel<0>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 71: { hipLaunchKernelGGL(valu_rate_probe_kernel<1>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 72: { hipLaunchKernelGGL(valu_rate_probe_kernel<2>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 73: { hipLaunchKernelGGL(valu_rate_probe_kernel<3>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 74: { hipLaunchKernelGGL(valu_rate_probe_kernel<4>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 75: { hipLaunchKernelGGL(valu_rate_probe_kernel<5>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 76: { hipLaunchKernelGGL(valu_rate_probe_kernel<6>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
+    case 77: { hipLaunchKernelGGL(valu_rate_probe_kernel<7>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
     case 82: return launch_valu_probe<2, 4, true, 1>(mask, cls_prob, rba, Q, HW, st);
     case 83: return launch_valu_probe<2, 4, true, 2>(mask, cls_prob, rba, Q, HW, st);
     case 80: return launch_valu_probe<2, 4, false>(mask, cls_prob, rba, Q, HW, st);
