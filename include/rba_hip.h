@@ -132,6 +132,18 @@ int rba_split_weight_bf16x3(const float* weight, void* packed, int N, int K, voi
 int rba_split_linear_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
                          int act, void* stream);
 
+/* The same GEMM with NHWC rows in and NCHW out: out[(b*N + n)*P + p] = sum_k x[b*P + p, k] * weight[n, k] + bias[n],
+ * P = rows_per_image, M % P == 0 (the mask-feature 1x1 convolution of pixel_decoder/msdeformattn.py:298-306). */
+int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N,
+                                  int K, int rows_per_image, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution over NHWC activations as an implicit GEMM on the same kernel:
+ * x [B,H,W,C] -> out [B,H,W,N]; weight_packed = rba_split_weight_bf16x3 of the [N, 9*C] matrix w[n][(3*ky + kx)*C + c]
+ * (conv weight [N,C,3,3] permuted to [N,3,3,C]); bias [N] or NULL.  C % 32 == 0.
+ * (the FPN output convolutions `layer_{j}` of pixel_decoder/msdeformattn.py:278-297, 357-360) */
+int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W, int C,
+                         int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

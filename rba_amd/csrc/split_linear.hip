@@ -109,6 +109,43 @@ __device__ __forceinline__ void store_tile(const f32x16_t (&acc)[2][2], const fl
   }
 }
 
+// Transposed epilogue (TRANS kernels): the accumulator rows are weight rows n, the columns GEMM rows m = b * ldo + p;
+// value (n, m) goes to C[(b * N + n) * ldo + p] (NCHW when the GEMM rows are NHWC pixels, ldo = H * W).
+template <int ACT>
+__device__ __forceinline__ void store_tile_transposed(const f32x16_t (&acc)[2][2], const float* __restrict__ bias,
+                                                      float* __restrict__ C, int M, int N, int nrow0, int mcol0, int ldo, int l31,
+                                                      int lh) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = mcol0 + 32 * j + l31;
+    const int b = m / ldo, p = m - b * ldo;
+    float* dst = C + (int64_t)b * N * ldo + p;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16_t v = acc[i][j];
+      const int nbase = nrow0 + 32 * i + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nbase + 8 * (r >> 2) + (r & 3);
+        v[r] += (bias && n < N) ? bias[n] : 0.f;
+        if (ACT == 1) v[r] = gelu_erf(v[r]);
+      }
+      if (m < M) {
+        if (nrow0 + 64 <= N) {                                     // wave-uniform: branch-free stores (see store_tile)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(int64_t)(nbase + 8 * (r >> 2) + (r & 3)) * ldo] = v[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = nbase + 8 * (r >> 2) + (r & 3);
+            if (n < N) dst[(int64_t)n * ldo] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
 __global__ void split_weight_kernel(const float* __restrict__ w, u32x4_t* __restrict__ packed, int N, int K) {
   const int Kc = K >> 3, S = K >> 4;                              // 8-element chunks per row, stages
   const int Np = (N + BN - 1) / BN * BN;                          // rows N..Np-1 of the last tile are zero
@@ -238,6 +275,13 @@ constexpr int BK2 = 16;                       // k extent of one pipelined stage
 struct StageRegs {
   f32x4 a0, a1;                               // A[row + 64 i][4 c .. 4 c + 3], i = 0, 1
   u32x4_t w0, w1, w2;                         // packed W block, plane p, linear 16-B index t
+  int ok;                                     // conv mode: bit i = the tap of this stage is inside the image for row i
+};
+
+// Implicit-GEMM geometry of a 3 x 3, stride 1, pad 1 convolution over NHWC activations x [B,H,W,C]:
+// GEMM row m = output pixel (b, y, x), k = (tap, c) with tap = 3 ky + kx; A[m][k] = x[b, y + ky - 1, x + kx - 1, c] or 0.
+struct ConvGeom {
+  int H, W, C, cpt;                           // cpt = C / 16 = k stages per tap
 };
 
 // Staging maps of the 256 staging threads (t = 0..255) for one 16-wide stage:
@@ -249,24 +293,53 @@ struct StageMap {
   const u32x4_t* w_src;                       // + s * 768
   int64_t a_row2;                             // element offset of the second row (0 when clamped onto the same row)
   int a_dst0, a_dst1;                         // uint2 index into a plane image [128][4]
+  int taps0, taps1;                           // conv mode: 9-bit masks of the taps that fall inside the image, rows 0 / 1
 };
-__device__ __forceinline__ StageMap make_stage_map(const float* A, const u32x4_t* Wp, int t, int m0, int nt, int M, int K) {
+// lda = row stride of A in floats (K for a Linear, C for the conv's NHWC activations)
+template <bool CONV>
+__device__ __forceinline__ StageMap make_stage_map(const float* A, const u32x4_t* Wp, int t, int m0, int nt, int M, int K, int lda,
+                                                   const ConvGeom& g) {
   StageMap m;
   const int c = t & 3, r0 = t >> 2, r1 = r0 + 64;
   int g0 = m0 + r0, g1 = m0 + r1;
   g0 = g0 < M ? g0 : M - 1;
   g1 = g1 < M ? g1 : M - 1;
-  m.a_src = A + (int64_t)g0 * K + c * 4;
-  m.a_row2 = (int64_t)(g1 - g0) * K;
+  m.a_src = A + (int64_t)g0 * lda + c * 4;
+  m.a_row2 = (int64_t)(g1 - g0) * lda;
   m.w_src = Wp + (int64_t)nt * (K >> 4) * 768 + t;
   m.a_dst0 = r0 * 4 + (((c >> 1) ^ ((r0 >> 3) & 1)) << 1) + (c & 1);
   m.a_dst1 = r1 * 4 + (((c >> 1) ^ ((r1 >> 3) & 1)) << 1) + (c & 1);
+  m.taps0 = m.taps1 = 0x1ff;
+  if (CONV) {
+    const int p0 = g0 % (g.H * g.W), p1 = g1 % (g.H * g.W);
+    const int y0 = p0 / g.W, x0 = p0 - y0 * g.W, y1 = p1 / g.W, x1 = p1 - y1 * g.W;
+    m.taps0 = m.taps1 = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      m.taps0 |= (y0 + dy >= 0 && y0 + dy < g.H && x0 + dx >= 0 && x0 + dx < g.W) ? 1 << tap : 0;
+      m.taps1 |= (y1 + dy >= 0 && y1 + dy < g.H && x1 + dx >= 0 && x1 + dx < g.W) ? 1 << tap : 0;
+    }
+  }
   return m;
 }
-__device__ __forceinline__ void stage_load(StageRegs& r, const StageMap& m, int s) {
-  const float* ap = m.a_src + s * 16;
-  r.a0 = *reinterpret_cast<const f32x4*>(ap);
-  r.a1 = *reinterpret_cast<const f32x4*>(ap + m.a_row2);
+template <bool CONV>
+__device__ __forceinline__ void stage_load(StageRegs& r, const StageMap& m, int s, const ConvGeom& g) {
+  if (CONV) {
+    const int tap = s / g.cpt, c0 = (s - tap * g.cpt) * 16;          // wave-uniform
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int off = (dy * g.W + dx) * g.C;
+    const int ok0 = (m.taps0 >> tap) & 1, ok1 = (m.taps1 >> tap) & 1;
+    r.ok = ok0 | (ok1 << 1);
+    // out-of-image taps read the pixel itself (always in bounds) and are zeroed when the data is stored to LDS
+    r.a0 = *reinterpret_cast<const f32x4*>(m.a_src + c0 + (ok0 ? off : 0));
+    r.a1 = *reinterpret_cast<const f32x4*>(m.a_src + m.a_row2 + c0 + (ok1 ? off : 0));
+  } else {
+    const float* ap = m.a_src + s * 16;
+    r.a0 = *reinterpret_cast<const f32x4*>(ap);
+    r.a1 = *reinterpret_cast<const f32x4*>(ap + m.a_row2);
+    r.ok = 3;
+  }
   const u32x4_t* wp = m.w_src + (int64_t)s * 768;
   r.w0 = wp[0];
   r.w1 = wp[256];
@@ -275,8 +348,10 @@ __device__ __forceinline__ void stage_load(StageRegs& r, const StageMap& m, int 
 // As3 / Ws3: the three plane images of one stage buffer, [3][128][2] x 16 B each
 __device__ __forceinline__ void stage_store(const StageRegs& r, const StageMap& m, u32x4_t* As3, u32x4_t* Ws3, int t) {
   uint2 p0, p1, p2, q0, q1, q2;
-  split4(make_float4(r.a0.x, r.a0.y, r.a0.z, r.a0.w), p0, p1, p2);
-  split4(make_float4(r.a1.x, r.a1.y, r.a1.z, r.a1.w), q0, q1, q2);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 v0 = (r.ok & 1) ? r.a0 : z, v1 = (r.ok & 2) ? r.a1 : z;
+  split4(make_float4(v0.x, v0.y, v0.z, v0.w), p0, p1, p2);
+  split4(make_float4(v1.x, v1.y, v1.z, v1.w), q0, q1, q2);
   uint2* a2 = reinterpret_cast<uint2*>(As3);
   a2[m.a_dst0] = p0;
   a2[512 + m.a_dst0] = p1;
@@ -297,10 +372,13 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, const StageMap& 
 // lane groups without padding.
 constexpr int STG = 3;
 
-template <int ACT>
+// CONV: A is an NHWC activation tensor and the GEMM is the implicit 3 x 3 convolution described at ConvGeom (K = 9 C).
+// TRANS: the output is written transposed, out[(b, n, p)] for GEMM row m = b * ldo + p (NCHW from NHWC rows): the operand roles
+// are swapped in the MFMAs (weights on the accumulator-row side) so that a wave-store still covers 128 contiguous bytes.
+template <int ACT, bool CONV = false, bool TRANS = false>
 __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                               const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                              int K, int MT, int NT) {
+                                                              int K, int MT, int NT, ConvGeom geom, int ldo) {
   __shared__ u32x4_t As[STG][3][BM][2];
   __shared__ u32x4_t Ws[STG][3][BN][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,9 +389,9 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
   const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const StageMap smap = make_stage_map(A, Wp, tid, m0, nt, M, K);
+  const StageMap smap = make_stage_map<CONV>(A, Wp, tid, m0, nt, M, K, CONV ? geom.C : K, geom);
   const int S = K / BK2, SL = S - 1;
-  auto gload = [&](StageRegs& r, int s) { stage_load(r, smap, s < SL ? s : SL); };
+  auto gload = [&](StageRegs& r, int s) { stage_load<CONV>(r, smap, s < SL ? s : SL, geom); };
   auto stash = [&](const StageRegs& r, int buf) { stage_store(r, smap, &As[buf][0][0][0], &Ws[buf][0][0][0], tid); };
 
   f32x16_t acc[2][2];
@@ -328,8 +406,12 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
   const int fa_row = 64 * wm + l31, fb_row = 64 * wn + l31;       // + 32 t; (row >> 3) & 1 is the same for t = 0, 1
   const int fa_slot = lh ^ ((fa_row >> 3) & 1), fb_slot = lh ^ ((fb_row >> 3) & 1);
   bf16x8_t a[2][3], b[2][3], na[2], nb0[2];
-  auto rd_a = [&](int buf, int t, int p) { return __builtin_bit_cast(bf16x8_t, As[buf][p][fa_row + 32 * t][fa_slot]); };
-  auto rd_b = [&](int buf, int t, int p) { return __builtin_bit_cast(bf16x8_t, Ws[buf][p][fb_row + 32 * t][fb_slot]); };
+  auto rd_a = [&](int buf, int t, int p) {
+    return __builtin_bit_cast(bf16x8_t, TRANS ? Ws[buf][p][fa_row + 32 * t][fa_slot] : As[buf][p][fa_row + 32 * t][fa_slot]);
+  };
+  auto rd_b = [&](int buf, int t, int p) {
+    return __builtin_bit_cast(bf16x8_t, TRANS ? As[buf][p][fb_row + 32 * t][fb_slot] : Ws[buf][p][fb_row + 32 * t][fb_slot]);
+  };
 #define RBA_G(pa, pb)                                                                                  \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)           \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
@@ -371,7 +453,10 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
 #undef RBA_STAGE
 #undef RBA_G
 
-  store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
+  if (TRANS)
+    store_tile_transposed<ACT>(acc, bias, C, M, N, n0 + 64 * wm, m0 + 64 * wn, ldo, l31, lh);
+  else
+    store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
 }
 
 
@@ -396,8 +481,9 @@ __global__ __launch_bounds__(512) void split_linear_ws_kernel(const float* __res
 
   if (wave >= 4) {                                                // ---------------- staging waves
     const int t = tid - 256;
-    const StageMap smap = make_stage_map(A, Wp, t, m0, nt, M, K);
-    auto gload = [&](StageRegs& r, int s) { stage_load(r, smap, s < SL ? s : SL); };
+    const ConvGeom nogeom = {0, 0, 0, 1};
+    const StageMap smap = make_stage_map<false>(A, Wp, t, m0, nt, M, K, K, nogeom);
+    auto gload = [&](StageRegs& r, int s) { stage_load<false>(r, smap, s < SL ? s : SL, nogeom); };
     auto stash = [&](const StageRegs& r, int buf) { stage_store(r, smap, &As[buf][0][0][0], &Ws[buf][0][0][0], t); };
     // NS rotating register sets: during stage s, set s % NS (stage s + 2, loaded NS stages ago) is split and stored, then
     // refilled with stage s + 2 + NS.  Loads are unconditional (clamped) so that the compiler's vmcnt waits stay exact.
@@ -503,6 +589,7 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
   static const int forced = getenv("RBA_GEMM_VARIANT") ? atoi(getenv("RBA_GEMM_VARIANT")) : 0;   // tuning hook (tools/gemm_sweep.py)
   const bool short_k = forced ? forced == 1 : K <= 256;
 #define RBA_L(KERNEL, A) hipLaunchKernelGGL(KERNEL<A>, grid, block, 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
+#define RBA_LP(A) hipLaunchKernelGGL((split_linear_pipe_kernel<A, false, false>), grid, block, 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT, ConvGeom{0, 0, 0, 1}, 0)
   if (forced == 4) {
 #define RBA_L8(A) hipLaunchKernelGGL((split_linear_ws_kernel<A>), grid, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
     if (act == 1) RBA_L8(1); else RBA_L8(0);
@@ -510,8 +597,47 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
   } else if (short_k) {
     if (act == 1) RBA_L(split_linear_short_kernel, 1); else RBA_L(split_linear_short_kernel, 0);
   } else {
-    if (act == 1) RBA_L(split_linear_pipe_kernel, 1); else RBA_L(split_linear_pipe_kernel, 0);
+    if (act == 1) RBA_LP(1); else RBA_LP(0);
   }
 #undef RBA_L
+#undef RBA_LP
+  return rba_launch_status();
+}
+
+// out[(b, n, p)] = sum_k x[b * P + p, k] * weight[n, k] + bias[n]: a Linear over NHWC rows written as NCHW ([B,N,P], P = rows
+// per image).  Used for the pixel decoder's mask-feature 1 x 1 convolution (msdeformattn.py:298-306 on NHWC activations).
+extern "C" int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M,
+                                             int N, int K, int rows_per_image, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= BK && (K % BK) == 0 && rows_per_image >= 1);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out && (M % rows_per_image) == 0);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out) & 15) == 0);
+  const int64_t MT = (M + BM - 1) / BM;
+  const int NT = (N + BN - 1) / BN;
+  RBA_CHECK_ARG(MT * NT < (int64_t)1 << 31 && M < (int64_t)1 << 31);
+  rba_begin();
+  hipLaunchKernelGGL((split_linear_pipe_kernel<0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<const u32x4_t*>(weight_packed), bias, out, (int)M, N, K, (int)MT, NT, ConvGeom{0, 0, 0, 1},
+                     rows_per_image);
+  return rba_launch_status();
+}
+
+// 3 x 3, stride 1, pad 1 convolution over NHWC activations as an implicit GEMM on the bf16x6 kernel:
+// x [B,H,W,C] -> out [B,H,W,N]; weight_packed = rba_split_weight_bf16x3 of the [N, 9 C] matrix w[n][(3 ky + kx) * C + c]
+// (= conv weight [N,C,3,3] permuted to [N,3,3,C]).  C % 16 == 0.  (msdeformattn.py:278-297 `layer_{j}` output convolutions.)
+extern "C" int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W,
+                                    int C, int N, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && C >= 16 && (C % 16) == 0 && N >= 1 && ((9 * C) % BK) == 0);
+  const int64_t M = (int64_t)B * H * W;
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out) & 15) == 0);
+  const int64_t MT = (M + BM - 1) / BM;
+  const int NT = (N + BN - 1) / BN;
+  RBA_CHECK_ARG(MT * NT < (int64_t)1 << 31 && M * C < (int64_t)1 << 31);
+  rba_begin();
+  hipLaunchKernelGGL((split_linear_pipe_kernel<0, true, false>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<const u32x4_t*>(weight_packed), bias, out, (int)M, N, 9 * C, (int)MT, NT,
+                     ConvGeom{H, W, C, C / 16}, 0);
   return rba_launch_status();
 }

@@ -356,3 +356,51 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None):
     _lib.check(lib.rba_split_linear_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, int(bool(gelu)), _stream()),
                "rba_split_linear_f32")
     return out
+
+
+def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
+    """x [B*P, K] (NHWC rows) -> [B, N, P]: the Linear of split_linear written channel-major (NHWC in, NCHW out)."""
+    lib = _lib.load()
+    _chk(x, "x", dim=2)
+    _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
+    M, K = x.shape
+    N = planes.shape[0] * 128 if out_features is None else int(out_features)
+    if (tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != K or (N + 127) // 128 != planes.shape[0]
+            or rows_per_image < 1 or M % rows_per_image):
+        raise RbaHipError("split_linear_nchw_out needs x [B*P, K], split_weight(W [N,K]) and M % rows_per_image == 0")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+        if bias.numel() != N:
+            raise RbaHipError("bias must have N elements")
+    out = torch.empty((M // rows_per_image, N, rows_per_image), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_split_linear_nchw_out_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, rows_per_image, _stream()),
+               "rba_split_linear_nchw_out_f32")
+    return out
+
+
+def conv3x3_weight(weight):
+    """conv weight [N, C, 3, 3] -> split_weight of the implicit-GEMM matrix [N, 9 C], k = (3 ky + kx) C + c."""
+    _chk(weight, "weight", dim=4)
+    N, C, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or C % 32:
+        raise RbaHipError("conv3x3_weight needs a [N, C, 3, 3] weight with C % 32 == 0")
+    return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous())
+
+
+def conv3x3_nhwc(x, planes, bias=None, out_features=None):
+    """3x3, stride 1, pad 1 convolution of NHWC x [B,H,W,C] with conv3x3_weight(W) -> [B,H,W,N] (implicit GEMM, bf16x6)."""
+    lib = _lib.load()
+    _chk(x, "x", dim=4)
+    _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
+    B, H, W, C = x.shape
+    N = planes.shape[0] * 128 if out_features is None else int(out_features)
+    if (tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != 9 * C or C % 16 or (9 * C) % 32
+            or (N + 127) // 128 != planes.shape[0]):
+        raise RbaHipError("conv3x3_nhwc needs x [B,H,W,C] (C % 32 == 0) and conv3x3_weight(W [N,C,3,3])")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+        if bias.numel() != N:
+            raise RbaHipError("bias must have N elements")
+    out = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_conv3x3_nhwc_f32(_p(x), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()), "rba_conv3x3_nhwc_f32")
+    return out

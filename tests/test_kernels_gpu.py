@@ -401,3 +401,31 @@ def test_split_linear_dispatch_and_errors(ops):
     with pytest.raises(RbaHipError):
         ops.split_linear(x, planes, out_features=1000)                           # does not match the packed tiles
     assert ops.split_linear(x[:0], planes).shape == (0, 16384, 2048)
+
+
+# ----------------------------------------------------------------------------------- bf16x6 conv3x3 (NHWC) and NCHW-out Linear
+@pytest.mark.parametrize("B,H,W,C,N,has_bias", [(1, 16, 24, 32, 128, False), (2, 9, 13, 64, 256, True), (1, 33, 20, 256, 256, False),
+                                                (1, 5, 3, 32, 40, True), (1, 64, 128, 256, 256, False)])
+def test_conv3x3_nhwc_vs_fp64(ops, B, H, W, C, N, has_bias):
+    """Implicit-GEMM 3x3 convolution (pad 1) on NHWC activations against F.conv2d in fp64, borders included."""
+    g = torch.Generator().manual_seed(B * 1000 + H * W + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5
+    b = torch.randn(N, generator=g) if has_bias else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if has_bias else None, padding=1).permute(0, 2, 3, 1)
+    planes = ops.conv3x3_weight(dev(w))
+    out = ops.conv3x3_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), planes, dev(b) if has_bias else None, out_features=N)
+    assert out.shape == (B, H, W, N)
+    assert maxerr(out, ref) < 2e-5 * (9 * C / 256) ** 0.5 + 2e-6
+
+
+@pytest.mark.parametrize("B,P,K,N", [(1, 1000, 64, 128), (2, 384, 256, 256), (1, 777, 128, 40), (3, 130, 32, 300)])
+def test_split_linear_nchw_out(ops, B, P, K, N):
+    g = torch.Generator().manual_seed(B + P + K + N)
+    x, w, b = torch.randn(B * P, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    ref = F.linear(x.double(), w.double(), b.double()).view(B, P, N).permute(0, 2, 1)
+    planes = ops.split_weight(dev(w))
+    out = ops.split_linear_nchw_out(dev(x), planes, dev(b), P, out_features=N)
+    assert out.shape == (B, N, P) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
+    same = ops.split_linear(dev(x), planes, dev(b), out_features=N).view(B, P, N).permute(0, 2, 1)
+    assert torch.equal(out, same.contiguous()), "transposed epilogue must give the same numbers as the row-major one"
