@@ -109,6 +109,14 @@ int64_t rba_group_norm_workspace_bytes(int B, int C, int HW, int G);
 int rba_group_norm_f32(const float* x, const float* gamma, const float* beta, float* y, float* workspace,
                        int B, int C, int HW, int G, float eps, int relu, void* stream);
 
+/* Channels-last variants of the two operators above for the token-layout (NHWC) FPN path:
+ * group norm over x [B,P,C] (statistics per image and group over P x C/G elements; (C/G) % 4 == 0, 256 % (C/4) == 0, C <= 1024),
+ * bilinear resample in [h,w,C] -> out [H,W,C] (+ add [H,W,C]); C % 4 == 0. */
+int64_t rba_group_norm_nhwc_workspace_bytes(int B, int P, int C, int G);
+int rba_group_norm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, float* workspace, int B, int P, int C,
+                            int G, float eps, int relu, void* stream);
+int rba_resample_bilinear_nhwc_f32(const float* in, const float* add, float* out, int C, int h, int w, int H, int W, void* stream);
+
 /* Fused residual add + LayerNorm over rows of length C (C % 4 == 0, C <= 8192):
  *   s = x (+ t) (+ t_bias[c]);  sum_out = s (optional, may alias x);  y = (s - mean) * rstd * gamma + beta.
  * t, t_bias, sum_out may be NULL.  (swin.py:284-293, msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58) */

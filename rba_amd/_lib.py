@@ -32,6 +32,9 @@ SIGNATURES = {
     "rba_split_linear_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_group_norm_nhwc_workspace_bytes": [_i, _i, _i, _i],
+    "rba_group_norm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
+    "rba_resample_bilinear_nhwc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_add_layer_norm_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_float, _vp],
     "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],

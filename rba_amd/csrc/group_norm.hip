@@ -96,6 +96,83 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// ---- channels-last (NHWC) variant for the token-layout FPN path: x [B, P, C] (P pixels), statistics per (image, group) over
+// P x (C / G) elements.  A thread owns one float4 of channels (one group when (C / G) % 4 == 0) and strides over pixels, so
+// every access is a contiguous row; per-chunk moments use the same workspace layout and Chan merge as the NCHW kernels.
+constexpr int PIX_CHUNK = 256;   // pixels per workgroup
+
+__global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const float* __restrict__ x, float* __restrict__ ws, int P, int C,
+                                                            int cpg, int splits) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int C4 = C >> 2, lanes = 256 / C4;                        // pixel lanes per workgroup
+  const int j = threadIdx.x % C4, pl = threadIdx.x / C4;
+  const int lo = s * PIX_CHUNK, hi = lo + PIX_CHUNK < P ? lo + PIX_CHUNK : P;
+  const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)b * P * C) + j;
+  float sum = 0.f, sq = 0.f;
+  if (pl < lanes)
+    for (int p = lo + pl; p < hi; p += lanes) {
+      const float4 v = xp[(int64_t)p * C4];
+      sum += (v.x + v.y) + (v.z + v.w);
+      sq = fmaf(v.x, v.x, sq); sq = fmaf(v.y, v.y, sq); sq = fmaf(v.z, v.z, sq); sq = fmaf(v.w, v.w, sq);
+    }
+  __shared__ float sh_s[256], sh_q[256];
+  sh_s[threadIdx.x] = sum;
+  sh_q[threadIdx.x] = sq;
+  __syncthreads();
+  const int G = C / cpg, q4 = cpg >> 2;                           // float4 chunks per group
+  if (threadIdx.x < G) {
+    const int g = threadIdx.x;
+    double ds = 0, dq = 0;
+    for (int l = 0; l < lanes; ++l)
+      for (int k = 0; k < q4; ++k) { ds += sh_s[l * C4 + g * q4 + k]; dq += sh_q[l * C4 + g * q4 + k]; }
+    const double n = (double)(hi - lo) * cpg;
+    const double mean = ds / n;
+    const double m2 = dq - ds * mean;
+    float* o = ws + (((int64_t)b * G + g) * splits + s) * 3;
+    o[0] = (float)n; o[1] = (float)mean; o[2] = (float)(m2 > 0 ? m2 : 0);
+  }
+}
+
+// one wave per (image, group): Chan merge of the chunk moments in double -> (mean, rstd)
+__global__ __launch_bounds__(64) void gn_merge_kernel(const float* __restrict__ ws, float* __restrict__ mr, int splits, float eps) {
+  const float* w = ws + (int64_t)blockIdx.x * splits * 3;
+  double n = 0, nm = 0;
+  for (int i = threadIdx.x; i < splits; i += 64) { n += w[3 * i]; nm += (double)w[3 * i] * w[3 * i + 1]; }
+  n = wave_sum_d(n); nm = wave_sum_d(nm);
+  const double mean = nm / n;
+  double m2 = 0;
+  for (int i = threadIdx.x; i < splits; i += 64) {
+    const double d = (double)w[3 * i + 1] - mean;
+    m2 += (double)w[3 * i + 2] + (double)w[3 * i] * d * d;
+  }
+  m2 = wave_sum_d(m2);
+  if (threadIdx.x == 0) { mr[2 * blockIdx.x] = (float)mean; mr[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(m2 / n + (double)eps)); }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ mr,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, int P, int C, int cpg) {
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int C4 = C >> 2, lanes = 256 / C4;
+  const int j = threadIdx.x % C4, pl = threadIdx.x / C4;
+  if (pl >= lanes) return;
+  const int G = C / cpg, g = (j << 2) / cpg;
+  const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[j], be = reinterpret_cast<const float4*>(beta)[j];
+  const float a0 = ga.x * rstd, a1 = ga.y * rstd, a2 = ga.z * rstd, a3 = ga.w * rstd;
+  const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+  const int lo = s * PIX_CHUNK, hi = lo + PIX_CHUNK < P ? lo + PIX_CHUNK : P;
+  const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)b * P * C) + j;
+  float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * P * C) + j;
+  for (int p = lo + pl; p < hi; p += lanes) {
+    float4 v = xp[(int64_t)p * C4];
+    v.x = fmaf(v.x, a0, b0); v.y = fmaf(v.y, a1, b1); v.z = fmaf(v.z, a2, b2); v.w = fmaf(v.w, a3, b3);
+    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    yp[(int64_t)p * C4] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t rba_group_norm_workspace_bytes(int B, int C, int HW, int G) {
@@ -122,5 +199,32 @@ extern "C" int rba_group_norm_f32(const float* x, const float* gamma, const floa
     hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, st, x, workspace, gamma, beta, y, gsize, (int)splits, HW, cpg, G, eps);
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, st, x, workspace, gamma, beta, y, gsize, (int)splits, HW, cpg, G, eps);
+  return rba_launch_status();
+}
+
+extern "C" int64_t rba_group_norm_nhwc_workspace_bytes(int B, int P, int C, int G) {
+  if (B <= 0 || C <= 0 || P <= 0 || G <= 0 || C % G) return 0;
+  const int64_t splits = (P + PIX_CHUNK - 1) / PIX_CHUNK;
+  return ((int64_t)B * G * splits * 3 + (int64_t)B * G * 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int rba_group_norm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, float* workspace, int B,
+                                       int P, int C, int G, float eps, int relu, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && C >= 4 && P >= 0 && G >= 1 && C % G == 0 && (C / G) % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && G <= 256);
+  if (B == 0 || P == 0) return 0;
+  RBA_CHECK_ARG(x && gamma && beta && y && workspace && B <= 65535);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+  const int cpg = C / G;
+  const int splits = (P + PIX_CHUNK - 1) / PIX_CHUNK;
+  float* mr = workspace + (int64_t)B * G * splits * 3;
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(splits, B);
+  hipLaunchKernelGGL(gn_stats_nhwc_kernel, grid, dim3(256), 0, st, x, workspace, P, C, cpg, splits);
+  hipLaunchKernelGGL(gn_merge_kernel, dim3(B * G), dim3(64), 0, st, workspace, mr, splits, eps);
+  if (relu)
+    hipLaunchKernelGGL(gn_apply_nhwc_kernel<true>, grid, dim3(256), 0, st, x, mr, gamma, beta, y, P, C, cpg);
+  else
+    hipLaunchKernelGGL(gn_apply_nhwc_kernel<false>, grid, dim3(256), 0, st, x, mr, gamma, beta, y, P, C, cpg);
   return rba_launch_status();
 }

@@ -46,6 +46,33 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
   }
 }
 
+// channels-last variant: in [h, w, C] -> out [H, W, C] (+ add).  A thread owns one float4 of channels of one output pixel:
+// the four taps are four contiguous 16-byte loads, a wave covers whole pixel rows.  Same tap arithmetic as above.
+template <bool ADD>
+__global__ __launch_bounds__(256) void resample_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ add,
+                                                            float* __restrict__ out, int C4, int h, int w, int H, int W, float sh,
+                                                            float sw) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)H * W * C4;
+  if (idx >= total) return;
+  const int j = (int)(idx % C4);
+  const int64_t pix = idx / C4;
+  const int x = (int)(pix % W), y = (int)(pix / W);
+  const BilinearTap ty = bilinear_tap(y, sh, h), tx = bilinear_tap(x, sw, w);
+  const f32x4* ip = reinterpret_cast<const f32x4*>(in) + j;
+  const f32x4 v00 = ip[((int64_t)ty.i0 * w + tx.i0) * C4], v01 = ip[((int64_t)ty.i0 * w + tx.i1) * C4];
+  const f32x4 v10 = ip[((int64_t)ty.i1 * w + tx.i0) * C4], v11 = ip[((int64_t)ty.i1 * w + tx.i1) * C4];
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float top = tx.l0 * v00[k] + tx.l1 * v01[k];
+    const float bot = tx.l0 * v10[k] + tx.l1 * v11[k];
+    r[k] = ty.l0 * top + ty.l1 * bot;
+  }
+  if (ADD) r += reinterpret_cast<const f32x4*>(add)[idx];
+  reinterpret_cast<f32x4*>(out)[idx] = r;
+}
+
 }  // namespace
 
 extern "C" int rba_resample_bilinear_f32(const float* in, const float* add, float* out, int C, int h, int w, int H, int W,
@@ -69,5 +96,22 @@ extern "C" int rba_resample_bilinear_f32(const float* in, const float* add, floa
   else if (vec4) RBA_L(false, true);
   else RBA_L(false, false);
 #undef RBA_L
+  return rba_launch_status();
+}
+
+extern "C" int rba_resample_bilinear_nhwc_f32(const float* in, const float* add, float* out, int C, int h, int w, int H, int W,
+                                              void* stream) {
+  RBA_CHECK_ARG(C >= 0 && (C & 3) == 0 && h >= 1 && w >= 1 && H >= 0 && W >= 0);
+  if (C == 0 || H == 0 || W == 0) return 0;
+  RBA_CHECK_ARG(in && out && ((((uintptr_t)in | (uintptr_t)out | (uintptr_t)add) & 15) == 0));
+  const int64_t total = (int64_t)H * W * (C >> 2);
+  RBA_CHECK_ARG((total + 255) / 256 <= 0x7fffffff);
+  rba_begin();
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (add)
+    hipLaunchKernelGGL(resample_nhwc_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, add, out, C >> 2, h, w, H, W, sh, sw);
+  else
+    hipLaunchKernelGGL(resample_nhwc_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, add, out, C >> 2, h, w, H, W, sh, sw);
   return rba_launch_status();
 }

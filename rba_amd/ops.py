@@ -404,3 +404,41 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     out = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
     _lib.check(lib.rba_conv3x3_nhwc_f32(_p(x), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()), "rba_conv3x3_nhwc_f32")
     return out
+
+
+def group_norm_nhwc(x, num_groups, weight, bias, eps=1e-5, relu=False):
+    """GroupNorm (+ReLU) of channels-last x [B, P, C] (or [B, H, W, C]): the same operator as group_norm on the token layout."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(weight, "weight", dim=1)
+    _chk(bias, "bias", dim=1)
+    if x.dim() not in (3, 4):
+        raise RbaHipError("x must be [B,P,C] or [B,H,W,C]")
+    B, C = x.shape[0], x.shape[-1]
+    P = x.numel() // (B * C) if B * C else 0
+    if C % num_groups or weight.numel() != C or bias.numel() != C or (C // num_groups) % 4 or C > 1024 or 256 % (C // 4):
+        raise RbaHipError("group_norm_nhwc needs C % G == 0, (C/G) % 4 == 0, C <= 1024 and 256 % (C/4) == 0")
+    nbytes = lib.rba_group_norm_nhwc_workspace_bytes(B, P, C, num_groups)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.rba_group_norm_nhwc_f32(_p(x), _p(weight), _p(bias), _p(y), _p(ws), B, P, C, num_groups, float(eps),
+                                           int(bool(relu)), _stream()), "rba_group_norm_nhwc_f32")
+    return y
+
+
+def resample_bilinear_nhwc(x, size, add=None):
+    """F.interpolate(mode="bilinear", align_corners=False) of channels-last x [h, w, C] -> [H, W, C], optional fused `+ add`."""
+    lib = _lib.load()
+    _chk(x, "x", dim=3)
+    h, w, C = x.shape
+    H, W = int(size[0]), int(size[1])
+    if C % 4:
+        raise RbaHipError("resample_bilinear_nhwc needs C % 4 == 0")
+    out = torch.empty((H, W, C), dtype=torch.float32, device=x.device)
+    if add is not None:
+        _chk(add, "add")
+        if tuple(add.shape) != tuple(out.shape):
+            raise RbaHipError("add must have the output's shape")
+    _lib.check(lib.rba_resample_bilinear_nhwc_f32(_p(x), _p(add), _p(out), C, h, w, H, W, _stream()),
+               "rba_resample_bilinear_nhwc_f32")
+    return out

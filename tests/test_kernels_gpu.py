@@ -419,7 +419,7 @@ def test_conv3x3_nhwc_vs_fp64(ops, B, H, W, C, N, has_bias):
     assert maxerr(out, ref) < 2e-5 * (9 * C / 256) ** 0.5 + 2e-6
 
 
-@pytest.mark.parametrize("B,P,K,N", [(1, 1000, 64, 128), (2, 384, 256, 256), (1, 777, 128, 40), (3, 130, 32, 300)])
+@pytest.mark.parametrize("B,P,K,N", [(1, 1000, 64, 128), (2, 384, 256, 256), (1, 777, 128, 40), (3, 130, 32, 300), (2, 640, 512, 256)])
 def test_split_linear_nchw_out(ops, B, P, K, N):
     g = torch.Generator().manual_seed(B + P + K + N)
     x, w, b = torch.randn(B * P, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
@@ -428,4 +428,34 @@ def test_split_linear_nchw_out(ops, B, P, K, N):
     out = ops.split_linear_nchw_out(dev(x), planes, dev(b), P, out_features=N)
     assert out.shape == (B, N, P) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
     same = ops.split_linear(dev(x), planes, dev(b), out_features=N).view(B, P, N).permute(0, 2, 1)
-    assert torch.equal(out, same.contiguous()), "transposed epilogue must give the same numbers as the row-major one"
+    assert maxerr(out, same.double()) < 1e-5      # same six terms; the operand roles (and so the summation order) are swapped
+
+
+# ----------------------------------------------------------------------------------- channels-last GroupNorm / resample
+@pytest.mark.parametrize("B,P,C,G,relu", [(1, 1000, 256, 32, True), (2, 257, 256, 32, False), (1, 131072, 256, 32, True),
+                                          (1, 77, 128, 32, False), (3, 5, 64, 4, True), (1, 300, 1024, 32, False)])
+def test_group_norm_nhwc(ops, B, P, C, G, relu):
+    g = torch.Generator().manual_seed(P + C)
+    x = torch.randn(B, P, C, generator=g) * 2.0 + 0.7
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x.double().permute(0, 2, 1), G, w.double(), b.double(), 1e-5).permute(0, 2, 1)
+    ref = F.relu(ref) if relu else ref
+    out = ops.group_norm_nhwc(dev(x), G, dev(w), dev(b), 1e-5, relu=relu)
+    assert out.shape == x.shape and maxerr(out, ref) < 2e-5
+    same = ops.group_norm(dev(x.permute(0, 2, 1).reshape(B, C, P, 1).contiguous()), G, dev(w), dev(b), 1e-5, relu=relu)
+    assert maxerr(out, same.view(B, C, P).permute(0, 2, 1).double()) < 2e-5
+
+
+@pytest.mark.parametrize("h,w,H,W,C,has_add", [(32, 64, 64, 128, 256, True), (7, 9, 14, 18, 8, False), (45, 80, 90, 160, 256, True),
+                                               (5, 5, 12, 7, 4, False), (64, 128, 256, 512, 256, True)])
+def test_resample_bilinear_nhwc(ops, h, w, H, W, C, has_add):
+    g = torch.Generator().manual_seed(h * w + C)
+    x = torch.randn(h, w, C, generator=g)
+    add = torch.randn(H, W, C, generator=g) if has_add else None
+    ref = F.interpolate(x.permute(2, 0, 1)[None].double(), size=(H, W), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    ref = ref + add.double() if has_add else ref
+    out = ops.resample_bilinear_nhwc(dev(x), (H, W), add=dev(add) if has_add else None)
+    assert out.shape == (H, W, C) and maxerr(out, ref) < 1e-5
+    nchw = ops.resample_bilinear(dev(x.permute(2, 0, 1).contiguous()), (H, W),
+                                 add=dev(add.permute(2, 0, 1).contiguous()) if has_add else None)
+    assert maxerr(out, nchw.permute(1, 2, 0).double()) < 2e-6      # same taps and weights (fma contraction may differ)
