@@ -156,7 +156,9 @@ class D2SwinTransformer(nn.Module):
             norm = getattr(self, f"norm{i}")
             t, tb = pending if pending is not None else (None, None)
             x, y = ops.add_layer_norm(x, norm.weight, norm.bias, norm.eps, t, tb, inplace_sum=True)
-            outs[f"res{i + 2}"] = y.view(-1, Wh, Ww, self.num_features[i]).permute(0, 3, 1, 2).contiguous()
+            # [B,C,h,w] as a channels-last VIEW of the token tensor (no copy): same values and shape as the reference's
+            # permute(0,3,1,2).contiguous() (swin.py:752-753); the pixel decoder consumes the token layout directly
+            outs[f"res{i + 2}"] = y.view(-1, Wh, Ww, self.num_features[i]).permute(0, 3, 1, 2)
             if layer.downsample is not None:
                 x = layer.downsample(x, Wh, Ww)
                 Wh, Ww = (Wh + 1) // 2, (Ww + 1) // 2

@@ -12,6 +12,13 @@ from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from .ops.ms_deform_attn import MSDeformAttn
 
 
+class _LinearView:
+    """A 1x1 convolution's parameters seen as an nn.Linear (weight [N,C], bias) for ops.linear."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+
+
 class ConvNorm(nn.Module):
     """Detectron2 ``Conv2d`` wrapper as a parameter holder: ``weight`` (+ ``bias``) and an optional ``norm`` child
     (conv -> GroupNorm(32) -> optional ReLU), keys ``<name>.weight``, ``<name>.norm.{weight,bias}``."""
@@ -117,11 +124,81 @@ class MSDeformAttnPixelDecoder(nn.Module):
             self.add_module(f"adapter_{j}", ConvNorm(chans[FEATURE_NAMES[j - 1]], d, 1, bias=False, norm=True))
             self.add_module(f"layer_{j}", ConvNorm(d, d, 3, bias=False, norm=True, relu=True))
 
-    def forward_features(self, features):
-        """-> (mask_features [B,md,H/4,W/4], out[0], multi_scale_features) (msdeformattn.py:323-367)."""
+    # ---- channels-last (token layout) path --------------------------------------------------------------------------
+    # Swin hands its feature maps over as channels-last views of [B, h*w, C] token tensors.  On that layout every 1x1
+    # convolution is a Linear on the tokens and the 3x3 output convolutions are implicit GEMMs (K6, bf16x6), GroupNorm and the
+    # top-down resample+add have channels-last kernels, and the mask-feature projection writes NCHW for K4: no layout
+    # transposes, no MIOpen.  Same arithmetic as the NCHW path below (msdeformattn.py:323-367), which stays for other layouts.
+    @staticmethod
+    def _tokens(x):
+        """[B,C,h,w] channels-last view -> [B, h*w, C] token view (no copy), or None for any other layout."""
+        t = x.permute(0, 2, 3, 1)
+        return t.reshape(x.shape[0], -1, x.shape[1]) if (x.is_cuda and x.dtype == torch.float32 and t.is_contiguous()) else None
+
+    @staticmethod
+    def _cached(mod, name, build):
+        w = mod.weight
+        key = (w.data_ptr(), w._version, w.device)
+        c = getattr(mod, name, None)
+        if c is None or c[0] != key:
+            c = (key, build())
+            setattr(mod, name, c)
+        return c[1]
+
+    def _conv1x1(self, tok, mod, use_bias=True):
+        """1x1 convolution of `mod` (weight [N,C,1,1]) on tokens [B,P,C] -> [B,P,N]."""
+        lin = self._cached(mod, "_rba_lin", lambda: _LinearView(mod.weight.view(mod.weight.shape[0], -1), mod.bias))
+        return ops.linear(tok, lin, use_bias=use_bias)
+
+    def _channels_last_ok(self, features):
+        d = self.mask_features.weight.shape[1]
+        if d % 32 or (d // 32) % 4 or 256 % (d // 4) or d > 1024:
+            return False
+        need = set(self.transformer_in_features) | set(self.in_features[:self.num_fpn_levels])
+        return all(self._tokens(features[f]) is not None and features[f].shape[1] % 32 == 0 for f in need)
+
+    def _forward_features_channels_last(self, features):
         srcs, pos = [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
-            x = features[f].float()
+            x = features[f]
+            B, _, h, w = x.shape
+            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+            y = ops.group_norm_nhwc(self._conv1x1(self._tokens(x), conv), 32, gn.weight, gn.bias, gn.eps)
+            srcs.append(y.view(B, h, w, -1).permute(0, 3, 1, 2))
+            pos.append(self.pe_layer(x))
+        y, shapes = self.transformer(srcs, pos)
+        B, d = y.shape[0], y.shape[2]
+        toks = [z.contiguous() for z in torch.split(y, [h * w for h, w in shapes], dim=1)]
+        outs = [z.view(B, h, w, d).permute(0, 3, 1, 2).contiguous() for z, (h, w) in zip(toks, shapes)]
+        prev, (ph, pw) = toks[-1], shapes[-1]
+        for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
+            j = self.num_fpn_levels - idx
+            x = features[f]
+            h, w = int(x.shape[-2]), int(x.shape[-1])
+            ad, ly = getattr(self, f"adapter_{j}"), getattr(self, f"layer_{j}")
+            cur = ops.group_norm_nhwc(self._conv1x1(self._tokens(x), ad, use_bias=False), 32, ad.norm.weight, ad.norm.bias,
+                                      ad.norm.eps)
+            ups = [ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d))
+                   for b in range(B)]                                                      # :357-358 fused sum
+            yy = ups[0][None] if B == 1 else torch.stack(ups)
+            planes = self._cached(ly, "_rba_conv", lambda: ops.conv3x3_weight(ly.weight.detach()))
+            z = ops.conv3x3_nhwc(yy, planes, None, out_features=d)
+            prev = ops.group_norm_nhwc(z.view(B, h * w, d), 32, ly.norm.weight, ly.norm.bias, ly.norm.eps, relu=True)
+            ph, pw = h, w
+        mfw = self.mask_features.weight
+        planes = self._cached(self.mask_features, "_rba_planes",
+                              lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous()))
+        mf = ops.split_linear_nchw_out(prev.view(B * ph * pw, d), planes, self.mask_features.bias, ph * pw,
+                                       out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)
+        return mf, outs[0], outs[:self.maskformer_num_feature_levels]
+
+    def forward_features(self, features):
+        """-> (mask_features [B,md,H/4,W/4], out[0], multi_scale_features) (msdeformattn.py:323-367)."""
+        if self.num_fpn_levels > 0 and self._channels_last_ok(features):
+            return self._forward_features_channels_last(features)
+        srcs, pos = [], []
+        for idx, f in enumerate(self.transformer_in_features[::-1]):
+            x = features[f].float().contiguous()                       # (channels-last views from Swin are copied to NCHW here)
             conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
             srcs.append(ops.group_norm(F.conv2d(x, conv.weight, conv.bias).contiguous(), 32, gn.weight, gn.bias, gn.eps))
             pos.append(self.pe_layer(x))
@@ -131,7 +208,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 for i, z in enumerate(torch.split(y, [h * w for h, w in shapes], dim=1))]
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             j = self.num_fpn_levels - idx
-            cur = getattr(self, f"adapter_{j}")(features[f].float())
+            cur = getattr(self, f"adapter_{j}")(features[f].float().contiguous())
             yy = ops.resample_bilinear(outs[-1], cur.shape[-2:], add=cur.contiguous())   # :357-358 fused sum
             outs.append(getattr(self, f"layer_{j}")(yy))
         mf = F.conv2d(outs[-1], self.mask_features.weight, self.mask_features.bias)
