@@ -341,6 +341,79 @@ int launch_reduce_pk(const float* mask, const float* prob, float* rba, float* se
   return rba_launch_status();
 }
 
+// LDS-DMA ring formulation (4 pixels per thread): each wave streams its query planes through a private ring of R 1-KiB LDS
+// slots with global_load_lds_dwordx4 (no destination VGPRs, so R planes per wave are in flight instead of 2), reads its own
+// 16 bytes back with ds_read_b128 once the counted vmcnt says the plane has landed, and refills the slot.  No barrier: a lane
+// only ever reads what it loaded itself.  The compiler does not order a ds_read behind a pending LDS-DMA, so the wait is an
+// explicit s_waitcnt vmcnt(R - 1) and the read is inline asm.  Arithmetic identical to rba_reduce_pk_kernel (bit-identical).
+template <int K, bool SEM, bool ARG, int R, int WPS>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_dma_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                float* __restrict__ rba, float* __restrict__ sem,
+                                                                int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode) {
+  static_assert(R >= 2 && R <= 15, "vmcnt immediate");
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char* wring = ring_raw + wave * (R * 1024);                       // this wave's ring
+  const uint32_t lds_lane = (uint32_t)(uintptr_t)(wring) + lane * 16;        // LDS byte address of this lane's 16 B in slot 0
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;              // HW % 1024 == 0 is required by the launcher
+    f32x2 a01[K], a23[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
+    const float* mp = mask + p0;
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mp + (int64_t)(u < Q ? u : Q - 1) * HW),
+                                       (__attribute__((address_space(3))) void*)(wring + u * 1024), 16, 0, 0);
+    for (int q0 = 0; q0 < Q; q0 += R) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int q = q0 + u;
+        if (q < Q) {                                                         // wave-uniform
+          f32x4 v;
+          // plane q is the oldest of the R DMAs in flight: wait until at most R - 1 are outstanding, then read it back
+          asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %1 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                       : "=v"(v) : "v"(lds_lane), "n"(R - 1), "n"(u * 1024) : "memory");
+          const int qn = q + R < Q ? q + R : Q - 1;                          // clamped refill keeps the count exact
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mp + (int64_t)qn * HW),
+                                           (__attribute__((address_space(3))) void*)(wring + u * 1024), 16, 0, 0);
+          const f32x2 s01 = {rba_sigmoid(v.x), rba_sigmoid(v.y)};
+          const f32x2 s23 = {rba_sigmoid(v.z), rba_sigmoid(v.w)};
+          const float* pq = prob + q * K;
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const f32x2 pk = {pq[k], pq[k]};
+            a01[k] = __builtin_elementwise_fma(pk, s01, a01[k]);
+            a23[k] = __builtin_elementwise_fma(pk, s23, a23[k]);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // drain the clamped refills before the ring is reused
+    float acc[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k][0] = a01[k].x; acc[k][1] = a01[k].y; acc[k][2] = a23[k].x; acc[k][3] = a23[k].y; }
+    rba_epilogue<K, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
+  }
+}
+
+template <int K, bool SEM, bool ARG, int R, int WPS>
+int launch_reduce_dma(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int64_t HW, int mode,
+                      hipStream_t st) {
+  if (HW % 1024) return (int)hipErrorInvalidValue;
+  const int64_t tiles = HW / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256 * WPS;
+  int64_t grid = tiles;
+  if (tiles > cap) {
+    const int64_t rounds = (tiles + cap - 1) / cap;
+    grid = (tiles + rounds - 1) / rounds;
+  }
+  hipLaunchKernelGGL((rba_reduce_dma_kernel<K, SEM, ARG, R, WPS>), dim3((unsigned)grid), dim3(256), 4 * R * 1024, st, mask, prob, rba, sem,
+                     argmax, Q, HW, (int)tiles, mode);
+  return rba_launch_status();
+}
+
 template <int K, int VEC, int U, int WPS>
 int launch_reduce_fast(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q,
                        int64_t HW, hipStream_t st, int mode = 0) {

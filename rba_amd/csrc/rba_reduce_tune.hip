@@ -526,6 +526,11 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
     case 62: return launch_reduce_pk<19, false, false, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 63: return launch_reduce_pk<19, false, false, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 64: return launch_reduce_pk<19, false, false, 2, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 65: return launch_reduce_dma<19, false, false, 8, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 66: return launch_reduce_dma<19, false, false, 6, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 67: return launch_reduce_dma<19, false, false, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 68: return launch_reduce_dma<19, false, false, 8, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 69: return launch_reduce_dma<19, false, false, 12, 3>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 70: { hipLaunchKernelGGL(valu_rate_probe_kernel<0>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
     case 71: { hipLaunchKernelGGL(valu_rate_probe_kernel<1>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
     case 72: { hipLaunchKernelGGL(valu_rate_probe_kernel<2>, dim3(256 * 8), dim3(256), 0, st, cls_prob, rba, 2000); return rba_launch_status(); }
