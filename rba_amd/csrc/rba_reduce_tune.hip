@@ -526,6 +526,24 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
     case 62: return launch_reduce_pk<19, false, false, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 63: return launch_reduce_pk<19, false, false, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 64: return launch_reduce_pk<19, false, false, 2, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 100: {   // non-persistent: one 1024-pixel tile per workgroup, the dispatcher balances the CUs
+      const int tiles = (int)((HW + 1023) / 1024);
+      hipLaunchKernelGGL((rba_reduce_fast_kernel<19, 4, false, false, 2, 4>), dim3(tiles), dim3(256), 0, st, mask, cls_prob, rba,
+                         (float*)nullptr, (int32_t*)nullptr, Q, HW, tiles, 0);
+      return rba_launch_status();
+    }
+    case 101: {   // 3/4 of the tiles persistent-style, rest picked up dynamically: grid = 1536
+      const int tiles = (int)((HW + 1023) / 1024);
+      hipLaunchKernelGGL((rba_reduce_fast_kernel<19, 4, false, false, 2, 4>), dim3(tiles * 3 / 4), dim3(256), 0, st, mask, cls_prob, rba,
+                         (float*)nullptr, (int32_t*)nullptr, Q, HW, tiles, 0);
+      return rba_launch_status();
+    }
+    case 102: {   // 2-pixel threads: 512-pixel tiles, 4096 workgroups, non-persistent
+      const int tiles = (int)((HW + 511) / 512);
+      hipLaunchKernelGGL((rba_reduce_fast_kernel<19, 2, false, false, 4, 8>), dim3(tiles), dim3(256), 0, st, mask, cls_prob, rba,
+                         (float*)nullptr, (int32_t*)nullptr, Q, HW, tiles, 0);
+      return rba_launch_status();
+    }
     case 65: return launch_reduce_dma<19, false, false, 8, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 66: return launch_reduce_dma<19, false, false, 6, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
     case 67: return launch_reduce_dma<19, false, false, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
