@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librba_hip.so")
+LIB_PATH = os.environ.get("RBA_HIP_LIB") or os.path.join(_HERE, "csrc", "librba_hip.so")   # env override: A/B runs of two builds
 
 _c_f32p = ctypes.c_void_p
 _i = ctypes.c_int
