@@ -25,6 +25,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (same guide; the 5 PFLOP/s headline is with 2:1 sparsity)
 
 
 def parse():
@@ -250,6 +251,34 @@ def main():
         torch.cuda.synchronize()
         exch_ms = (time.perf_counter() - t1) * 1e3
 
+    # ---- K6 (bf16x6 Linear), the kernel that takes most of the image time: one of its stage-3 launches (fc1 + GELU of the
+    # backbone's deepest stage at this resolution) timed with HIP events outside the timed region.  bf16 flops = 6 per fp32 MAC pair.
+    gemm = None
+    if rank == 0:
+        try:
+            C3 = a["embed_dim"] * 4
+            M3 = (H // 16) * (W // 16)
+            lin = model.backbone.layers[2].blocks[0].mlp.fc1
+            if ops.split_linear_pays(M3, lin.weight.shape[0], lin.weight.shape[1], True):
+                xg = torch.randn(M3, C3, device=dev)
+                with torch.no_grad():
+                    for _ in range(3):
+                        ops.linear(xg, lin, gelu=True)
+                    evs = []
+                    for _ in range(10):
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record(); ops.linear(xg, lin, gelu=True); e1.record()
+                        evs.append((e0, e1))
+                torch.cuda.synchronize()
+                g_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+                flops32 = 2.0 * M3 * lin.weight.shape[0] * lin.weight.shape[1]
+                gemm = {"bound": "mfma", "kernel": "split_linear_pipe_kernel<gelu> (fc1 of Swin stage 3)", "shape_MNK": [M3, lin.weight.shape[0], lin.weight.shape[1]],
+                        "achieved": 6.0 * flops32 / (g_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16, six products per fp32 product)",
+                        "frac": 6.0 * flops32 / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": flops32 / (g_ms * 1e-3) / 1e12,
+                        "avg_launch_ms": g_ms, "launches_timed": len(evs)}
+        except Exception as e:                                           # informational only
+            print(f"[bench] K6 roofline probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
+
     traffic = None
     pmc = os.path.join(REPO, "profiles", "k1_pmc.json")
     if args.k1 == "fullres" and os.path.exists(pmc):
@@ -283,6 +312,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg_ms,
                          "min_launch_ms": k1_ms[0], "launches_timed": len(k1_ms)},
         }
+        if gemm is not None:
+            res["roofline_gemm"] = gemm
         if exch_ms is not None:
             res["metric_exchange_ms"] = exch_ms
             res["pooled_metrics"] = m
