@@ -230,3 +230,37 @@ def test_c1_random_tensor_256x512_vs_oracle():
     assert maxerr(out["sem_seg"], ref["sem_seg"]) < 1e-4 and maxerr(out["rba"], ref["rba"]) < 1e-4
     bad, flips = argmax_bad(out["argmax"], ref["sem_seg"])
     assert bad == 0, (bad, flips)
+
+
+def test_channels_last_fpn_path_matches_nchw_path_and_batches():
+    """The token-layout (channels-last) pixel-decoder path -- 1x1 convs as Linears, 3x3 convs as bf16x6 implicit GEMMs, NHWC
+    GroupNorm / resample, NCHW mask features -- against the NCHW path (MIOpen convs) on the same Swin-B features, for a batch
+    of two images; and the batch against the same images run one at a time."""
+    model, a, sd = build("swin_b_1dl", 0)
+
+    def maxerr(u, v):
+        return (u.double() - v.double()).abs().max().item()
+
+    pd = model.sem_seg_head.pixel_decoder
+    g = torch.Generator().manual_seed(21)
+    ims = [torch.randint(0, 256, (3, 256, 384), generator=g, dtype=torch.uint8) for _ in range(2)]
+    with torch.no_grad():
+        x, _ = model.preprocess([{"image": im} for im in ims])
+        feats = model.backbone(x)
+        assert pd._channels_last_ok(feats), "Swin must hand over channels-last views the FPN can consume"
+        mf_cl, out0_cl, ms_cl = pd.forward_features(feats)
+        ok = pd._channels_last_ok
+        try:
+            pd._channels_last_ok = lambda f: False                                              # force the NCHW path
+            mf_nc, out0_nc, ms_nc = pd.forward_features(feats)
+        finally:
+            pd._channels_last_ok = ok
+        assert mf_cl.shape == mf_nc.shape == (2, 256, 64, 96) and mf_cl.is_contiguous()
+        scale = float(mf_nc.abs().max())
+        assert maxerr(mf_cl, mf_nc) < 2e-5 * max(scale, 1.0), (maxerr(mf_cl, mf_nc), scale)
+        assert maxerr(out0_cl, out0_nc) < 2e-5 and all(maxerr(u, v) < 2e-5 for u, v in zip(ms_cl, ms_nc))
+        # batch of two == each image alone (no cross-image leakage in the implicit-GEMM borders / per-image statistics)
+        for b in range(2):
+            xb, _ = model.preprocess([{"image": ims[b]}])
+            mf_b, _, _ = pd.forward_features(model.backbone(xb))
+            assert maxerr(mf_b[0], mf_cl[b]) < 2e-5 * max(scale, 1.0)
