@@ -294,13 +294,14 @@ struct StageMap {
   int64_t a_row2;                             // element offset of the second row (0 when clamped onto the same row)
   int a_dst0, a_dst1;                         // uint2 index into a plane image [128][4]
   int taps0, taps1;                           // conv mode: 9-bit masks of the taps that fall inside the image, rows 0 / 1
+  int w_second;                               // 512-thread tiles: offset of this thread's second W piece relative to w_src
 };
 // lda = row stride of A in floats (K for a Linear, C for the conv's NHWC activations)
-template <bool CONV>
+template <bool CONV, int BMT = 128>
 __device__ __forceinline__ StageMap make_stage_map(const float* A, const u32x4_t* Wp, int t, int m0, int nt, int M, int K, int lda,
                                                    const ConvGeom& g) {
   StageMap m;
-  const int c = t & 3, r0 = t >> 2, r1 = r0 + 64;
+  const int c = t & 3, r0 = t >> 2, r1 = r0 + BMT / 2;           // 2 BMT threads x 2 rows x 4 chunks = BMT rows x 16 floats
   int g0 = m0 + r0, g1 = m0 + r1;
   g0 = g0 < M ? g0 : M - 1;
   g1 = g1 < M ? g1 : M - 1;
@@ -310,6 +311,7 @@ __device__ __forceinline__ StageMap make_stage_map(const float* A, const u32x4_t
   m.a_dst0 = r0 * 4 + (((c >> 1) ^ ((r0 >> 3) & 1)) << 1) + (c & 1);
   m.a_dst1 = r1 * 4 + (((c >> 1) ^ ((r1 >> 3) & 1)) << 1) + (c & 1);
   m.taps0 = m.taps1 = 0x1ff;
+  m.w_second = 512 + (t & 255) - t;
   if (CONV) {
     const int p0 = g0 % (g.H * g.W), p1 = g1 % (g.H * g.W);
     const int y0 = p0 / g.W, x0 = p0 - y0 * g.W, y1 = p1 / g.W, x1 = p1 - y1 * g.W;
@@ -323,7 +325,7 @@ __device__ __forceinline__ StageMap make_stage_map(const float* A, const u32x4_t
   }
   return m;
 }
-template <bool CONV>
+template <bool CONV, int BMT = 128>
 __device__ __forceinline__ void stage_load(StageRegs& r, const StageMap& m, int s, const ConvGeom& g) {
   if (CONV) {
     const int tap = s / g.cpt, c0 = (s - tap * g.cpt) * 16;          // wave-uniform
@@ -342,10 +344,16 @@ __device__ __forceinline__ void stage_load(StageRegs& r, const StageMap& m, int 
   }
   const u32x4_t* wp = m.w_src + (int64_t)s * 768;
   r.w0 = wp[0];
-  r.w1 = wp[256];
-  r.w2 = wp[512];
+  if (BMT == 128) {                                               // 256 threads: three 16-byte pieces each
+    r.w1 = wp[256];
+    r.w2 = wp[512];
+  } else {                                                        // 512 threads: piece t and piece 512 + (t & 255) (loaded twice, stored once)
+    r.w1 = wp[m.w_second];
+    r.w2 = r.w1;
+  }
 }
-// As3 / Ws3: the three plane images of one stage buffer, [3][128][2] x 16 B each
+// As3 / Ws3: the three plane images of one stage buffer, [3][BMT][2] / [3][128][2] x 16 B each
+template <int BMT = 128>
 __device__ __forceinline__ void stage_store(const StageRegs& r, const StageMap& m, u32x4_t* As3, u32x4_t* Ws3, int t) {
   uint2 p0, p1, p2, q0, q1, q2;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -353,15 +361,20 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, const StageMap& 
   split4(make_float4(v0.x, v0.y, v0.z, v0.w), p0, p1, p2);
   split4(make_float4(v1.x, v1.y, v1.z, v1.w), q0, q1, q2);
   uint2* a2 = reinterpret_cast<uint2*>(As3);
+  constexpr int PL = BMT * 4;                                     // uint2 per A plane image
   a2[m.a_dst0] = p0;
-  a2[512 + m.a_dst0] = p1;
-  a2[1024 + m.a_dst0] = p2;
+  a2[PL + m.a_dst0] = p1;
+  a2[2 * PL + m.a_dst0] = p2;
   a2[m.a_dst1] = q0;
-  a2[512 + m.a_dst1] = q1;
-  a2[1024 + m.a_dst1] = q2;
+  a2[PL + m.a_dst1] = q1;
+  a2[2 * PL + m.a_dst1] = q2;
   Ws3[t] = r.w0;
-  Ws3[256 + t] = r.w1;
-  Ws3[512 + t] = r.w2;
+  if (BMT == 128) {
+    Ws3[256 + t] = r.w1;
+    Ws3[512 + t] = r.w2;
+  } else if (t < 256) {
+    Ws3[512 + t] = r.w1;
+  }
 }
 
 // ---- v3: three unpadded, swizzled LDS stage buffers (24 KB each) and ONE barrier per 16-wide k stage, placed mid-stage.
@@ -375,11 +388,11 @@ constexpr int STG = 3;
 // CONV: A is an NHWC activation tensor and the GEMM is the implicit 3 x 3 convolution described at ConvGeom (K = 9 C).
 // TRANS: the output is written transposed, out[(b, n, p)] for GEMM row m = b * ldo + p (NCHW from NHWC rows): the operand roles
 // are swapped in the MFMAs (weights on the accumulator-row side) so that a wave-store still covers 128 contiguous bytes.
-template <int ACT, bool CONV = false, bool TRANS = false>
-__global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+template <int ACT, bool CONV = false, bool TRANS = false, int BMT = 128>
+__global__ __launch_bounds__(2 * BMT) void split_linear_pipe_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                               const float* __restrict__ bias, float* __restrict__ C, int M, int N,
                                                               int K, int MT, int NT, ConvGeom geom, int ldo) {
-  __shared__ u32x4_t As[STG][3][BM][2];
+  __shared__ u32x4_t As[STG][3][BMT][2];
   __shared__ u32x4_t Ws[STG][3][BN][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -387,12 +400,12 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
   const int nb = MT * NT;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   const int mt = bid / NT, nt = bid - mt * NT;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * BMT, n0 = nt * BN;
 
-  const StageMap smap = make_stage_map<CONV>(A, Wp, tid, m0, nt, M, K, CONV ? geom.C : K, geom);
+  const StageMap smap = make_stage_map<CONV, BMT>(A, Wp, tid, m0, nt, M, K, CONV ? geom.C : K, geom);
   const int S = K / BK2, SL = S - 1;
-  auto gload = [&](StageRegs& r, int s) { stage_load<CONV>(r, smap, s < SL ? s : SL, geom); };
-  auto stash = [&](const StageRegs& r, int buf) { stage_store(r, smap, &As[buf][0][0][0], &Ws[buf][0][0][0], tid); };
+  auto gload = [&](StageRegs& r, int s) { stage_load<CONV, BMT>(r, smap, s < SL ? s : SL, geom); };
+  auto stash = [&](const StageRegs& r, int buf) { stage_store<BMT>(r, smap, &As[buf][0][0][0], &Ws[buf][0][0][0], tid); };
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(256) void split_linear_pipe_kernel(const float* __r
   if (TRANS)
     store_tile_transposed<ACT>(acc, bias, C, M, N, n0 + 64 * wm, m0 + 64 * wn, ldo, l31, lh);
   else
-    store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
+    store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BMT <= M && n0 + BN <= N, l31, lh);
 }
 
 
@@ -590,7 +603,17 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
   const bool short_k = forced ? forced == 1 : K <= 256;
 #define RBA_L(KERNEL, A) hipLaunchKernelGGL(KERNEL<A>, grid, block, 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
 #define RBA_LP(A) hipLaunchKernelGGL((split_linear_pipe_kernel<A, false, false>), grid, block, 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT, ConvGeom{0, 0, 0, 1}, 0)
-  if (forced == 4) {
+  // 256 x 128 tiles (8 waves, one workgroup per CU; RBA_GEMM_VARIANT=7) halve the W staging per MFMA.  Stand-alone they are up to
+  // 14 % faster where the 256-row tiles fill the CUs in whole rounds (8192 x 2048 x 512: 100 vs 117 us) and slower elsewhere; inside
+  // the network a shape rule that picks them made no difference (72.6 vs 73.1 images/s), so the 128-row tile stays the default.
+  if (forced == 7) {
+    const int64_t MT2 = (M + 255) / 256;
+    const dim3 grid2((unsigned)(MT2 * NT));
+    if (act == 1)
+      hipLaunchKernelGGL((split_linear_pipe_kernel<1, false, false, 256>), grid2, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT2, NT, ConvGeom{0, 0, 0, 1}, 0);
+    else
+      hipLaunchKernelGGL((split_linear_pipe_kernel<0, false, false, 256>), grid2, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT2, NT, ConvGeom{0, 0, 0, 1}, 0);
+  } else if (forced == 4) {
 #define RBA_L8(A) hipLaunchKernelGGL((split_linear_ws_kernel<A>), grid, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
     if (act == 1) RBA_L8(1); else RBA_L8(0);
 #undef RBA_L8
