@@ -135,7 +135,7 @@ int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias
  *                          three bf16 planes tiled as the kernel's LDS image, [Np/128][K/16][3][128][2][8] bf16 with the
  *                          8-element half h of row r in slot h ^ ((r >> 3) & 1).  Once per weight load.  K % 32 == 0.
  * rba_split_linear_f32:    out[m,n] = act(sum_k x[m,k] * weight[n,k] + bias[n]); x [M,K] fp32, `weight_packed` from
- *                          rba_split_weight_bf16x3 for the same (N, K), bias [N] or NULL; act 0 = none, 1 = exact (erf) GELU. */
+ *                          rba_split_weight_bf16x3 for the same (N, K), bias [N] or NULL; act 0 = none, 1 = exact (erf) GELU, 2 = ReLU. */
 int rba_split_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream);
 int rba_split_linear_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
                          int act, void* stream);

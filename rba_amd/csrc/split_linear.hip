@@ -92,6 +92,7 @@ __device__ __forceinline__ void store_tile(const f32x16_t (&acc)[2][2], const fl
       for (int r = 0; r < 16; ++r) {
         v[r] += bv;
         if (ACT == 1) v[r] = gelu_erf(v[r]);
+        if (ACT == 2) v[r] = fmaxf(v[r], 0.f);
       }
       const int rbase = row0 + 32 * i + 4 * lh;
       float* dst = C + (int64_t)rbase * N + col;
@@ -129,6 +130,7 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16_t (&acc)[2][2
         const int n = nbase + 8 * (r >> 2) + (r & 3);
         v[r] += (bias && n < N) ? bias[n] : 0.f;
         if (ACT == 1) v[r] = gelu_erf(v[r]);
+        if (ACT == 2) v[r] = fmaxf(v[r], 0.f);
       }
       if (m < M) {
         if (nrow0 + 64 <= N) {                                     // wave-uniform: branch-free stores (see store_tile)
@@ -166,7 +168,7 @@ __global__ void split_weight_kernel(const float* __restrict__ w, u32x4_t* __rest
   }
 }
 
-// act: 0 none, 1 exact GELU (0.5 x (1 + erf(x / sqrt 2)), nn.GELU default, swin.py:51)
+// act: 0 none, 1 exact GELU (0.5 x (1 + erf(x / sqrt 2)), nn.GELU default, swin.py:51), 2 ReLU
 template <int ACT>
 __global__ __launch_bounds__(256) void split_linear_short_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                            const float* __restrict__ bias, float* __restrict__ C, int M, int N,
@@ -589,7 +591,7 @@ extern "C" int rba_split_weight_bf16x3(const float* weight, void* packed, int N,
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {
-  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= BK && (K % BK) == 0 && (act == 0 || act == 1));
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= BK && (K % BK) == 0 && act >= 0 && act <= 2);
   if (M == 0) return 0;
   RBA_CHECK_ARG(x && weight_planes && out);
   RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_planes | (uintptr_t)out) & 15) == 0);
@@ -611,16 +613,18 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
     const dim3 grid2((unsigned)(MT2 * NT));
     if (act == 1)
       hipLaunchKernelGGL((split_linear_pipe_kernel<1, false, false, 256>), grid2, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT2, NT, ConvGeom{0, 0, 0, 1}, 0);
+    else if (act == 2)
+      hipLaunchKernelGGL((split_linear_pipe_kernel<2, false, false, 256>), grid2, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT2, NT, ConvGeom{0, 0, 0, 1}, 0);
     else
       hipLaunchKernelGGL((split_linear_pipe_kernel<0, false, false, 256>), grid2, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT2, NT, ConvGeom{0, 0, 0, 1}, 0);
   } else if (forced == 4) {
 #define RBA_L8(A) hipLaunchKernelGGL((split_linear_ws_kernel<A>), grid, dim3(512), 0, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT)
-    if (act == 1) RBA_L8(1); else RBA_L8(0);
+    if (act == 1) RBA_L8(1); else if (act == 2) RBA_L8(2); else RBA_L8(0);
 #undef RBA_L8
   } else if (short_k) {
-    if (act == 1) RBA_L(split_linear_short_kernel, 1); else RBA_L(split_linear_short_kernel, 0);
+    if (act == 1) RBA_L(split_linear_short_kernel, 1); else if (act == 2) RBA_L(split_linear_short_kernel, 2); else RBA_L(split_linear_short_kernel, 0);
   } else {
-    if (act == 1) RBA_LP(1); else RBA_LP(0);
+    if (act == 1) RBA_LP(1); else if (act == 2) RBA_LP(2); else RBA_LP(0);
   }
 #undef RBA_L
 #undef RBA_LP

@@ -50,7 +50,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         """msdeformattn.py:131-140 (dropout = identity)."""
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index)
         _, src = ops.add_layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps, src2.contiguous())
-        src2 = F.linear(F.relu(self.linear1(src)), self.linear2.weight)
+        src2 = ops.linear(ops.linear(src, self.linear1, relu=True), self.linear2, use_bias=False)   # bf16x6 (K6) when the level set is large
         return ops.add_layer_norm(src, self.norm2.weight, self.norm2.bias, self.norm2.eps, src2, self.linear2.bias)[1]
 
 

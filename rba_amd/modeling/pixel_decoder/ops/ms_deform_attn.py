@@ -38,11 +38,11 @@ class MSDeformAttn(nn.Module):
         N, Lq, _ = query.shape
         S = input_flatten.shape[1]
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(input_flatten)
+        value = ops.linear(input_flatten, self.value_proj)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
+        offsets = ops.linear(query, self.sampling_offsets).view(N, Lq, M, L, P, 2)
         weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
         if reference_points.shape[-1] != 2:
             raise ValueError(f"Last dim of reference_points must be 2 on this path, got {reference_points.shape[-1]}")
@@ -50,4 +50,4 @@ class MSDeformAttn(nn.Module):
         loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
         out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                          loc.contiguous(), weights.contiguous(), self.im2col_step)
-        return self.output_proj(out)
+        return ops.linear(out, self.output_proj)

@@ -318,8 +318,8 @@ def split_linear_pays(M, N, K, gelu=False):
     return tiles >= 256
 
 
-def linear(x, lin, use_bias=True, gelu=False):
-    """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU] for an ``nn.Linear`` on a token tensor, through the bf16x6
+def linear(x, lin, use_bias=True, gelu=False, relu=False):
+    """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the bf16x6
     kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise."""
     w = lin.weight
     N, K = w.shape
@@ -331,12 +331,12 @@ def linear(x, lin, use_bias=True, gelu=False):
         if cache is None or cache[0] != key:
             cache = (key, split_weight(w.detach().contiguous()))
             lin._rba_planes = cache
-        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu, out_features=N)
+        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu, out_features=N, relu=relu)
     y = torch.nn.functional.linear(x, w, bias)
-    return torch.nn.functional.gelu(y) if gelu else y
+    return torch.nn.functional.gelu(y) if gelu else (torch.relu(y) if relu else y)
 
 
-def split_linear(x, planes, bias=None, gelu=False, out_features=None):
+def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False):
     """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe.
     ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
     lib = _lib.load()
@@ -353,7 +353,7 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None):
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
     out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.rba_split_linear_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, int(bool(gelu)), _stream()),
+    _lib.check(lib.rba_split_linear_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, 1 if gelu else (2 if relu else 0), _stream()),
                "rba_split_linear_f32")
     return out
 

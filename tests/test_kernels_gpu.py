@@ -359,6 +359,17 @@ def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias):
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
 
 
+def test_split_linear_relu_epilogue(ops):
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in ((1000, 1024, 256), (300, 256, 1024)):
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+        out = ops.split_linear(dev(x), ops.split_weight(dev(w)), dev(b), relu=True)
+        assert maxerr(out, F.relu(F.linear(x.double(), w.double(), b.double()))) < 2e-5 * (K / 256) ** 0.5 + 2e-6 and float(out.min()) >= 0.0
+        lin = torch.nn.Linear(K, N).cuda()
+        xx = torch.randn(40000, K, device="cuda")
+        assert maxerr(ops.linear(xx, lin, relu=True), F.relu(F.linear(xx.double(), lin.weight.double(), lin.bias.double()))) < 3e-5
+
+
 def test_split_linear_extreme_values(ops):
     """Exactness of the split over the exponent range, zeros, and values whose low planes vanish."""
     g = torch.Generator().manual_seed(5)
