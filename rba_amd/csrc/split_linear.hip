@@ -475,6 +475,131 @@ __global__ __launch_bounds__(2 * BMT) void split_linear_pipe_kernel(const float*
 }
 
 
+// ---- LDS-DMA variant (RBA_GEMM_VARIANT=8): the packed W tile of a stage is already the LDS image, so it is moved by
+// global_load_lds_dwordx4 (three 1-KiB pieces per wave, no VGPRs, no ds_write); only the activations go through registers for
+// the split.  With an LDS-DMA in flight hipcc would drain vmcnt(0) at every use of an ordinary global load and at
+// __syncthreads(), so the A loads are inline asm and the VM counter is managed by hand.  Per thread and stage the VMEM issue order
+// is [W(s+2) x3 DMA, A(s+4) x2]: A(s+2) has landed when at most 8 newer operations are outstanding (vmcnt(8), head of the stage),
+// W(s+1) when at most 7 are (vmcnt(7), before the stage's barrier; stage s+1 is first read after that barrier).
+extern __shared__ __attribute__((aligned(16))) u32x4_t lds_main[];
+extern __shared__ __attribute__((aligned(16))) u32x4_t lds_alias[];
+
+template <int ACT>
+__global__ __launch_bounds__(256) void split_linear_dma_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+                                                             const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                             int K, int MT, int NT) {
+  // One dynamic LDS block seen through two symbols: HIP places every `extern __shared__` array at the same base, and the
+  // compiler treats them as distinct objects.  The DMA writes through `lds_dma`, everything else goes through `lds`; otherwise
+  // hipcc orders every LDS read behind the pending LDS-DMAs with s_waitcnt vmcnt(0) and the prefetch collapses.  The ordering
+  // that IS needed (W of stage s+1 landed before the barrier that precedes its first read) is the counted vmcnt(7) below.
+  u32x4_t(*As)[3][BM][2] = reinterpret_cast<u32x4_t(*)[3][BM][2]>(lds_main);
+  u32x4_t(*Ws)[3][BN][2] = reinterpret_cast<u32x4_t(*)[3][BN][2]>(lds_main + STG * 3 * BM * 2);
+  u32x4_t* Wdma = lds_alias + STG * 3 * BM * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int nb = MT * NT;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+  const int mt = bid / NT, nt = bid - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const ConvGeom nogeom = {0, 0, 0, 1};
+  const StageMap smap = make_stage_map<false>(A, Wp, tid, m0, nt, M, K, K, nogeom);
+  const int S = K / BK2, SL = S - 1;
+
+  struct ARegs { f32x4 a0, a1; };
+  auto aload = [&](ARegs& r, int s) {
+    const float* ap = smap.a_src + (s < SL ? s : SL) * 16;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a0) : "v"(ap) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a1) : "v"(ap + smap.a_row2) : "memory");
+  };
+  auto wdma = [&](int s, int buf) {                               // W tile of stage s -> Ws[buf]: lane's piece index = tid
+    const u32x4_t* wp = smap.w_src + (int64_t)(s < SL ? s : SL) * 768;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + 256 * p),
+                                       (__attribute__((address_space(3))) void*)(Wdma + (buf * 3 + p) * (BN * 2) + wave * 64), 16, 0, 0);
+  };
+  // the A-plane stores are inline asm as well: hipcc puts s_waitcnt vmcnt(0) in front of every LDS store it can see while an
+  // LDS-DMA is pending (write-after-write ordering it cannot disprove)
+  const uint32_t as_base = (uint32_t)(uintptr_t)(&As[0][0][0][0]);
+  const uint32_t ad0 = as_base + smap.a_dst0 * 8, ad1 = as_base + smap.a_dst1 * 8;
+  auto astash = [&](const ARegs& r, int buf) {
+    uint2 p0, p1, p2, q0, q1, q2;
+    split4(make_float4(r.a0.x, r.a0.y, r.a0.z, r.a0.w), p0, p1, p2);
+    split4(make_float4(r.a1.x, r.a1.y, r.a1.z, r.a1.w), q0, q1, q2);
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const uint32_t o = buf * (3 * BM * 2 * 16);
+    const u2 P0 = {p0.x, p0.y}, P1 = {p1.x, p1.y}, P2 = {p2.x, p2.y}, Q0 = {q0.x, q0.y}, Q1 = {q1.x, q1.y}, Q2 = {q2.x, q2.y};
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:4096\n\tds_write_b64 %0, %3 offset:8192"
+                 :: "v"(ad0 + o), "v"(P0), "v"(P1), "v"(P2) : "memory");
+    asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:4096\n\tds_write_b64 %0, %3 offset:8192"
+                 :: "v"(ad1 + o), "v"(Q0), "v"(Q1), "v"(Q2) : "memory");
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int fa_row = 64 * wm + l31, fb_row = 64 * wn + l31;
+  const int fa_slot = lh ^ ((fa_row >> 3) & 1), fb_slot = lh ^ ((fb_row >> 3) & 1);
+  bf16x8_t a[2][3], b[2][3], na[2], nb0[2];
+  auto rd_a = [&](int buf, int t, int p) { return __builtin_bit_cast(bf16x8_t, As[buf][p][fa_row + 32 * t][fa_slot]); };
+  auto rd_b = [&](int buf, int t, int p) { return __builtin_bit_cast(bf16x8_t, Ws[buf][p][fb_row + 32 * t][fb_slot]); };
+#define RBA_G(pa, pb)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)           \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+
+  ARegs ax, ay;
+  aload(ax, 0);
+  aload(ay, 1);
+  wdma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax.a0), "+v"(ax.a1), "+v"(ay.a0), "+v"(ay.a1)::"memory");
+  astash(ax, 0);
+  astash(ay, 1);
+  // establish the steady-state queue [A(2) x2, W(1) x3, A(3) x2] the counted waits of stage 0 assume
+  aload(ax, 2);
+  wdma(1, 1);
+  aload(ay, 3);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { a[t][0] = rd_a(0, t, 0); b[t][0] = rd_b(0, t, 0); }
+
+  int cur = 0;
+  // at the head of stage s the outstanding VMEM operations are, oldest first: [A(s+2) x2] (set SET), W(s+1) x3, A(s+3) x2
+#define RBA_STAGE(SET, s)                                                            \
+  {                                                                                  \
+    const int nxt = cur == 2 ? 0 : cur + 1, wr = nxt == 2 ? 0 : nxt + 1;             \
+    wdma((s) + 2, wr);                                                               \
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(SET.a0), "+v"(SET.a1)::"memory");       \
+    astash(SET, wr);                                                                 \
+    aload(SET, (s) + 4);                                                             \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                  \
+      a[t][1] = rd_a(cur, t, 1); b[t][1] = rd_b(cur, t, 1);                          \
+      a[t][2] = rd_a(cur, t, 2); b[t][2] = rd_b(cur, t, 2);                          \
+    }                                                                                \
+    RBA_G(0, 0) RBA_G(0, 1) RBA_G(1, 0)                                              \
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");         \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) { na[t] = rd_a(nxt, t, 0); nb0[t] = rd_b(nxt, t, 0); } \
+    RBA_G(1, 1) RBA_G(0, 2) RBA_G(2, 0)                                              \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) { a[t][0] = na[t]; b[t][0] = nb0[t]; } \
+    cur = nxt;                                                                       \
+  }
+  int s = 0;
+  for (; s + 2 <= S; s += 2) {
+    RBA_STAGE(ax, s)
+    RBA_STAGE(ay, s + 1)
+  }
+  if (s < S) RBA_STAGE(ax, s)
+#undef RBA_STAGE
+#undef RBA_G
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // drain the clamped surplus loads / DMAs before the epilogue
+  store_tile<ACT>(acc, bias, C, M, N, m0 + 64 * wm, n0 + 64 * wn, m0 + BM <= M && n0 + BN <= N, l31, lh);
+}
+
 // ---- wave-specialised variant: 8 waves per workgroup.  Waves 0-3 (one per SIMD) only read operand fragments and issue
 // MFMAs; waves 4-7 (their SIMD partners) only stage: global loads two stages ahead, the bf16 split, LDS stores.  A wave issues
 // in order, so in the 4-wave kernels every staging instruction sits between two MFMAs of the same wave (counters: LDS stores
@@ -608,7 +733,17 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
   // 256 x 128 tiles (8 waves, one workgroup per CU; RBA_GEMM_VARIANT=7) halve the W staging per MFMA.  Stand-alone they are up to
   // 14 % faster where the 256-row tiles fill the CUs in whole rounds (8192 x 2048 x 512: 100 vs 117 us) and slower elsewhere; inside
   // the network a shape rule that picks them made no difference (72.6 vs 73.1 images/s), so the 128-row tile stays the default.
-  if (forced == 7) {
+  if (forced == 8) {
+    constexpr size_t dyn = (size_t)STG * 3 * (BM + BN) * 2 * sizeof(u32x4_t);
+#define RBA_LD(A)                                                                                                                    \
+  {                                                                                                                                  \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)split_linear_dma_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+    (void)attr;                                                                                                                      \
+    hipLaunchKernelGGL(split_linear_dma_kernel<A>, grid, block, dyn, (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT); \
+  }
+    if (act == 1) RBA_LD(1) else if (act == 2) RBA_LD(2) else RBA_LD(0)
+#undef RBA_LD
+  } else if (forced == 7) {
     const int64_t MT2 = (M + 255) / 256;
     const dim3 grid2((unsigned)(MT2 * NT));
     if (act == 1)
