@@ -27,6 +27,7 @@
  *                                  (mask2former_transformer_decoder.py:25-212)
  *   rba_split_linear_f32        <- nn.Linear on the backbone's token tensors: qkv / proj / Mlp.fc1(+GELU) / Mlp.fc2 /
  *                                  PatchMerging.reduction (backbone/swin.py:44-71, 131-171, 319-343)
+ *   rba_gaussian_blur_f32       <- transforms.GaussianBlur(7, sigma=1) on the anomaly map (support.py:366-383)
  *   rba_add_layer_norm_f32      <- `x = x + proj(...)` followed by nn.LayerNorm (swin.py:284-293 and the post-norm layers
  *                                  of msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58,106-118,171-175)
  *   rba_group_norm_f32          <- GroupNorm(32) [+ ReLU] behind Detectron2's Conv2d(norm=get_norm("GN"), activation)
@@ -151,6 +152,11 @@ int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, con
  * (the FPN output convolutions `layer_{j}` of pixel_decoder/msdeformattn.py:278-297, 357-360) */
 int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W, int C,
                          int N, void* stream);
+
+/* Gaussian smoothing of the score map (the evaluator's optional transforms.GaussianBlur(7, sigma=1), support.py:366-383):
+ * out[H,W] = correlation of in[H,W] (reflect-padded by kernel_size/2) with the normalised outer-product kernel of
+ * exp(-0.5 (x/sigma)^2), x = -(k-1)/2 .. (k-1)/2.  kernel_size odd, <= 15; in != out. */
+int rba_gaussian_blur_f32(const float* in, float* out, int H, int W, int kernel_size, float sigma, void* stream);
 
 #ifdef __cplusplus
 }

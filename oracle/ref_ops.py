@@ -212,3 +212,20 @@ def attn_mask_from_logits(mask_logits):
     blocked = mask_logits.sigmoid() < 0.5
     blocked[torch.where(blocked.sum(-1) == blocked.shape[-1])] = False
     return blocked
+
+
+def gaussian_blur(score: torch.Tensor, kernel_size: int = 7, sigma: float = 1.0) -> torch.Tensor:
+    """Optional smoothing of the anomaly map, ``transforms.GaussianBlur(7, sigma=1)`` at support.py:366-383.
+    PARITY UNPINNED: the algorithm lives in torchvision (a dependency of the reference that is not installed here), so this
+    restates its published definition -- 1-D kernel ``exp(-0.5 (x / sigma)^2)`` on ``linspace(-(k-1)/2, (k-1)/2, k)``
+    normalised to sum 1, 2-D kernel = outer product, reflect padding by k // 2, depthwise conv2d
+    (torchvision/transforms/_functional_tensor.py: ``_get_gaussian_kernel1d/2d``, ``gaussian_blur``) -- and is cross-checked
+    against ``scipy.ndimage.gaussian_filter(mode="mirror", truncate=3)`` in tests/test_oracle_golden.py.  score [H,W] -> [H,W]."""
+    half = (kernel_size - 1) * 0.5
+    x = torch.linspace(-half, half, steps=kernel_size, dtype=score.dtype)
+    pdf = torch.exp(-0.5 * (x / sigma) ** 2)
+    k1 = pdf / pdf.sum()
+    k2 = torch.mm(k1[:, None], k1[None, :])
+    p = kernel_size // 2
+    img = F.pad(score[None, None], (p, p, p, p), mode="reflect")
+    return F.conv2d(img, k2[None, None].to(score.dtype))[0, 0]

@@ -442,3 +442,15 @@ def resample_bilinear_nhwc(x, size, add=None):
     _lib.check(lib.rba_resample_bilinear_nhwc_f32(_p(x), _p(add), _p(out), C, h, w, H, W, _stream()),
                "rba_resample_bilinear_nhwc_f32")
     return out
+
+
+def gaussian_blur(score, kernel_size=7, sigma=1.0):
+    """transforms.GaussianBlur(kernel_size, sigma) of a score map [H,W] (reflect padding): the evaluator's optional smoothing."""
+    lib = _lib.load()
+    _chk(score, "score", dim=2)
+    H, W = score.shape
+    if kernel_size % 2 == 0 or not (1 <= kernel_size <= 15) or sigma <= 0 or (H and W and (H <= kernel_size // 2 or W <= kernel_size // 2)):
+        raise RbaHipError("gaussian_blur needs an odd kernel_size <= 15, sigma > 0 and a map larger than the padding")
+    out = torch.empty_like(score)
+    _lib.check(lib.rba_gaussian_blur_f32(_p(score), _p(out), H, W, int(kernel_size), float(sigma), _stream()), "rba_gaussian_blur_f32")
+    return out

@@ -6,6 +6,7 @@ from typing import Callable
 import numpy as np
 import torch
 
+from . import ops
 from .metrics import ood_metrics, select_labelled
 
 
@@ -45,8 +46,6 @@ class OODEvaluator:
     def compute_anomaly_scores(self, loader, device=torch.device("cpu"), return_preds=False,
                                use_gaussian_smoothing=False, upper_limit=450):
         """Batch-1 scoring loop (support.py:353-399).  Returns numpy arrays like the reference."""
-        if use_gaussian_smoothing:
-            raise NotImplementedError("gaussian smoothing of the score map is outside the RbA hot path")
         anomaly_score, ood_gts, predictions = [], [], []
         for jj, (x, y) in enumerate(loader):
             if jj >= upper_limit:
@@ -62,6 +61,8 @@ class OODEvaluator:
                 if return_preds:
                     logits = self.get_logits(x)
                     predictions.append(logits[:, :19].max(dim=1)[1].cpu().numpy())
+            if use_gaussian_smoothing:                                  # transforms.GaussianBlur(7, sigma=1), support.py:366-383
+                score = ops.gaussian_blur(score.contiguous(), 7, 1.0)
             anomaly_score.append(score.cpu().numpy())
         ood_gts, anomaly_score = np.array(ood_gts), np.array(anomaly_score)
         if return_preds:

@@ -470,3 +470,18 @@ def test_resample_bilinear_nhwc(ops, h, w, H, W, C, has_add):
     nchw = ops.resample_bilinear(dev(x.permute(2, 0, 1).contiguous()), (H, W),
                                  add=dev(add.permute(2, 0, 1).contiguous()) if has_add else None)
     assert maxerr(out, nchw.permute(1, 2, 0).double()) < 2e-6      # same taps and weights (fma contraction may differ)
+
+
+# ----------------------------------------------------------------------------------- gaussian smoothing of the score map
+@pytest.mark.parametrize("H,W,k,sigma", [(1024, 2048, 7, 1.0), (60, 90, 7, 1.0), (33, 70, 5, 0.8), (4, 5, 7, 1.0), (129, 65, 15, 2.5)])
+def test_gaussian_blur_vs_oracle(ops, H, W, k, sigma):
+    from oracle import ref_ops
+    from rba_amd._lib import RbaHipError
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(H, W, generator=g) * 3.0
+    out = ops.gaussian_blur(dev(x), k, sigma)
+    assert out.shape == (H, W) and maxerr(out, ref_ops.gaussian_blur(x.double(), k, sigma)) < 5e-6
+    with pytest.raises(RbaHipError):
+        ops.gaussian_blur(dev(x), 6, 1.0)
+    with pytest.raises(RbaHipError):
+        ops.gaussian_blur(dev(x[:3, :3]), 7, 1.0)                                  # reflect padding needs pad < size

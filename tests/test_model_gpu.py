@@ -89,6 +89,11 @@ def test_evaluator_surface_tiny(golden, tmp_path):
     from oracle import ref_metrics
     want = ref_metrics.evaluate_ood(scores, gts)
     assert all(abs(r[k] - want[k]) < 1e-9 for k in want)
+    # optional smoothing of the score map (support.py:366-383): GaussianBlur(7, sigma=1) of the same scores
+    from oracle import ref_ops
+    smooth, _ = ev.compute_anomaly_scores([(x, gt)], device=torch.device("cuda"), use_gaussian_smoothing=True)
+    assert smooth.shape == (1, 60, 90)
+    assert maxerr(torch.as_tensor(smooth[0]), ref_ops.gaussian_blur(torch.as_tensor(scores[0]).double(), 7, 1.0)) < 1e-5
 
 
 def _full_size(golden, fixture, arch_name, tol_rba):

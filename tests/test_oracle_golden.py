@@ -174,3 +174,18 @@ def test_c1_plumbing_cpu_forward_256x512():
     assert o["sem_seg"].shape == (19, 256, 512) and o["rba"].shape == (256, 512) and o["argmax"].shape == (256, 512)
     assert torch.isfinite(o["rba"]).all() and float(o["rba"].max()) <= 0.0 and float(o["rba"].min()) > -19.0
     assert float(o["sem_seg"].min()) >= 0.0
+
+
+def test_gaussian_blur_oracle_vs_scipy():
+    """The oracle's restatement of torchvision's GaussianBlur(7, sigma=1) (torchvision is not installed: parity unpinned) against
+    an independent implementation of the same definition: scipy's gaussian_filter with mirror boundaries, radius 3."""
+    from scipy import ndimage
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(4)
+    for H, W in ((40, 64), (7, 9), (128, 33)):
+        x = torch.randn(H, W, generator=g, dtype=torch.float64)
+        want = ndimage.gaussian_filter(x.numpy(), sigma=1.0, mode="mirror", truncate=3.0)
+        got = ref_ops.gaussian_blur(x, 7, 1.0).numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-12
+    const = ref_ops.gaussian_blur(torch.full((16, 16), 2.5), 7, 1.0)
+    assert (const - 2.5).abs().max() < 1e-6                                                  # weights sum to one
