@@ -28,6 +28,8 @@
  *   rba_split_linear_f32        <- nn.Linear on the backbone's token tensors: qkv / proj / Mlp.fc1(+GELU) / Mlp.fc2 /
  *                                  PatchMerging.reduction (backbone/swin.py:44-71, 131-171, 319-343)
  *   rba_gaussian_blur_f32       <- transforms.GaussianBlur(7, sigma=1) on the anomaly map (support.py:366-383)
+ *   rba_threshold_u8 / rba_morph3x3_u8 / rba_ccl4_roots_i32 <- the open-set branch of MaskFormer.panoptic_inference
+ *                                  (maskformer_model.py:454-481: threshold, cv2.morphologyEx open/close, cv2.connectedComponents)
  *   rba_add_layer_norm_f32      <- `x = x + proj(...)` followed by nn.LayerNorm (swin.py:284-293 and the post-norm layers
  *                                  of msdeformattn.py:134-138, mask2former_transformer_decoder.py:48-58,106-118,171-175)
  *   rba_group_norm_f32          <- GroupNorm(32) [+ ReLU] behind Detectron2's Conv2d(norm=get_norm("GN"), activation)
@@ -157,6 +159,16 @@ int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float*
  * out[H,W] = correlation of in[H,W] (reflect-padded by kernel_size/2) with the normalised outer-product kernel of
  * exp(-0.5 (x/sigma)^2), x = -(k-1)/2 .. (k-1)/2.  kernel_size odd, <= 15; in != out. */
 int rba_gaussian_blur_f32(const float* in, float* out, int H, int W, int kernel_size, float sigma, void* stream);
+
+/* Open-set panoptic epilogue of the RbA map (MaskFormer.panoptic_inference, maskformer_model.py:454-481):
+ * rba_threshold_u8:   out[i] = score[i] > threshold
+ * rba_morph3x3_u8:    3x3 box erosion (dilate = 0) or dilation (dilate = 1) of a 0/1 map, out-of-image neighbours ignored
+ *                     (cv2.morphologyEx's default border); opening = erode, dilate; closing = dilate, erode.  in != out.
+ * rba_ccl4_roots_i32: 4-connected components: roots[p] = smallest linear index of p's component, -1 on background
+ *                     (numbering the distinct roots in increasing order gives cv2.connectedComponents' raster-order labels). */
+int rba_threshold_u8(const float* score, uint8_t* out, int64_t n, float threshold, void* stream);
+int rba_morph3x3_u8(const uint8_t* in, uint8_t* out, int H, int W, int dilate, void* stream);
+int rba_ccl4_roots_i32(const uint8_t* mask, int32_t* roots, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -229,3 +229,92 @@ def gaussian_blur(score: torch.Tensor, kernel_size: int = 7, sigma: float = 1.0)
     p = kernel_size // 2
     img = F.pad(score[None, None], (p, p, p, p), mode="reflect")
     return F.conv2d(img, k2[None, None].to(score.dtype))[0, 0]
+
+
+def ood_components(score, threshold):
+    """The open-set branch of MaskFormer.panoptic_inference (maskformer_model.py:454-474) on a score map [H,W]:
+    ``binary = score > threshold`` -> cv2.morphologyEx(MORPH_OPEN, 3x3 ones) -> cv2.morphologyEx(MORPH_CLOSE, 3x3 ones) ->
+    cv2.connectedComponents(connectivity=4).  PARITY UNPINNED: OpenCV is a dependency of the reference that is not installed here;
+    this restates its documented semantics in plain numpy -- erosion / dilation with a 3x3 box and the default border
+    (the operation's neutral value: out-of-image neighbours never veto an erosion nor trigger a dilation), labels numbered in raster
+    order of each component's first pixel -- and is cross-checked against scipy.ndimage in tests/test_oracle_golden.py.
+    Returns (labels int32 [H,W], 0 = background, 1..n, n)."""
+    import numpy as np
+    b = (np.asarray(score) > threshold)
+    H, W = b.shape
+
+    def morph(m, dilate):
+        pad = np.full((H + 2, W + 2), not dilate, dtype=bool)          # neutral border
+        pad[1:-1, 1:-1] = m
+        out = np.full((H, W), not dilate, dtype=bool)
+        for dy in range(3):
+            for dx in range(3):
+                win = pad[dy:dy + H, dx:dx + W]
+                out = (out | win) if dilate else (out & win)
+        return out
+
+    b = morph(morph(b, False), True)                                   # opening
+    b = morph(morph(b, True), False)                                   # closing
+    labels = np.zeros((H, W), dtype=np.int32)
+    n = 0
+    for y in range(H):                                                 # flood fill in raster order (small maps only)
+        for x in range(W):
+            if b[y, x] and labels[y, x] == 0:
+                n += 1
+                stack = [(y, x)]
+                labels[y, x] = n
+                while stack:
+                    cy, cx = stack.pop()
+                    for ny, nx in ((cy - 1, cx), (cy + 1, cx), (cy, cx - 1), (cy, cx + 1)):
+                        if 0 <= ny < H and 0 <= nx < W and b[ny, nx] and labels[ny, nx] == 0:
+                            labels[ny, nx] = n
+                            stack.append((ny, nx))
+    return labels, n
+
+
+def panoptic_inference(mask_cls, mask_pred, thing_classes, object_mask_threshold, overlap_threshold, open_panoptic=False,
+                       ood_threshold=-0.1, pixel_min=300):
+    """MaskFormer.panoptic_inference (maskformer_model.py:394-486) restated for CPU tensors: mask_cls [Q,K+1] logits,
+    mask_pred [Q,H,W] logits -> (panoptic_seg int32 [H,W] numpy, segments_info, rba map).  The open-set branch goes through
+    ``ood_components`` above (OpenCV semantics restated: parity unpinned for that step)."""
+    import numpy as np
+    K = mask_cls.shape[-1] - 1
+    prob = F.softmax(mask_cls.double(), dim=-1)
+    scores, labels = prob.max(-1)
+    mp = mask_pred.double().sigmoid()
+    keep = labels.ne(K) & (scores > object_mask_threshold)
+    H, W = mask_pred.shape[-2:]
+    pan = np.zeros((H, W), dtype=np.int32)
+    info = []
+    sem = torch.einsum("qc,qhw->chw", prob[:, :-1], mp)
+    rba = -(sem.tanh()).sum(0)
+    if int(keep.sum()) == 0:
+        return pan, info, rba
+    cs, cc, cm = scores[keep], labels[keep], mp[keep]
+    ids = (cs.view(-1, 1, 1) * cm).argmax(0).numpy()
+    cur, stuff = 0, {}
+    for k in range(cc.shape[0]):
+        cls = int(cc[k])
+        won, solid = ids == k, cm[k].numpy() >= 0.5
+        m = won & solid
+        if won.sum() > 0 and solid.sum() > 0 and m.sum() > 0:
+            if won.sum() / solid.sum() < overlap_threshold:
+                continue
+            if cls not in thing_classes:
+                if cls in stuff:
+                    pan[m] = stuff[cls]
+                    continue
+                stuff[cls] = cur + 1
+            cur += 1
+            pan[m] = cur
+            info.append({"id": cur, "isthing": cls in thing_classes, "category_id": cls})
+    if open_panoptic:
+        lab, n = ood_components(rba.numpy(), ood_threshold)
+        for i in range(1, n + 1):
+            m = (lab == i) & (pan == 0)
+            if m.sum() < pixel_min:
+                continue
+            cur += 1
+            pan[m] = cur
+            info.append({"id": cur, "isthing": True, "category_id": 255})
+    return pan, info, rba

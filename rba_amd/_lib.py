@@ -36,6 +36,9 @@ SIGNATURES = {
     "rba_group_norm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
     "rba_resample_bilinear_nhwc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_gaussian_blur_f32": [_vp, _vp, _i, _i, _i, ctypes.c_float, _vp],
+    "rba_threshold_u8": [_vp, _vp, _i64, ctypes.c_float, _vp],
+    "rba_morph3x3_u8": [_vp, _vp, _i, _i, _i, _vp],
+    "rba_ccl4_roots_i32": [_vp, _vp, _i, _i, _vp],
     "rba_add_layer_norm_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_float, _vp],
     "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],

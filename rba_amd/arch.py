@@ -33,7 +33,10 @@ ARCHS = {
 
 _DEFAULTS = dict(patch_size=4, mlp_ratio=4.0, enc_points=4, enc_dim_feedforward=1024,
                  pixel_mean=[123.675, 116.28, 103.53], pixel_std=[58.395, 57.12, 57.375],
-                 size_divisibility=32, common_stride=4)
+                 size_divisibility=32, common_stride=4,
+                 # panoptic inference (maskformer_model.py:202-220; config.py:57-59, 243)
+                 panoptic_on=False, open_panoptic=True, object_mask_threshold=0.0, overlap_threshold=0.0,
+                 thing_classes=[11, 12, 13, 14, 15, 16, 17, 18])   # Cityscapes train ids of the "thing" classes
 
 
 def complete(arch: dict) -> dict:
@@ -79,8 +82,8 @@ def arch_from_cfg(cfg) -> dict:
     if list(M.SEM_SEG_HEAD.IN_FEATURES) != list(FEATURE_NAMES):
         unsupported.append("SEM_SEG_HEAD.IN_FEATURES != res2..res5")
     T = M.MASK_FORMER.TEST
-    if not T.SEMANTIC_ON or T.INSTANCE_ON or T.PANOPTIC_ON:
-        unsupported.append("only TEST.SEMANTIC_ON inference is on the hot path")
+    if not T.SEMANTIC_ON or T.INSTANCE_ON:
+        unsupported.append("TEST.SEMANTIC_ON=False / TEST.INSTANCE_ON (only semantic and open-set panoptic inference are provided)")
     if cfg.get("SOLVER", {}).get("FORCE_REGION_PARTITION", False):
         unsupported.append("SOLVER.FORCE_REGION_PARTITION")
     if unsupported:
@@ -94,7 +97,9 @@ def arch_from_cfg(cfg) -> dict:
         dec_layers=M.MASK_FORMER.DEC_LAYERS - 1,
         enc_in=list(M.SEM_SEG_HEAD.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES),
         common_stride=M.SEM_SEG_HEAD.COMMON_STRIDE, size_divisibility=M.MASK_FORMER.SIZE_DIVISIBILITY,
-        pixel_mean=list(M.PIXEL_MEAN), pixel_std=list(M.PIXEL_STD)))
+        pixel_mean=list(M.PIXEL_MEAN), pixel_std=list(M.PIXEL_STD),
+        panoptic_on=bool(T.PANOPTIC_ON), open_panoptic=bool(M.MASK_FORMER.get("OPEN_PANOPTIC", True)),
+        object_mask_threshold=float(T.OBJECT_MASK_THRESHOLD), overlap_threshold=float(T.OVERLAP_THRESHOLD)))
 
 
 def num_fpn_levels(a: dict) -> int:

@@ -76,7 +76,9 @@ _DEFAULTS = {
                         "NUM_OBJECT_QUERIES": 100, "NHEADS": 8, "DROPOUT": 0.0, "DIM_FEEDFORWARD": 2048,
                         "DEC_LAYERS": 10, "PRE_NORM": False, "ENFORCE_INPUT_PROJ": False, "SIZE_DIVISIBILITY": 32,
                         "DENSE_HYBRID_LOSS": False,
+                        "OPEN_PANOPTIC": True,
                         "TEST": {"SEMANTIC_ON": True, "INSTANCE_ON": False, "PANOPTIC_ON": False,
+                                 "OBJECT_MASK_THRESHOLD": 0.0, "OVERLAP_THRESHOLD": 0.0,
                                  "SEM_SEG_POSTPROCESSING_BEFORE_INFERENCE": False}},
     },
     "SOLVER": {"FORCE_REGION_PARTITION": False},

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["rba_reduce.hip", "rba_reduce_tune.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn.hip", "mask_logits.hip",
-           "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "gaussian_blur.hip"]
+           "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "gaussian_blur.hip", "open_panoptic.hip"]
 HEADERS = ["common.h", "rba_reduce_kernels.h", os.path.join("..", "..", "include", "rba_hip.h")]
 LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")

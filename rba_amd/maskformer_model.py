@@ -29,6 +29,10 @@ class MaskFormer(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(a["pixel_mean"], dtype=torch.float32).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(a["pixel_std"], dtype=torch.float32).view(-1, 1, 1), False)
         self.fused_upsample = True      # K1 reads the low-res logits and up-samples on the fly (rba_reduce_up4)
+        # panoptic inference (maskformer_model.py:202-220): off unless TEST.PANOPTIC_ON
+        self.panoptic_on, self.open_panoptic = bool(a["panoptic_on"]), bool(a["open_panoptic"])
+        self.object_mask_threshold, self.overlap_threshold = float(a["object_mask_threshold"]), float(a["overlap_threshold"])
+        self.thing_classes = frozenset(int(c) for c in a["thing_classes"])
         self.eval()
 
     @property
@@ -72,11 +76,72 @@ class MaskFormer(nn.Module):
             arg = arg[:h, :w].contiguous() if arg is not None else None
         return rba, sem, arg
 
+    # ------------------------------------------------------------------ open-set panoptic inference (:394-486)
+    @torch.no_grad()
+    def panoptic_inference(self, mask_cls, mask_pred, open_panoptic=False, ood_threshold=-0.1, pixel_min=300,
+                           return_ood_pred=False):
+        """mask_cls [Q,K+1] logits, mask_pred [Q,H,W] logits at the output resolution ->
+        (panoptic_seg int32 [H,W], segments_info[, rba map]).  Closed-set part: the Mask2Former merge (:395-452) -- queries whose
+        best class is not void and scores above ``object_mask_threshold`` compete per pixel by score x sigmoid(mask); a query
+        keeps its pixels if enough of its own >= 0.5 area wins (``overlap_threshold``); "stuff" classes merge into one segment.
+        Open-set part (:454-481): the RbA map (K1) thresholded, 3x3 opened and closed, 4-connected components of at least
+        ``pixel_min`` still-unclaimed pixels become new "thing" segments of category 255."""
+        Q, H, W = mask_pred.shape
+        K = mask_cls.shape[-1] - 1
+        prob_all = F.softmax(mask_cls, dim=-1)
+        scores, labels = prob_all.max(-1)
+        keep = labels.ne(K) & (scores > self.object_mask_threshold)
+        panoptic_seg = torch.zeros((H, W), dtype=torch.int32, device=mask_pred.device)
+        segments_info = []
+        if not bool(keep.any()):
+            return panoptic_seg, segments_info                        # (the reference also skips the open-set part here, :414-416)
+        cur_scores, cur_classes = scores[keep], labels[keep]
+        cur_masks = mask_pred[keep].sigmoid()
+        cur_mask_ids = (cur_scores.view(-1, 1, 1) * cur_masks).argmax(0)
+        current = 0
+        stuff_ids = {}
+        for k in range(cur_classes.shape[0]):
+            cls = int(cur_classes[k])
+            won = cur_mask_ids == k
+            solid = cur_masks[k] >= 0.5
+            mask = won & solid
+            mask_area, original_area, inter = int(won.sum()), int(solid.sum()), int(mask.sum())
+            if mask_area == 0 or original_area == 0 or inter == 0 or mask_area / original_area < self.overlap_threshold:
+                continue
+            isthing = cls in self.thing_classes
+            if not isthing:
+                if cls in stuff_ids:
+                    panoptic_seg[mask] = stuff_ids[cls]
+                    continue
+                stuff_ids[cls] = current + 1
+            current += 1
+            panoptic_seg[mask] = current
+            segments_info.append({"id": current, "isthing": bool(isthing), "category_id": cls})
+        if not open_panoptic:
+            return panoptic_seg, segments_info
+        ood_mask = ops.rba_reduce(mask_pred.contiguous(), prob_all[:, :-1].contiguous())[0]      # -sum_k tanh(sem_k), K1
+        comp, n = ops.ood_components(ood_mask, ood_threshold)
+        if n:
+            free = panoptic_seg == 0
+            sizes = torch.bincount(comp[free].long(), minlength=n + 1)
+            ok = sizes >= pixel_min
+            ok[0] = False                                                                     # background
+            new_id = current + torch.cumsum(ok.to(torch.int32), 0, dtype=torch.int32)         # in component (= raster) order
+            sel = free & ok[comp.long()]
+            panoptic_seg[sel] = new_id[comp.long()][sel]
+            for _ in range(int(ok.sum())):
+                current += 1
+                segments_info.append({"id": current, "isthing": True, "category_id": 255})
+        if return_ood_pred:
+            return panoptic_seg, segments_info, ood_mask
+        return panoptic_seg, segments_info
+
     @torch.no_grad()
     def forward(self, batched_inputs, include_void=False, return_separately=False, return_aux=False,
-                return_ood_pred=False, return_argmax=False, **kwargs):
+                return_ood_pred=False, return_argmax=False, panoptic_ood_threshold=-0.3, panoptic_pixel_min=200,
+                return_panoptic_ood=False, **kwargs):
         if include_void or return_separately or return_aux or return_ood_pred or kwargs:
-            raise NotImplementedError("only the default semantic inference path of MaskFormer.forward is provided")
+            raise NotImplementedError("only the semantic and (open-set) panoptic inference paths of MaskFormer.forward are provided")
         mask_cls, mask_pred, sizes, padded = self.predict(batched_inputs)
         results = []
         for i, inp in enumerate(batched_inputs):
@@ -89,6 +154,12 @@ class MaskFormer(nn.Module):
             r = {"sem_seg": sem, "rba": rba}
             if return_argmax:
                 r["argmax"] = arg
+            if self.panoptic_on:                                   # :337-341; masks first brought to the output resolution (:318-321)
+                mp = ops.resample_bilinear(mask_pred[i].contiguous(), padded)[:, : sizes[i][0], : sizes[i][1]].contiguous()
+                if (height, width) != sizes[i]:
+                    mp = ops.resample_bilinear(mp, (height, width))
+                r["panoptic_seg"] = self.panoptic_inference(mask_cls[i], mp, self.open_panoptic, panoptic_ood_threshold,
+                                                            panoptic_pixel_min, return_panoptic_ood)
             results.append(r)
         return results
 

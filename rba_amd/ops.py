@@ -454,3 +454,26 @@ def gaussian_blur(score, kernel_size=7, sigma=1.0):
     out = torch.empty_like(score)
     _lib.check(lib.rba_gaussian_blur_f32(_p(score), _p(out), H, W, int(kernel_size), float(sigma), _stream()), "rba_gaussian_blur_f32")
     return out
+
+
+def ood_components(score, threshold, min_dummy=None):
+    """Open-set panoptic epilogue of a score map [H,W] (maskformer_model.py:454-474): binary = score > threshold, 3x3 opening
+    then closing, 4-connected components.  Returns (labels int32 [H,W] with 0 = background and components numbered 1..n in
+    raster order of their first pixel, n) like cv2.connectedComponents(connectivity=4) minus the background count."""
+    lib = _lib.load()
+    _chk(score, "score", dim=2)
+    H, W = score.shape
+    a = torch.empty((H, W), dtype=torch.uint8, device=score.device)
+    b = torch.empty_like(a)
+    st = _stream()
+    _lib.check(lib.rba_threshold_u8(_p(score), _p(a), H * W, float(threshold), st), "rba_threshold_u8")
+    for dilate, (src, dst) in ((0, (a, b)), (1, (b, a)), (1, (a, b)), (0, (b, a))):          # open, then close
+        _lib.check(lib.rba_morph3x3_u8(_p(src), _p(dst), H, W, dilate, st), "rba_morph3x3_u8")
+    roots = torch.empty((H, W), dtype=torch.int32, device=score.device)
+    _lib.check(lib.rba_ccl4_roots_i32(_p(a), _p(roots), H, W, st), "rba_ccl4_roots_i32")
+    flat = roots.view(-1)
+    is_root = flat == torch.arange(H * W, dtype=torch.int32, device=score.device)
+    rank = torch.cumsum(is_root.to(torch.int32), 0, dtype=torch.int32)                    # raster-order number of every root
+    labels = torch.where(flat >= 0, rank[flat.clamp_min(0).long()], torch.zeros_like(flat))
+    n = int(rank[-1].item()) if H * W else 0
+    return labels.view(H, W), n

@@ -485,3 +485,28 @@ def test_gaussian_blur_vs_oracle(ops, H, W, k, sigma):
         ops.gaussian_blur(dev(x), 6, 1.0)
     with pytest.raises(RbaHipError):
         ops.gaussian_blur(dev(x[:3, :3]), 7, 1.0)                                  # reflect padding needs pad < size
+
+
+# ----------------------------------------------------------------------------------- open-set panoptic epilogue
+@pytest.mark.parametrize("H,W,p,seed", [(64, 96, 0.5, 0), (200, 300, 0.4, 1), (33, 17, 0.7, 2), (512, 1024, 0.45, 3)])
+def test_ood_components_vs_oracle(ops, H, W, p, seed):
+    """threshold -> 3x3 open -> 3x3 close -> 4-connected components numbered in raster order, against the oracle (and so SciPy)."""
+    from scipy import ndimage
+    g = np.random.default_rng(seed)
+    score = ndimage.gaussian_filter(g.standard_normal((H, W)), 2.0).astype(np.float32) * 5
+    thr = float(np.quantile(score, 1 - p))
+    labels, n = ops.ood_components(dev(torch.from_numpy(score)), thr)
+    box = np.ones((3, 3), bool)
+    b = score > thr
+    opened = ndimage.binary_dilation(ndimage.binary_erosion(b, box, border_value=1), box, border_value=0)
+    closed = ndimage.binary_erosion(ndimage.binary_dilation(opened, box, border_value=0), box, border_value=1)
+    want, wn = ndimage.label(closed)
+    assert n == wn and labels.dtype == torch.int32 and np.array_equal(labels.cpu().numpy(), want)
+    if H * W <= 64 * 96:
+        from oracle import ref_ops
+        lab2, n2 = ref_ops.ood_components(score, thr)
+        assert n2 == n and np.array_equal(lab2, want)
+    empty, n0 = ops.ood_components(dev(torch.zeros(8, 8)), 1.0)
+    assert n0 == 0 and not empty.any()
+    full, n1 = ops.ood_components(dev(torch.ones(8, 8)), 0.0)
+    assert n1 == 1 and bool((full == 1).all())

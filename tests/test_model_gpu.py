@@ -269,3 +269,42 @@ def test_channels_last_fpn_path_matches_nchw_path_and_batches():
             xb, _ = model.preprocess([{"image": ims[b]}])
             mf_b, _, _ = pd.forward_features(model.backbone(xb))
             assert maxerr(mf_b[0], mf_cl[b]) < 2e-5 * max(scale, 1.0)
+
+
+def test_open_panoptic_inference_vs_oracle():
+    """MaskFormer.panoptic_inference (closed-set merge + RbA-threshold / morphology / connected-components open-set branch) on
+    synthetic queries against the oracle restatement; then through forward() with TEST.PANOPTIC_ON."""
+    from oracle import ref_ops
+    model, a, sd = build("tiny1", 0)
+    model.object_mask_threshold, model.overlap_threshold = 0.5, 0.6
+    g = torch.Generator().manual_seed(13)
+    Q, K, H, W = 16, 19, 96, 160
+    mask_cls = torch.randn(Q, K + 1, generator=g)
+    mask_cls[:, K] -= 2.0
+    cls_of = [3, 3, 11, 12, 0, 13, 8, 11]                                 # two "stuff" queries share class 3 -> merged
+    for q, c in enumerate(cls_of):
+        mask_cls[q, c] += 8.0
+    mask_cls[len(cls_of):, K] += 9.0                                       # the rest predict void
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    mask_pred = torch.full((Q, H, W), -6.0)
+    for q in range(len(cls_of)):                                           # overlapping boxes; a band on the right stays unclaimed
+        y0, x0 = 8 * q, 14 * q
+        mask_pred[q] = torch.where((yy >= y0) & (yy < y0 + 40) & (xx >= x0) & (xx < x0 + 36), 5.0 - 0.3 * q, -6.0)
+    mask_pred += 0.05 * torch.randn(Q, H, W, generator=g)
+    for open_p in (False, True):
+        pan, info, rba = ref_ops.panoptic_inference(mask_cls, mask_pred, set(model.thing_classes), 0.5, 0.6, open_p, -0.3, 50)
+        out = model.panoptic_inference(mask_cls.cuda(), mask_pred.cuda(), open_p, -0.3, 50, return_ood_pred=open_p)
+        assert np.array_equal(out[0].cpu().numpy(), pan) and out[1] == info
+        if open_p:
+            assert maxerr(out[2], rba) < 1e-5 and any(s["category_id"] == 255 for s in info), "the test must exercise the open-set branch"
+    assert sum(1 for s in info if s["category_id"] == 3) == 1, "stuff regions of one class merge"
+    # through forward(): TEST.PANOPTIC_ON -> "panoptic_seg" next to "sem_seg"
+    model.panoptic_on, model.object_mask_threshold, model.overlap_threshold = True, 0.0, 0.0
+    with torch.no_grad():                                                  # make some queries prefer a non-void class
+        model.sem_seg_head.predictor.class_embed.bias[:K] += 6.0
+    im = torch.randint(0, 256, (3, 60, 90), generator=g, dtype=torch.uint8)
+    r = model([{"image": im}], panoptic_ood_threshold=-0.3, panoptic_pixel_min=20, return_panoptic_ood=True)[0]
+    assert len(r["panoptic_seg"]) == 3, "queries were kept, so the open-set branch must have run"
+    pan_g, info_g, ood = r["panoptic_seg"]
+    assert pan_g.shape == (60, 90) and pan_g.dtype == torch.int32 and maxerr(ood, r["rba"].cpu()) < 1e-4
+    assert sorted(s["id"] for s in info_g) == list(range(1, len(info_g) + 1)) and int(pan_g.max()) <= len(info_g)

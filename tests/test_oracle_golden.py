@@ -189,3 +189,28 @@ def test_gaussian_blur_oracle_vs_scipy():
         assert got.shape == want.shape and np.abs(got - want).max() < 1e-12
     const = ref_ops.gaussian_blur(torch.full((16, 16), 2.5), 7, 1.0)
     assert (const - 2.5).abs().max() < 1e-6                                                  # weights sum to one
+
+
+def test_ood_components_oracle_vs_scipy():
+    """Oracle restatement of the cv2 morphology + connected-components step (OpenCV is not installed: parity unpinned) against
+    scipy.ndimage's binary_opening / binary_closing / label on random blob maps, plus a hand-checked case."""
+    from scipy import ndimage
+    from oracle import ref_ops
+    box = np.ones((3, 3), bool)
+    g = np.random.default_rng(7)
+    for H, W, p in ((40, 60, 0.55), (17, 9, 0.7), (64, 64, 0.35)):
+        score = ndimage.gaussian_filter(g.standard_normal((H, W)), 1.5) * 4
+        thr = float(np.quantile(score, 1 - p))
+        labels, n = ref_ops.ood_components(score, thr)
+        b = score > thr
+        # scipy: erosion with border_value=1 / dilation with border_value=0 == "out-of-image neighbours are ignored"
+        opened = ndimage.binary_dilation(ndimage.binary_erosion(b, box, border_value=1), box, border_value=0)
+        closed = ndimage.binary_erosion(ndimage.binary_dilation(opened, box, border_value=0), box, border_value=1)
+        want, wn = ndimage.label(closed)                                   # default structure = 4-connectivity, raster order
+        assert n == wn and np.array_equal(labels, want)
+    m = np.zeros((7, 11))
+    m[0:4, 0:4] = 1; m[0:3, 7:10] = 1; m[5, 5] = 1                         # two blobs survive (gap of 3 columns: the closing does
+    labels, n = ref_ops.ood_components(m, 0.5)                             # not bridge it), the single pixel is opened away
+    assert n == 2 and labels[1, 1] == 1 and labels[1, 8] == 2 and labels[5, 5] == 0
+    m[0:3, 6] = 1                                                          # gap of 2 columns: the closing merges the blobs
+    assert ref_ops.ood_components(m, 0.5)[1] == 1
