@@ -6,7 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...arch import FEATURE_NAMES, FEATURE_STRIDES, num_fpn_levels
+from ...arch import FEATURE_NAMES, num_fpn_levels
 from ...registry import SEM_SEG_HEADS_REGISTRY
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from .ops.ms_deform_attn import MSDeformAttn
