@@ -501,6 +501,199 @@ __global__ __launch_bounds__(256) void valu_rate_probe_kernel(const float* __res
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+
+// ---- residency probe (variant 110): the default K1 kernel body with every workgroup recording its start / end on the constant
+// 100 MHz wall clock; the timestamps overwrite the first 4 floats per workgroup of the output (results are not kept).
+template <int K, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_timed_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                  float* __restrict__ rba, int Q, int64_t HW, int tiles) {
+  const unsigned long long t0 = wall_clock64();
+  float sink = 0.f;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;
+    f32x2 a01[K], a23[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
+    const float* mp = mask + p0;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)u * HW));
+    for (int q0 = 0; q0 < Q; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        const f32x2 s01 = {rba_sigmoid(buf[u].x), rba_sigmoid(buf[u].y)};
+        const f32x2 s23 = {rba_sigmoid(buf[u].z), rba_sigmoid(buf[u].w)};
+        const int qn = q + U < Q ? q + U : Q - 1;
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+        const float* pq = prob + q * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const f32x2 pk = {pq[k], pq[k]};
+          a01[k] = __builtin_elementwise_fma(pk, s01, a01[k]);
+          a23[k] = __builtin_elementwise_fma(pk, s23, a23[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) sink += rba_tanh(a01[k].x) + rba_tanh(a01[k].y) + rba_tanh(a23[k].x) + rba_tanh(a23[k].y);
+  }
+  const unsigned long long t1 = wall_clock64();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(rba) + 2 * blockIdx.x;
+    o[0] = t0;
+    o[1] = t1 + (sink == 12345.f ? 1 : 0);
+  }
+}
+
+
+// ---- wave-granular dynamic tile assignment (variant 111): every wave fetches 256-pixel tiles from an atomic counter, so waves on
+// slower CUs simply take fewer tiles (the residency probe shows identical-work workgroups finishing between 103 and 159 us).
+__device__ unsigned int k1_tile_counter[2];
+
+template <int K, int U>
+__device__ __forceinline__ void k1_tile_body(const float* __restrict__ mask, const float* __restrict__ prob, float* __restrict__ rba,
+                                             int Q, int64_t HW, int64_t p0) {
+  f32x2 a01[K], a23[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
+  const float* mp = mask + p0;
+  f32x4 buf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+  const int Qmain = Q / U * U;
+  for (int q0 = 0; q0 < Qmain; q0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + u;
+      const f32x2 s01 = {rba_sigmoid(buf[u].x), rba_sigmoid(buf[u].y)};
+      const f32x2 s23 = {rba_sigmoid(buf[u].z), rba_sigmoid(buf[u].w)};
+      const int qn = q + U < Q ? q + U : Q - 1;
+      buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+      const float* pq = prob + q * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const f32x2 pk = {pq[k], pq[k]};
+        a01[k] = __builtin_elementwise_fma(pk, s01, a01[k]);
+        a23[k] = __builtin_elementwise_fma(pk, s23, a23[k]);
+      }
+    }
+  }
+  float acc[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { acc[k][0] = a01[k].x; acc[k][1] = a01[k].y; acc[k][2] = a23[k].x; acc[k][3] = a23[k].y; }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int q = Qmain + u;
+    if (q < Q) {
+      const float* pq = prob + q * K;
+      const float b[4] = {buf[u].x, buf[u].y, buf[u].z, buf[u].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float si = rba_sigmoid(b[i]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k][i] = fmaf(pq[k], si, acc[k][i]);
+      }
+    }
+  }
+  rba_epilogue<K, 4, false, false>(acc, K, 0, rba, nullptr, nullptr, p0, HW);
+}
+
+// hybrid dynamic assignment: 1024-pixel workgroup tiles for the first `coarse` tiles (4 KB contiguous per plane and workgroup),
+// then 256-pixel wave tiles for the rest of the map (fine-grained end game)
+template <int K, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_hybrid_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                   float* __restrict__ rba, int Q, int64_t HW, int coarse, int fine,
+                                                                   unsigned int* __restrict__ counter) {
+  __shared__ unsigned int sh_tile;
+  const int lane = threadIdx.x & 63;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) sh_tile = atomicAdd(counter, 1u);
+    __syncthreads();
+    const unsigned int tile = sh_tile;
+    if (tile >= (unsigned)coarse) break;
+    k1_tile_body<K, U>(mask, prob, rba, Q, HW, ((int64_t)tile * 256 + threadIdx.x) * 4);
+  }
+  const int64_t base = (int64_t)coarse * 1024;
+  for (;;) {
+    unsigned int tile = 0;
+    if (lane == 0) tile = atomicAdd(counter + 1, 1u);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (tile >= (unsigned)fine) break;
+    k1_tile_body<K, U>(mask, prob, rba, Q, HW, base + ((int64_t)tile * 64 + lane) * 4);
+  }
+}
+
+template <int K, int U, int WPS, bool BLOCKTILE = false>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_steal_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                  float* __restrict__ rba, int Q, int64_t HW, int tiles,
+                                                                  unsigned int* __restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  __shared__ unsigned int sh_tile;
+  for (;;) {
+    unsigned int tile = 0;
+    int64_t p0;
+    if (BLOCKTILE) {
+      __syncthreads();
+      if (threadIdx.x == 0) sh_tile = atomicAdd(counter, 1u);
+      __syncthreads();
+      tile = sh_tile;
+      if (tile >= (unsigned)tiles) break;
+      p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;
+    } else {
+      if (lane == 0) tile = atomicAdd(counter, 1u);
+      tile = __builtin_amdgcn_readfirstlane(tile);
+      if (tile >= (unsigned)tiles) break;
+      p0 = ((int64_t)tile * 64 + lane) * 4;
+    }
+    f32x2 a01[K], a23[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
+    const float* mp = mask + p0;
+    f32x4 buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+    const int Qmain = Q / U * U;
+    for (int q0 = 0; q0 < Qmain; q0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        const f32x2 s01 = {rba_sigmoid(buf[u].x), rba_sigmoid(buf[u].y)};
+        const f32x2 s23 = {rba_sigmoid(buf[u].z), rba_sigmoid(buf[u].w)};
+        const int qn = q + U < Q ? q + U : Q - 1;
+        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+        const float* pq = prob + q * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const f32x2 pk = {pq[k], pq[k]};
+          a01[k] = __builtin_elementwise_fma(pk, s01, a01[k]);
+          a23[k] = __builtin_elementwise_fma(pk, s23, a23[k]);
+        }
+      }
+    }
+    float acc[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc[k][0] = a01[k].x; acc[k][1] = a01[k].y; acc[k][2] = a23[k].x; acc[k][3] = a23[k].y; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = Qmain + u;
+      if (q < Q) {
+        const float* pq = prob + q * K;
+        const float b[4] = {buf[u].x, buf[u].y, buf[u].z, buf[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float si = rba_sigmoid(b[i]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k][i] = fmaf(pq[k], si, acc[k][i]);
+        }
+      }
+    }
+    rba_epilogue<K, 4, false, false>(acc, K, 0, rba, nullptr, nullptr, p0, HW);
+  }
+}
+
 extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, float* rba, int Q, int64_t HW, int variant,
                                    void* stream) {
   rba_begin();
@@ -542,6 +735,40 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       const int tiles = (int)((HW + 511) / 512);
       hipLaunchKernelGGL((rba_reduce_fast_kernel<19, 2, false, false, 4, 8>), dim3(tiles), dim3(256), 0, st, mask, cls_prob, rba,
                          (float*)nullptr, (int32_t*)nullptr, Q, HW, tiles, 0);
+      return rba_launch_status();
+    }
+    case 116: case 117: case 118: {
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st);
+      const int all = (int)(HW / 1024);
+      const int coarse = variant == 116 ? all * 3 / 4 : (variant == 117 ? all * 7 / 8 : all / 2);
+      const int fine = (all - coarse) * 4;
+      hipLaunchKernelGGL((rba_reduce_hybrid_kernel<19, 2, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, coarse, fine, ctr);
+      return rba_launch_status();
+    }
+    case 114: case 115: {
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      hipMemsetAsync(ctr, 0, sizeof(unsigned int), st);
+      const int tiles = (int)(HW / 1024);
+      if (variant == 114) hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 2, 4, true>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, tiles, ctr);
+      else hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 2, 4, true>), dim3(768), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, tiles, ctr);
+      return rba_launch_status();
+    }
+    case 111: case 112: case 113: {
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      hipMemsetAsync(ctr, 0, sizeof(unsigned int), st);
+      const int tiles = (int)(HW / 256);
+      if (variant == 111) hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 2, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, tiles, ctr);
+      else if (variant == 112) hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 3, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, tiles, ctr);
+      else hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 2, 4>), dim3(2048), dim3(128), 0, st, mask, cls_prob, rba, Q, HW, tiles, ctr);
+      return rba_launch_status();
+    }
+    case 110: {
+      const int tiles = (int)(HW / 1024);
+      hipLaunchKernelGGL((rba_reduce_timed_kernel<19, 2, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, tiles);
       return rba_launch_status();
     }
     case 65: return launch_reduce_dma<19, false, false, 8, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
