@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_hybrid_kernel(const float
 }
 
 template <int K, int U, int WPS, bool BLOCKTILE = false>
-__global__ __launch_bounds__(256, WPS) void rba_reduce_steal_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+__global__ __launch_bounds__(512, WPS / 2) void rba_reduce_steal_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
                                                                   float* __restrict__ rba, int Q, int64_t HW, int tiles,
                                                                   unsigned int* __restrict__ counter) {
   const int lane = threadIdx.x & 63;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_steal_kernel(const float*
       __syncthreads();
       tile = sh_tile;
       if (tile >= (unsigned)tiles) break;
-      p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;
+      p0 = ((int64_t)tile * blockDim.x + threadIdx.x) * 4;
     } else {
       if (lane == 0) tile = atomicAdd(counter, 1u);
       tile = __builtin_amdgcn_readfirstlane(tile);
@@ -745,6 +745,14 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       const int coarse = variant == 116 ? all * 3 / 4 : (variant == 117 ? all * 7 / 8 : all / 2);
       const int fine = (all - coarse) * 4;
       hipLaunchKernelGGL((rba_reduce_hybrid_kernel<19, 2, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, coarse, fine, ctr);
+      return rba_launch_status();
+    }
+    case 119: case 120: {   // workgroup-granular stealing with 512-pixel (128-thread) or 2048-pixel (512-thread) tiles
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st);
+      if (variant == 119) hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 2, 4, true>), dim3(2048), dim3(128), 0, st, mask, cls_prob, rba, Q, HW, (int)(HW / 512), ctr);
+      else hipLaunchKernelGGL((rba_reduce_steal_kernel<19, 2, 4, true>), dim3(512), dim3(512), 0, st, mask, cls_prob, rba, Q, HW, (int)(HW / 2048), ctr);
       return rba_launch_status();
     }
     case 114: case 115: {
