@@ -306,7 +306,7 @@ def main():
                                    f"(BASELINE.json configs[1]); random-init seeded weights",
                        "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None,
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_fast_kernel",
+            "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/k1_pmc.json)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg_ms,

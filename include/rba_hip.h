@@ -57,6 +57,12 @@ int rba_hip_version(void);
 int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
                    int Q, int K, int64_t HW, int score_mode, void* stream);
 
+/* The same with dynamic tile assignment: `workspace` = 8 bytes of device memory owned by the caller, zero before the first use
+ * (the kernel leaves it zero); one workspace per stream that may run K1 concurrently.  Workgroups fetch their tiles from an atomic
+ * counter in it, which evens out the per-CU rate spread of the static split (same results bit for bit). */
+int rba_reduce_ws_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax, int Q, int K,
+                      int64_t HW, int score_mode, void* workspace, void* stream);
+
 /* K1 fused with the x4 bilinear upsample (align_corners=False) in front and the crop behind it.
  * mask_lowres [Q,h,w]; the virtual full-resolution map is [Q,4h,4w]; outputs cover rows < crop_h and
  * columns < crop_w of it: rba [crop_h,crop_w], sem_seg [K,crop_h,crop_w] or NULL, argmax or NULL. */

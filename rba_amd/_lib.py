@@ -18,6 +18,7 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     "rba_hip_version": [],
     "rba_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp],
+    "rba_reduce_ws_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp],
     "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

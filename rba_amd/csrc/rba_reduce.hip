@@ -16,8 +16,8 @@ using namespace rba_k1;
 
 extern "C" int rba_hip_version(void) { return 140; }
 
-extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
-                              int Q, int K, int64_t HW, int score_mode, void* stream) {
+static int reduce_impl(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax, int Q, int K, int64_t HW,
+                       int score_mode, unsigned int* counters, void* stream) {
   RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 160 && HW >= 0 && score_mode >= 0 && score_mode <= 2);
   const int mode = score_mode;
   if (HW == 0) return 0;
@@ -37,12 +37,24 @@ extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* r
       default: return launch_reduce_mfma_wl<4, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
     }
   }
-  if (K == 19 && vec4) return launch_reduce_fast<19, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st, mode);
-  if (K == 20 && vec4) return launch_reduce_fast<20, 4, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, st, mode);
+  // K = 19 / 20 (Cityscapes without / with void): compile-time K, packed FMAs, 2-deep prefetch ring, 4 workgroups per CU
+  if (K == 19 && vec4) return launch_reduce_pk<19, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, mode, counters, st);
+  if (K == 20 && vec4) return launch_reduce_pk<20, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, mode, counters, st);
   if (K <= 32 && vec4) return launch_reduce<32, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
   if (K <= 32) return launch_reduce<32, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
   if (K <= 80) return launch_reduce<80, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
   return launch_reduce<160, 1>(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, st, mode);
+}
+
+extern "C" int rba_reduce_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
+                              int Q, int K, int64_t HW, int score_mode, void* stream) {
+  return reduce_impl(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, score_mode, nullptr, stream);
+}
+
+extern "C" int rba_reduce_ws_f32(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax,
+                                 int Q, int K, int64_t HW, int score_mode, void* workspace, void* stream) {
+  RBA_CHECK_ARG(workspace && (((uintptr_t)workspace) & 3) == 0);
+  return reduce_impl(mask, cls_prob, rba, sem_seg, argmax, Q, K, HW, score_mode, reinterpret_cast<unsigned int*>(workspace), stream);
 }
 
 extern "C" int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_prob, float* rba, float* sem_seg,

@@ -272,13 +272,25 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_fast_kernel(const float* 
 // float2 register pairs from the start, so every FMA is a v_pk_fma_f32 whose operands need no pairing moves
 // (the scalar formulation is SLP-vectorised by the compiler, which inserts 21 v_mov per two planes to build the pairs).
 // Same operations in the same order per element as rba_reduce_fast_kernel: bit-identical results.
-template <int K, bool SEM, bool ARG, int U, int WPS>
+template <int K, bool SEM, bool ARG, int U, int WPS, bool DYN>
 __global__ __launch_bounds__(256, WPS) void rba_reduce_pk_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
                                                                float* __restrict__ rba, float* __restrict__ sem,
-                                                               int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode) {
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+                                                               int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode,
+                                                               unsigned int* __restrict__ counters) {
+  // DYN: tiles are handed out by an atomic counter in a caller-provided workspace (two zeroed uint32), so workgroups on slower
+  // CUs take fewer tiles -- with a static split identical workgroups finish between 103 and 159 us (residency probe in
+  // profiles/r01_k1_bandwidth_probes.txt).  The last workgroup to leave zeroes the workspace again.
+  __shared__ unsigned int sh_tile;
+  auto next_tile = [&](int prev) -> int {
+    if (!DYN) return prev < 0 ? (int)blockIdx.x : prev + (int)gridDim.x;
+    __syncthreads();
+    if (threadIdx.x == 0) sh_tile = atomicAdd(counters, 1u);
+    __syncthreads();
+    return (int)sh_tile;
+  };
+  for (int tile = next_tile(-1); tile < tiles; tile = next_tile(tile)) {
     const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;
-    if (p0 >= HW) continue;
+    if (p0 < HW) {
     f32x2 a01[K], a23[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
@@ -322,22 +334,37 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_pk_kernel(const float* __
       }
     }
     rba_epilogue<K, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
+    }
+  }
+  if (DYN && threadIdx.x == 0) {
+    const unsigned int done = atomicAdd(counters + 1, 1u);
+    if (done == gridDim.x - 1) {                                   // every other workgroup has fetched its last (out-of-range) tile
+      atomicExch(counters, 0u);
+      atomicExch(counters + 1, 0u);
+    }
   }
 }
 
-template <int K, bool SEM, bool ARG, int U, int WPS>
+// counters == nullptr: static tile split (re-entrant, nothing but the arguments); otherwise dynamic assignment through the workspace
+template <int K, int U, int WPS>
 int launch_reduce_pk(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int64_t HW, int mode,
-                     hipStream_t st) {
+                     unsigned int* counters, hipStream_t st) {
   const int64_t tiles = (HW + 1023) / 1024;
   if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   const int64_t cap = 256 * WPS;
   int64_t grid = tiles;
   if (tiles > cap) {
     const int64_t rounds = (tiles + cap - 1) / cap;
-    grid = (tiles + rounds - 1) / rounds;
+    grid = counters ? cap : (tiles + rounds - 1) / rounds;
   }
-  hipLaunchKernelGGL((rba_reduce_pk_kernel<K, SEM, ARG, U, WPS>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW,
-                     (int)tiles, mode);
+#define RBA_L(S, A, D) \
+  hipLaunchKernelGGL((rba_reduce_pk_kernel<K, S, A, U, WPS, D>), dim3((unsigned)grid), dim3(256), 0, st, mask, prob, rba, sem, argmax, Q, HW, (int)tiles, mode, counters)
+  if (counters) {
+    if (sem && argmax) RBA_L(true, true, true); else if (sem) RBA_L(true, false, true); else if (argmax) RBA_L(false, true, true); else RBA_L(false, false, true);
+  } else {
+    if (sem && argmax) RBA_L(true, true, false); else if (sem) RBA_L(true, false, false); else if (argmax) RBA_L(false, true, false); else RBA_L(false, false, false);
+  }
+#undef RBA_L
   return rba_launch_status();
 }
 

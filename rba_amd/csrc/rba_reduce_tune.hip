@@ -714,11 +714,11 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
     case 12: return launch_reduce_fast<19, 4, 1, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
     case 13: return launch_reduce_fast<19, 4, 1, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
     case 14: return launch_reduce_fast<19, 4, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, st);
-    case 60: return launch_reduce_pk<19, false, false, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
-    case 61: return launch_reduce_pk<19, false, false, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
-    case 62: return launch_reduce_pk<19, false, false, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
-    case 63: return launch_reduce_pk<19, false, false, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
-    case 64: return launch_reduce_pk<19, false, false, 2, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, st);
+    case 60: return launch_reduce_pk<19, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, nullptr, st);
+    case 61: return launch_reduce_pk<19, 2, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, nullptr, st);
+    case 62: return launch_reduce_pk<19, 3, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, nullptr, st);
+    case 63: return launch_reduce_pk<19, 4, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, nullptr, st);
+    case 64: return launch_reduce_pk<19, 2, 6>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, nullptr, st);
     case 100: {   // non-persistent: one 1024-pixel tile per workgroup, the dispatcher balances the CUs
       const int tiles = (int)((HW + 1023) / 1024);
       hipLaunchKernelGGL((rba_reduce_fast_kernel<19, 4, false, false, 2, 4>), dim3(tiles), dim3(256), 0, st, mask, cls_prob, rba,

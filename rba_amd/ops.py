@@ -42,6 +42,18 @@ def _mode(score):
     return SCORE_MODES[score]
 
 
+_K1_WORKSPACES = {}
+
+
+def _k1_workspace(device):
+    """8 zeroed bytes per (device, stream) for K1's dynamic tile counter (the kernel leaves them zero)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _K1_WORKSPACES.get(key)
+    if ws is None:
+        ws = _K1_WORKSPACES[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return ws
+
+
 def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False, score="rba"):
     """K1.  mask_pred [Q,H,W] full-resolution mask logits, cls_prob [Q,K] -> (rba [H,W], sem_seg [K,H,W] | None,
     argmax int32 [H,W] | None).  maskformer_model.py:381-386 + evaluate_ood.py:150 + support.py:385-388."""
@@ -56,8 +68,8 @@ def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False, score
     rba = torch.empty((H, W), dtype=torch.float32, device=dev)
     sem = torch.empty((K, H, W), dtype=torch.float32, device=dev) if want_sem_seg else None
     arg = torch.empty((H, W), dtype=torch.int32, device=dev) if want_argmax else None
-    _lib.check(lib.rba_reduce_f32(_p(mask_pred), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, H * W, _mode(score),
-                                  _stream()), "rba_reduce_f32")
+    _lib.check(lib.rba_reduce_ws_f32(_p(mask_pred), _p(cls_prob), _p(rba), _p(sem), _p(arg), Q, K, H * W, _mode(score),
+                                     _p(_k1_workspace(dev)), _stream()), "rba_reduce_ws_f32")
     return rba, sem, arg
 
 

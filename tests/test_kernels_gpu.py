@@ -510,3 +510,33 @@ def test_ood_components_vs_oracle(ops, H, W, p, seed):
     assert n0 == 0 and not empty.any()
     full, n1 = ops.ood_components(dev(torch.ones(8, 8)), 0.0)
     assert n1 == 1 and bool((full == 1).all())
+
+
+def test_k1_dynamic_tiles_match_static_and_workspace_self_resets(ops):
+    """rba_reduce_ws_f32 (tiles fetched from an atomic counter) against rba_reduce_f32 (static split): identical bits, the
+    workspace is zero again after every launch, and two streams with their own workspaces do not interfere."""
+    import ctypes
+    from rba_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    Q, K, H, W = 100, 19, 256, 512
+    mask = dev(torch.randn(Q, H, W, generator=g) * 5)
+    prob = dev(torch.softmax(torch.randn(Q, K + 1, generator=g) * 3, -1)[:, :K].contiguous())
+    st = torch.cuda.current_stream().cuda_stream
+    static = torch.empty(H, W, device="cuda")
+    sem_s = torch.empty(K, H, W, device="cuda")
+    arg_s = torch.empty(H, W, dtype=torch.int32, device="cuda")
+    assert lib.rba_reduce_f32(mask.data_ptr(), prob.data_ptr(), static.data_ptr(), sem_s.data_ptr(), arg_s.data_ptr(), Q, K, H * W, 0, st) == 0
+    for _ in range(3):                                                     # the same cached workspace is reused
+        rba, sem, arg = ops.rba_reduce(mask, prob, True, True)
+        assert torch.equal(rba, static) and torch.equal(sem, sem_s) and torch.equal(arg, arg_s)
+        ws = ops._k1_workspace(mask.device)
+        torch.cuda.synchronize()
+        assert ws.tolist() == [0, 0], "the last workgroup must leave the counters zeroed"
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        r2 = ops.rba_reduce(mask, prob)[0]
+    r1 = ops.rba_reduce(mask, prob)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(r1, static) and torch.equal(r2, static) and len(ops._K1_WORKSPACES) >= 2
