@@ -747,6 +747,13 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       hipLaunchKernelGGL((rba_reduce_hybrid_kernel<19, 2, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, coarse, fine, ctr);
       return rba_launch_status();
     }
+    case 121: {   // the product kernel: packed, dynamic tile assignment through a (here: static device) workspace
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      static bool zeroed = false;
+      if (!zeroed) { hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st); zeroed = true; }
+      return launch_reduce_pk<19, 2, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, ctr, st);
+    }
     case 119: case 120: {   // workgroup-granular stealing with 512-pixel (128-thread) or 2048-pixel (512-thread) tiles
       unsigned int* ctr = nullptr;
       if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
