@@ -179,6 +179,10 @@ ARCHS = {
     "swin_b_1dl": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=12,
                        conv_dim=256, mask_dim=256, nheads=8, num_queries=100, num_classes=19,
                        dim_feedforward=2048, enc_layers=6, dec_layers=1, enc_in=["res5"]),
+    # ckpts/swin_l_1dl/config.yaml
+    "swin_l_1dl": dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=12,
+                       conv_dim=256, mask_dim=256, nheads=8, num_queries=100, num_classes=19,
+                       dim_feedforward=2048, enc_layers=6, dec_layers=1, enc_in=["res5"]),
     # configs/.../swin/all_decoder_layers/maskformer2_swin_base_IN21k_384_bs16_90k.yaml (DEC_LAYERS 10)
     "swin_b_9dl": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=12,
                        conv_dim=256, mask_dim=256, nheads=8, num_queries=100, num_classes=19,
@@ -469,6 +473,8 @@ def main():
     if args.full:
         jobs["g5c2"] = lambda: g_end_to_end(R, "swin_b_1dl", 1024, 2048, 0, 1234, False, "g5_swin_b_1dl_1024x2048")
         jobs["g5c5"] = lambda: g_end_to_end(R, "swin_b_9dl", 720, 1280, 0, 1234, False, "g5_swin_b_9dl_720x1280")
+        # BASELINE C4's architecture (Swin-L, channel counts that are not multiples of 128) at a size the CPU reference finishes quickly
+        jobs["g5c4"] = lambda: g_end_to_end(R, "swin_l_1dl", 512, 1024, 0, 1234, False, "g5_swin_l_1dl_512x1024")
     for k, fn in jobs.items():
         if args.only and k != args.only:
             continue

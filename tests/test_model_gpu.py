@@ -123,6 +123,12 @@ def test_full_size_swin_b_1dl_1024x2048(golden):
     _full_size(golden, "g5_swin_b_1dl_1024x2048", "swin_b_1dl", 1e-4)
 
 
+def test_swin_l_1dl_512x1024(golden):
+    """BASELINE config C4's architecture (Swin-L: channel counts 192..1536, not multiples of the GEMM tile) against the reference's
+    own modules at 512x1024."""
+    _full_size(golden, "g5_swin_l_1dl_512x1024", "swin_l_1dl", 1e-4)
+
+
 def test_full_size_swin_b_9dl_720x1280(golden):
     """BASELINE config C5 (9 decoder layers, 3-level MSDeformAttn, 720 -> 736 padding)."""
     _full_size(golden, "g5_swin_b_9dl_720x1280", "swin_b_9dl", 1e-4)

@@ -141,7 +141,8 @@ def test_c_oracle_k1_k2(golden):
 
 
 @pytest.mark.parametrize("fixture,arch_name", [("g5_swin_b_1dl_1024x2048", "swin_b_1dl"),
-                                               ("g5_swin_b_9dl_720x1280", "swin_b_9dl")])
+                                               ("g5_swin_b_9dl_720x1280", "swin_b_9dl"),
+                                               ("g5_swin_l_1dl_512x1024", "swin_l_1dl")])
 def test_end_to_end_full_size(golden, fixture, arch_name):
     """BASELINE configs C2 / C5 at full size: oracle vs sampled outputs of the reference's own modules (about 10 s each)."""
     g = golden(fixture)
