@@ -540,3 +540,50 @@ def test_k1_dynamic_tiles_match_static_and_workspace_self_resets(ops):
     r1 = ops.rba_reduce(mask, prob)[0]
     torch.cuda.synchronize()
     assert torch.equal(r1, static) and torch.equal(r2, static) and len(ops._K1_WORKSPACES) >= 2
+
+
+# ----------------------------------------------------------------------------------- size-independent properties at BASELINE sizes
+def test_k1_full_size_properties(ops):
+    """K1 at the BASELINE C2 size (100 x 19 x 1024 x 2048) through properties that need no CPU reference of that size:
+    linearity of sem in the queries (two halves add up), one-hot class rows select sigmoid sums, saturated masks give closed forms."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Q, K, H, W = 100, 19, 1024, 2048
+    mask = torch.randn(Q, H, W, device="cuda", generator=g) * 5
+    prob = torch.softmax(torch.randn(Q, K + 1, device="cuda", generator=g) * 3, -1)[:, :K].contiguous()
+    rba, sem, arg = ops.rba_reduce(mask, prob, True, True)
+    assert torch.equal(arg.long(), sem.argmax(0)) and maxerr(rba, -sem.double().tanh().sum(0)) < 1e-5
+    _, s1, _ = ops.rba_reduce(mask[:40].contiguous(), prob[:40].contiguous(), True)
+    _, s2, _ = ops.rba_reduce(mask[40:].contiguous(), prob[40:].contiguous(), True)
+    assert (s1 + s2 - sem).abs().max().item() < 5e-6                         # same terms, different association
+    onehot = torch.zeros(Q, K, device="cuda")
+    cls = torch.arange(Q, device="cuda") % K
+    onehot[torch.arange(Q), cls] = 1.0
+    _, so, _ = ops.rba_reduce(mask, onehot, True)
+    rows = torch.tensor([0, 511, 1023], device="cuda")
+    want = torch.zeros(K, 3, W, device="cuda", dtype=torch.float64).index_add_(0, cls, mask[:, rows].double().sigmoid())
+    assert (so[:, rows].double() - want).abs().max().item() < 1e-5
+    sat = torch.full((Q, H, W), -40.0, device="cuda")
+    sat[7] = 40.0                                                             # only query 7 is "on": sem = prob[7], everywhere
+    r_sat, s_sat, _ = ops.rba_reduce(sat, prob, True)
+    assert (s_sat - prob[7].view(K, 1, 1)).abs().max().item() < 1e-6
+    assert (r_sat + prob[7].double().tanh().sum()).abs().max().item() < 1e-6
+
+
+def test_split_linear_full_size_properties(ops):
+    """K6 at the largest BASELINE GEMM (Swin-B stage 1, M = 131072): exactness on selection weights, additivity in the input,
+    and fp64 agreement on sampled rows."""
+    g = torch.Generator(device="cuda").manual_seed(6)
+    M, N, K = 131072, 512, 128
+    x = torch.randn(M, K, device="cuda", generator=g) * torch.logspace(-3, 3, K, device="cuda").view(1, K)
+    sel = torch.zeros(N, K, device="cuda")
+    sel[torch.arange(N), torch.arange(N) % K] = 1.0
+    out = ops.split_linear(x, ops.split_weight(sel))
+    assert torch.equal(out, x[:, torch.arange(N, device="cuda") % K]), "hi + mid + lo must reproduce every fp32 input exactly"
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    planes = ops.split_weight(w)
+    x1, x2 = torch.randn(M, K, device="cuda", generator=g), torch.randn(M, K, device="cuda", generator=g)
+    y1, y2, y12 = ops.split_linear(x1, planes, b), ops.split_linear(x2, planes, b), ops.split_linear(x1 + x2, planes, b)
+    assert (y1 + y2 - b - y12).abs().max().item() < 2e-5
+    rows = torch.randint(0, M, (256,), device="cuda", generator=g)
+    assert maxerr(y1[rows], F.linear(x1[rows].double(), w.double(), b.double())) < 1e-5
