@@ -333,11 +333,12 @@ def split_linear_pays(M, N, K, gelu=False):
 def linear(x, lin, use_bias=True, gelu=False, relu=False):
     """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the bf16x6
     kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise."""
+    _chk(x, "x") if x.is_contiguous() else _chk(x.contiguous(), "x")          # HIP fp32 tensors only: no CPU path here either
     w = lin.weight
     N, K = w.shape
     M = x.numel() // K if K else 0
     bias = lin.bias if use_bias else None
-    if x.is_cuda and x.dtype == torch.float32 and split_linear_pays(M, N, K, gelu):
+    if split_linear_pays(M, N, K, gelu):
         key = (w.data_ptr(), w._version, w.device)
         cache = getattr(lin, "_rba_planes", None)
         if cache is None or cache[0] != key:

@@ -43,6 +43,13 @@ def test_ops_have_no_cpu_path():
                                    torch.zeros(1, 4, 2, 1, 2, 2), torch.zeros(1, 4, 2, 1, 2))
     with pytest.raises(RbaHipError):
         ops.resample_bilinear(torch.zeros(1, 2, 2), (4, 4))
+    with pytest.raises(RbaHipError, match="no CPU path"):
+        ops.linear(torch.zeros(4, 32), torch.nn.Linear(32, 128))
+    for fn, args in ((ops.split_weight, (torch.zeros(128, 32),)), (ops.gaussian_blur, (torch.zeros(16, 16),)),
+                     (ops.ood_components, (torch.zeros(16, 16), 0.0)), (ops.group_norm_nhwc, (torch.zeros(1, 8, 32), 4, torch.ones(32), torch.zeros(32))),
+                     (ops.conv3x3_weight, (torch.zeros(128, 32, 3, 3),))):
+        with pytest.raises(RbaHipError):
+            fn(*args)
 
 
 def test_product_never_imports_oracle():
