@@ -4,7 +4,7 @@
 live with HIP events inside the same steps, plus the oracle (CPU restatement of the reference path) timed on this
 box's host cores.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 outside torchrun: spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -44,27 +44,154 @@ def parse():
                     help="images per GPU per step, each on its own HIP stream (concurrent kernels fill under-occupied "
                          "stage-3/4 launches: +7..10 %% images/s at 2-3, but K1's live timing then includes contention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=1.0, help="scale of the wall-time bounds of the cpu_baseline legs")
     ap.add_argument("--n-images", type=int, default=4, help="distinct resident synthetic images cycled through")
     return ap.parse_args()
 
 
-def cpu_baseline(arch_name, h, w):
-    """Oracle (oracle/ref_model.py = CPU restatement of the reference path, pinned by tests/golden) on one image."""
-    from oracle import ref_model
+def _timed_runs(fn, reps, budget_s):
+    """reps timed runs of fn (at least 1; stops early once budget_s of wall time is spent) -> sorted seconds"""
+    ts, t_all = [], time.perf_counter()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s:
+            break
+    return sorted(ts)
+
+
+def _med(ts):
+    return ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+
+
+def exchange_inputs(rank, h, w, device):
+    """Synthetic OoD labels of BASELINE C3 for the metric exchange: Bernoulli(0.03) anomaly mask (seed 99 + rank) and a
+    16-pixel void border.  -> (labels bool [h, w], valid bool [h, w])"""
+    g = torch.Generator().manual_seed(99 + rank)
+    lab = (torch.rand(h, w, generator=g) < 0.03).to(device)
+    valid = torch.ones(h, w, dtype=torch.bool, device=device)
+    valid[:16] = valid[-16:] = False
+    valid[:, :16] = valid[:, -16:] = False
+    return lab, valid
+
+
+def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0):
+    """the oracle (oracle/ref_model.py + oracle/ref_ops.py = CPU restatement of the reference path,
+    pinned by tests/golden) timed on this box's host cores, fp32, no_grad, batch 1, after a warm-up, median of repeated runs:
+      (1) full forward + RbA score at the bench size (C2) with the best thread count of a short sweep, and at C1's size
+          (256x512) with all cores and with ONE thread;
+      (2) the isolated post-network reduction on K1's own synthetic tensors (mask logits ~ N(0,5^2) [Q,H/4,W/4], class logits
+          ~ N(0,3^2) [Q,K+1], seed 0): x4 bilinear -> sigmoid -> einsum('qc,qhw->chw') -> -tanh().sum(0) (+ argmax) =
+          maskformer_model.py:294-299, 381-386 + evaluate_ood.py:150, all cores and ONE thread, beside K1's own time.
+    Every leg is bounded (sample sizes in the record)."""
+    from oracle import ref_model, ref_ops
     from rba_amd import arch as A
     a = A.complete(A.ARCHS[arch_name])
     sd = A.seeded_weights(a, 0)
     g = torch.Generator().manual_seed(1234)
-    warm = torch.randint(0, 256, (3, 128, 256), generator=g, dtype=torch.uint8)
-    ref_model.forward(warm, sd, a)                              # untimed warm-up (thread pool, allocator)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    rec = {"unit": "images/s", "kind": "port", "logical_cpus": ncpu, "torch_default_threads": default_threads}
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        rec["cpu_model"] = names[0] if names else None
+    except OSError:
+        rec["cpu_model"] = None
+
+    # ---- thread-count sweep on the C1-size forward (one socket's worth of threads usually beats every logical cpu)
+    img_c1 = torch.randint(0, 256, (3, 256, 512), generator=g, dtype=torch.uint8)
+    cands = sorted({t for t in (ncpu, default_threads, ncpu // 2, 64, 32, 16) if 1 <= t <= ncpu}, reverse=True)
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        ref_model.forward(img_c1, sd, a)                                      # warm-up (thread pool, allocator)
+        sweep[t] = _med(_timed_runs(lambda: ref_model.forward(img_c1, sd, a), 3, 8.0 * budget_scale))
+    best = min(sweep, key=sweep.get)
+    rec["thread_sweep_256x512_s"] = {str(k): round(v, 4) for k, v in sweep.items()}
+
+    # ---- (1) full forward at C1's size: best thread count (median of 5) and ONE thread (median of 3)
+    torch.set_num_threads(best)
+    c1_all = _timed_runs(lambda: ref_model.forward(img_c1, sd, a), 5, 15.0 * budget_scale)
+    torch.set_num_threads(1)
+    c1_one = _timed_runs(lambda: ref_model.forward(img_c1, sd, a), 3, 25.0 * budget_scale)
+    rec["forward_256x512"] = {"threads": best, "median_s": _med(c1_all), "runs_s": c1_all,
+                              "one_thread_median_s": _med(c1_one), "one_thread_runs_s": c1_one}
+
+    # ---- (1) full forward at the bench size
+    torch.set_num_threads(best)
     image = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
-    t0 = time.perf_counter()
-    out = ref_model.forward(image, sd, a)
-    dt = time.perf_counter() - t0
-    assert out["rba"].shape == (h, w)
-    return {"value": 1.0 / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 image 3x{h}x{w}, full forward + RbA score, torch CPU fp32, {dt:.1f} s "
-                      f"({os.cpu_count()} logical cpus visible)"}
+    out = {}
+
+    def fwd():
+        out["o"] = ref_model.forward(image, sd, a)
+    full = _timed_runs(fwd, 3, 40.0 * budget_scale)
+    assert out["o"]["rba"].shape == (h, w)
+    rec.update(value=1.0 / _med(full), cores=best, runs_s=full,
+               sample=f"{len(full)} run(s) of 1 image 3x{h}x{w}, full forward + RbA score, torch CPU fp32, {best} threads "
+                      f"(best of {cands} on the 256x512 forward), median {_med(full):.2f} s; warm-up = the 256x512 runs")
+
+    # ---- (2) isolated reduction on K1's synthetic tensors
+    Q, K = a["num_queries"], a["num_classes"]
+    H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    g0 = torch.Generator().manual_seed(0)
+    low = torch.randn(Q, H // 4, W // 4, generator=g0) * 5.0
+    cls = torch.randn(Q, K + 1, generator=g0) * 3.0
+
+    def reduction():
+        up = ref_ops.upsample_bilinear(low[None], (H, W))[0]
+        sem = ref_ops.semantic_inference(cls, up)
+        return ref_ops.rba_score(sem), sem.argmax(0)
+    reduction()
+    red_all = _timed_runs(reduction, 5, 15.0 * budget_scale)
+    torch.set_num_threads(1)
+    red_one = _timed_runs(reduction, 3, 30.0 * budget_scale)
+    alg = 4 * Q * H * W + 4 * Q * K + 4 * H * W
+    rec["reduction"] = {"what": "x4 bilinear -> sigmoid -> einsum(qc,qhw->chw) -> -tanh.sum(0) + argmax on [Q=%d,%d,%d] logits" % (Q, H // 4, W // 4),
+                        "threads": best, "median_s": _med(red_all), "runs_s": red_all,
+                        "one_thread_median_s": _med(red_one), "one_thread_runs_s": red_one,
+                        "k1_algorithmic_GBps_cpu": alg / _med(red_all) / 1e9,
+                        "k1_gpu_ms": k1_gpu_ms,
+                        "gpu_over_cpu": (_med(red_all) * 1e3 / k1_gpu_ms) if k1_gpu_ms else None}
+    torch.set_num_threads(default_threads)
+    return rec
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: spawn the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1), stream rank 0's stdout through, fail if any rank fails."""
+    import socket
+    import subprocess
+    n = args.gpus
+    share = os.environ.get("RBA_BENCH_SHARE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < n and not share:
+        raise SystemExit(f"--gpus {n} but only {ndev} visible HIP device(s) (set RBA_BENCH_SHARE_DEVICE=1 to let ranks "
+                         f"share device 0 -- a plumbing test, not a measurement)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RBA_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = []
+    for pr in procs:
+        try:
+            rcs.append(pr.wait(timeout=3600))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            rcs.append(-9)
+    if any(rcs):
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        raise SystemExit(f"bench ranks exited with {rcs}")
 
 
 def main():
@@ -76,12 +203,13 @@ def main():
     from rba_amd.maskformer_model import MaskFormer
 
     # test-only overrides so the N > 1 code path can be exercised on a 1-GPU box: ranks share device 0 over gloo
-    rank, world, local = D.init_from_env(os.environ.get("RBA_BENCH_BACKEND"))
-    if os.environ.get("RBA_BENCH_SHARE_DEVICE") == "1":
-        local = 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+    share = os.environ.get("RBA_BENCH_SHARE_DEVICE") == "1"
+    if share:                                    # ranks share device 0: gloo (RCCL refuses two ranks on one device)
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = D.init_from_env(os.environ.get("RBA_BENCH_BACKEND", "gloo" if share else None))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs through torch.distributed.run (see the module docstring)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
@@ -240,11 +368,7 @@ def main():
     # ---- pooled OoD metric exchange over RCCL, outside the timed region
     exch_ms = None
     if world > 1:
-        g = torch.Generator().manual_seed(99 + rank)
-        lab = (torch.rand(h, w, generator=g) < 0.03).to(dev)
-        valid = torch.ones(h, w, dtype=torch.bool, device=dev)
-        valid[:16] = valid[-16:] = False
-        valid[:, :16] = valid[:, -16:] = False
+        lab, valid = exchange_inputs(rank, h, w, dev)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
         m = D.pooled_ood_metrics(out[valid], lab[valid])
@@ -318,7 +442,8 @@ def main():
             res["metric_exchange_ms"] = exch_ms
             res["pooled_metrics"] = m
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.arch, h, w)
+            res["cpu_baseline"] = cpu_baseline(args.arch, h, w, k1_gpu_ms=k1_avg_ms if args.k1 == "fullres" else None,
+                                               budget_scale=args.cpu_budget)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

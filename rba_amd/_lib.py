@@ -45,6 +45,8 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
+EXPECTED_ABI = 150        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+
 _lib = None
 
 
@@ -73,6 +75,10 @@ def load():
             raise RbaHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_elems")) else ctypes.c_int
+    abi = int(lib.rba_hip_version())
+    if abi != EXPECTED_ABI:               # same names, possibly different argument lists: calling it would corrupt memory
+        raise RbaHipError(f"{LIB_PATH} has ABI version {abi}, these bindings are written for {EXPECTED_ABI}; rebuild it "
+                          "(python -m rba_amd.csrc.build)")
     _lib = lib
     return lib
 

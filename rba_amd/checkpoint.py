@@ -10,12 +10,29 @@ import torch
 IGNORED_EXTRA = ("criterion.",)       # criterion.empty_weight is constructed even for eval (maskformer_model.py:148-150)
 
 
-def read_state_dict(path):
+class _TensorsOnlyUnpickler(pickle.Unpickler):
+    """.pkl checkpoints (convert-pretrained-swin-model-to-d2.py) hold a dict of numpy arrays and strings: allow exactly the
+    globals numpy needs to rebuild an ndarray, nothing else -- a pickle can otherwise run arbitrary code on load."""
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"),
+                ("numpy._core.multiarray", "scalar"), ("collections", "OrderedDict")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint pickle references {module}.{name}; only numpy arrays are accepted "
+                                     "(pass trusted=True to load a checkpoint you trust with the full unpickler)")
+
+
+def read_state_dict(path, trusted=False):
+    """trusted=False (default): .pth through torch.load(weights_only=True), .pkl through an unpickler restricted to numpy
+    arrays -- a checkpoint file cannot execute code.  trusted=True: the full unpicklers, for checkpoints that carry other
+    objects (Detectron2 writes plain tensors, so the default reads every released model_final.pth)."""
     if path.endswith(".pkl"):
         with open(path, "rb") as f:
-            data = pickle.load(f, encoding="latin1")
+            data = pickle.load(f, encoding="latin1") if trusted else _TensorsOnlyUnpickler(f, encoding="latin1").load()
     else:
-        data = torch.load(path, map_location="cpu", weights_only=False)
+        data = torch.load(path, map_location="cpu", weights_only=not trusted)
     sd = data["model"] if isinstance(data, dict) and "model" in data else data
     out = {}
     for k, v in sd.items():
@@ -25,10 +42,10 @@ def read_state_dict(path):
     return out
 
 
-def load_checkpoint(model, path_or_sd):
+def load_checkpoint(model, path_or_sd, trusted=False):
     """Name-matched load; tolerates the extra criterion buffers and the recomputed integer index buffers, raises on
     anything else missing / unexpected / mis-shaped."""
-    sd = read_state_dict(path_or_sd) if isinstance(path_or_sd, str) else dict(path_or_sd)
+    sd = read_state_dict(path_or_sd, trusted) if isinstance(path_or_sd, str) else dict(path_or_sd)
     sd = {k: v for k, v in sd.items() if not k.startswith(IGNORED_EXTRA)}
     own = model.state_dict()
     bad = [f"{k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}" for k, v in sd.items()

@@ -46,6 +46,8 @@ def all_gather_variable(t: torch.Tensor) -> torch.Tensor:
     world = _world()
     if world == 1:
         return t
+    if t.is_cuda and dist.get_backend() == "gloo":      # gloo has no device all_gather: stage through the host (tests only)
+        return all_gather_variable(t.cpu()).to(t.device)
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)

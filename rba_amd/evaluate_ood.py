@@ -30,7 +30,8 @@ def get_model(config_path, model_path, device=None):
     cfg = load_cfg(config_path, ["OUTPUT_DIR", "output/"])
     model = build_model(cfg)
     if model_path is not None:
-        load_checkpoint(model, model_path)
+        # default: a checkpoint file cannot execute code (weights_only / numpy-only unpickler); opt in for trusted files
+        load_checkpoint(model, model_path, trusted=os.environ.get("RBA_TRUSTED_CHECKPOINT") == "1")
     model.to(device or DEVICE)
     return model.eval()
 
@@ -67,6 +68,13 @@ def get_neg_logit_sum(model, x, **kwargs):
     with torch.no_grad():
         out = model([{"image": x[0].to(model.device)}])
     return -out[0]["sem_seg"].sum(dim=0)
+
+
+# K1 epilogue each score function selects: lets OODEvaluator take score + argmax from ONE forward (support.py) without
+# guessing from the function's name
+get_RbA.rba_score_mode = "rba"
+get_energy.rba_score_mode = "energy"
+get_neg_logit_sum.rba_score_mode = "neg_logit_sum"
 
 
 # ------------------------------------------------------------------------------------------------- command line

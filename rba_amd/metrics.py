@@ -59,6 +59,33 @@ def ood_metrics(scores: torch.Tensor, labels: torch.Tensor) -> dict:
 
 
 @torch.no_grad()
+def roc_at_tpr95(scores: torch.Tensor, labels: torch.Tensor):
+    """OODEvaluator.calculate_auroc (support.py:247-257): (auc of roc_curve, fpr and threshold of the first ROC point with
+    tpr > 0.95; if there is none: fpr 0 and the last threshold).  roc_curve's first threshold is +inf (scikit-learn >= 1.3)."""
+    scores, labels = scores.reshape(-1), labels.reshape(-1)
+    fps, tps = binary_clf_curve(scores, labels)
+    order = torch.argsort(scores, descending=True, stable=True)
+    s = scores[order]
+    distinct = torch.nonzero(s[1:] != s[:-1]).reshape(-1)
+    thr = s[torch.cat([distinct, torch.tensor([s.numel() - 1], device=s.device, dtype=distinct.dtype)])]
+    P, Nn = tps[-1].double(), fps[-1].double()
+    if fps.numel() > 2:
+        d2f = fps[2:] - 2 * fps[1:-1] + fps[:-2]
+        d2t = tps[2:] - 2 * tps[1:-1] + tps[:-2]
+        one = torch.ones(1, dtype=torch.bool, device=fps.device)
+        keep = torch.cat([one, (d2f != 0) | (d2t != 0), one])
+        fps, tps, thr = fps[keep], tps[keep], thr[keep]
+    fpr = torch.cat([fps.new_zeros(1), fps]).double() / Nn
+    tpr = torch.cat([tps.new_zeros(1), tps]).double() / P
+    thr = torch.cat([thr.new_full((1,), float("inf")), thr])
+    auroc = torch.sum((fpr[1:] - fpr[:-1]) * (tpr[1:] + tpr[:-1]) * 0.5)
+    above = torch.nonzero(tpr > 0.95).reshape(-1)
+    if above.numel():
+        return float(auroc), float(fpr[above[0]]), float(thr[above[0]])
+    return float(auroc), 0, float(thr[-1])
+
+
+@torch.no_grad()
 def select_labelled(anomaly_score: torch.Tensor, ood_gts: torch.Tensor):
     """Keep pixels labelled 0 (inlier) or 1 (OoD); everything else (255) is ignored (support.py:275-285)."""
     s = anomaly_score.reshape(-1)

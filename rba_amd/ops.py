@@ -5,6 +5,8 @@ Error behaviour mirrors the reference's native op (pixel_decoder/ops/src/cuda/ms
 AT_ASSERTM on contiguity and device -> RuntimeError): a bad argument raises RuntimeError (RbaHipError); there is
 no fallback path.
 """
+import functools
+
 import torch
 
 from . import _lib
@@ -12,7 +14,39 @@ from ._lib import RbaHipError
 
 
 def _stream():
+    """The HIP stream a kernel is enqueued on: torch's current stream of the CURRENT device -- which `_hip_op` has made the
+    device of the call's tensors."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _cuda_tensors(args):
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                yield a
+        elif isinstance(a, (list, tuple)):
+            yield from _cuda_tensors(a)
+        elif isinstance(a, torch.nn.Module):
+            yield from (p_ for p_ in a.parameters(recurse=False) if p_.is_cuda)
+
+
+def _hip_op(fn):
+    """Every launch wrapper: all device tensors of a call must live on ONE HIP device (RbaHipError otherwise), and the call
+    runs with that device current, so outputs, workspaces, `_stream()` and the kernel all refer to the tensors' device and its
+    current stream -- also when the caller never called torch.cuda.set_device (get_model(device="cuda:1"))."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for t in _cuda_tensors(args + tuple(kwargs.values())):
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RbaHipError(f"{fn.__name__}: tensors on different devices ({dev} and {t.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _chk(t, name, dtype=torch.float32, dim=None):
@@ -47,13 +81,14 @@ _K1_WORKSPACES = {}
 
 def _k1_workspace(device):
     """8 zeroed bytes per (device, stream) for K1's dynamic tile counter (the kernel leaves them zero)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream())                      # called under _hip_op: the current device IS `device`
     ws = _K1_WORKSPACES.get(key)
     if ws is None:
         ws = _K1_WORKSPACES[key] = torch.zeros(2, dtype=torch.int32, device=device)
     return ws
 
 
+@_hip_op
 def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False, score="rba"):
     """K1.  mask_pred [Q,H,W] full-resolution mask logits, cls_prob [Q,K] -> (rba [H,W], sem_seg [K,H,W] | None,
     argmax int32 [H,W] | None).  maskformer_model.py:381-386 + evaluate_ood.py:150 + support.py:385-388."""
@@ -73,6 +108,7 @@ def rba_reduce(mask_pred, cls_prob, want_sem_seg=False, want_argmax=False, score
     return rba, sem, arg
 
 
+@_hip_op
 def rba_reduce_up4(mask_lowres, cls_prob, crop_hw, want_sem_seg=False, want_argmax=False, score="rba"):
     """K1 fused with the x4 upsample (maskformer_model.py:294-299) and the crop (:330-332).
     mask_lowres [Q,h,w]; outputs are [crop_h, crop_w] of the virtual [4h,4w] map."""
@@ -91,6 +127,7 @@ def rba_reduce_up4(mask_lowres, cls_prob, crop_hw, want_sem_seg=False, want_argm
     return rba, sem, arg
 
 
+@_hip_op
 def resample_bilinear(x, size, add=None):
     """F.interpolate(x, size, mode="bilinear", align_corners=False) for x [C,h,w] or [B,C,h,w]; optional fused
     `+ add` (the FPN top-down sum of msdeformattn.py:358)."""
@@ -114,6 +151,7 @@ def resample_bilinear(x, size, add=None):
     return out
 
 
+@_hip_op
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
                            im2col_step=128):
     """K2.  Same signature and checks as MultiScaleDeformableAttention.ms_deform_attn_forward
@@ -145,6 +183,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+@_hip_op
 def masked_xattn(q, k, v, mask_logits=None, split_keys=None):
     """K3.  q [B,Q,nH,hd] (unscaled), k, v [B,S,nH,hd], mask_logits [B,Q,S] | None -> [B,Q,nH*hd].
     split_keys: use the split-key matrix-pipe path (needs a scratch buffer, allocated here); None = automatic
@@ -172,6 +211,7 @@ def masked_xattn(q, k, v, mask_logits=None, split_keys=None):
     return out
 
 
+@_hip_op
 def mask_logits(embed, feat):
     """K4.  einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479): embed [B,Q,C], feat [B,C,h,w]."""
     lib = _lib.load()
@@ -191,6 +231,7 @@ def mask_logits(embed, feat):
     return out
 
 
+@_hip_op
 def swin_bias_fragments(rel_bias, window_size):
     """[nH,N,N] gathered relative-position bias -> the MFMA-fragment-ordered copy K5 reads with coalesced loads."""
     lib = _lib.load()
@@ -203,6 +244,7 @@ def swin_bias_fragments(rel_bias, window_size):
     return frag
 
 
+@_hip_op
 def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shift, bias_frag=None):
     """K5.  qkv [B,H*W,3*C] = Linear(norm1(x)) on un-padded tokens, qkv_bias [3*C], rel_bias [nH,N,N] ->
     attention output [B,H*W,C] (before proj).  swin.py:131-171 + :251-284 + :413-440."""
@@ -228,6 +270,7 @@ def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shif
     return out
 
 
+@_hip_op
 def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     """GroupNorm (+ReLU) of x [B,C,h,w] -- the norm/activation of Detectron2's Conv2d wrapper
     (msdeformattn.py:222-235, 278-297)."""
@@ -246,6 +289,7 @@ def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     return y
 
 
+@_hip_op
 def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None, inplace_sum=False):
     """y = LayerNorm(x + residual + residual_bias) over the last dim.  Returns (s, y) where s = the summed tensor
     (x itself when there is nothing to add; written in place over x when inplace_sum, else a new tensor)."""
@@ -274,6 +318,7 @@ def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None,
     return s, y
 
 
+@_hip_op
 def skinny_linear(x, weight, bias=None, relu=False):
     """F.linear(x, weight, bias) [+ ReLU] for x with at most 128 rows (the decoder's 100 queries): [..., K] -> [..., N]."""
     lib = _lib.load()
@@ -294,6 +339,7 @@ def skinny_linear(x, weight, bias=None, relu=False):
     return out
 
 
+@_hip_op
 def split_weight(weight):
     """fp32 weight [N,K] -> the three bf16 planes (hi, mid, lo; their sum is exactly `weight`) packed as the kernel's LDS
     tiles: [N/128, K/16, 3, 128, 2, 8] bf16, the 8-element half h of row r in slot h ^ ((r >> 3) & 1).  Once per weight load."""
@@ -307,6 +353,7 @@ def split_weight(weight):
     return packed
 
 
+@_hip_op
 def unpack_split_weight(packed):
     """Inverse of split_weight's tiling: -> planes [3, Np, K] bf16, Np = N rounded up to 128 (for inspection and tests)."""
     nt, S = packed.shape[:2]
@@ -330,6 +377,7 @@ def split_linear_pays(M, N, K, gelu=False):
     return tiles >= 256
 
 
+@_hip_op
 def linear(x, lin, use_bias=True, gelu=False, relu=False):
     """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the bf16x6
     kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise."""
@@ -349,6 +397,7 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False):
     return torch.nn.functional.gelu(y) if gelu else (torch.relu(y) if relu else y)
 
 
+@_hip_op
 def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False):
     """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe.
     ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
@@ -371,6 +420,7 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False
     return out
 
 
+@_hip_op
 def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
     """x [B*P, K] (NHWC rows) -> [B, N, P]: the Linear of split_linear written channel-major (NHWC in, NCHW out)."""
     lib = _lib.load()
@@ -391,6 +441,7 @@ def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
     return out
 
 
+@_hip_op
 def conv3x3_weight(weight):
     """conv weight [N, C, 3, 3] -> split_weight of the implicit-GEMM matrix [N, 9 C], k = (3 ky + kx) C + c."""
     _chk(weight, "weight", dim=4)
@@ -400,6 +451,7 @@ def conv3x3_weight(weight):
     return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous())
 
 
+@_hip_op
 def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     """3x3, stride 1, pad 1 convolution of NHWC x [B,H,W,C] with conv3x3_weight(W) -> [B,H,W,N] (implicit GEMM, bf16x6)."""
     lib = _lib.load()
@@ -419,6 +471,7 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     return out
 
 
+@_hip_op
 def group_norm_nhwc(x, num_groups, weight, bias, eps=1e-5, relu=False):
     """GroupNorm (+ReLU) of channels-last x [B, P, C] (or [B, H, W, C]): the same operator as group_norm on the token layout."""
     lib = _lib.load()
@@ -439,6 +492,7 @@ def group_norm_nhwc(x, num_groups, weight, bias, eps=1e-5, relu=False):
     return y
 
 
+@_hip_op
 def resample_bilinear_nhwc(x, size, add=None):
     """F.interpolate(mode="bilinear", align_corners=False) of channels-last x [h, w, C] -> [H, W, C], optional fused `+ add`."""
     lib = _lib.load()
@@ -457,6 +511,7 @@ def resample_bilinear_nhwc(x, size, add=None):
     return out
 
 
+@_hip_op
 def gaussian_blur(score, kernel_size=7, sigma=1.0):
     """transforms.GaussianBlur(kernel_size, sigma) of a score map [H,W] (reflect padding): the evaluator's optional smoothing."""
     lib = _lib.load()
@@ -469,6 +524,7 @@ def gaussian_blur(score, kernel_size=7, sigma=1.0):
     return out
 
 
+@_hip_op
 def ood_components(score, threshold, min_dummy=None):
     """Open-set panoptic epilogue of a score map [H,W] (maskformer_model.py:454-474): binary = score > threshold, 3x3 opening
     then closing, 4-connected components.  Returns (labels int32 [H,W] with 0 = background and components numbered 1..n in

@@ -22,6 +22,12 @@ class OODEvaluator:
     def get_anomaly_score(self, x, **kwargs):
         return self.anomaly_score_func(self.model, x, **kwargs)
 
+    def calculate_auroc(self, conf, gt):
+        """-> (auroc, fpr at the first tpr > 0.95, the threshold there) (support.py:247-257)."""
+        from .metrics import roc_at_tpr95
+        dev = getattr(self.model, "device", torch.device("cpu")) if self.model is not None else torch.device("cpu")
+        return roc_at_tpr95(torch.as_tensor(conf, device=dev), torch.as_tensor(gt, device=dev))
+
     def calculate_ood_metrics(self, out, label):
         """-> (auroc, aupr, fpr95) for flat score / {0,1} label arrays (support.py:259-268)."""
         dev = getattr(self.model, "device", torch.device("cpu")) if self.model is not None else torch.device("cpu")
@@ -52,9 +58,10 @@ class OODEvaluator:
                 break
             x = x.to(device)
             ood_gts.append(np.asarray(y.cpu()))
-            if return_preds and hasattr(self.model, "rba_scores") and self.anomaly_score_func.__name__ == "get_RbA":
+            mode = getattr(self.anomaly_score_func, "rba_score_mode", None)     # set on rba_amd.evaluate_ood's score functions
+            if return_preds and mode is not None and hasattr(self.model, "rba_scores"):
                 # one forward instead of the reference's two (support.py:380,386)
-                score, preds = self.model.rba_scores([{"image": x[0]}], return_argmax=True)[0]
+                score, preds = self.model.rba_scores([{"image": x[0]}], return_argmax=True, score=mode)[0]
                 predictions.append(preds.to(torch.int64).unsqueeze(0).cpu().numpy())
             else:
                 score = self.get_anomaly_score(x)
@@ -68,3 +75,19 @@ class OODEvaluator:
         if return_preds:
             return anomaly_score, ood_gts, np.array(predictions)
         return anomaly_score, ood_gts
+
+    def evaluate_ood_bootstrapped(self, dataset, ratio, trials, device=torch.device("cpu"), batch_size=1, num_workers=10):
+        """Metrics over `trials` random subsets of ratio * len(dataset) images -> (means, stds) in percent
+        (support.py:305-351; np.random.choice without replacement, as there)."""
+        from torch.utils.data import DataLoader, Subset
+        results = {}
+        n = len(dataset)
+        for _ in range(trials):
+            idx = np.random.choice(np.arange(n), int(n * ratio), replace=False)
+            loader = DataLoader(Subset(dataset, idx.tolist()), batch_size=batch_size, num_workers=num_workers)
+            score, gts = self.compute_anomaly_scores(loader=loader, device=device, return_preds=False)
+            for k, v in self.evaluate_ood(score, gts, verbose=False).items():
+                results.setdefault(k, []).append(v)
+        means = {k: float(np.mean(v)) * 100.0 for k, v in results.items()}
+        stds = {k: float(np.std(v)) * 100.0 for k, v in results.items()}
+        return means, stds

@@ -67,9 +67,11 @@ def test_relative_position_index_matches_reference(golden):
     assert np.array_equal(relative_position_index(6).numpy(), g["wa_sd.relative_position_index"])
 
 
-@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90"])
+@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90", "g5_swin_b_1dl_1024x2048", "g5_swin_b_9dl_720x1280",
+                                  "g5_swin_l_1dl_1024x2048"])
 def test_model_state_dict_contract(golden, name):
-    """our module tree has exactly the reference's state-dict keys and shapes (the model_final.pth contract)"""
+    """our module tree has exactly the reference's state-dict keys and shapes (the model_final.pth contract) -- the toy
+    architectures and the released ones (Swin-B 1dl / 9dl, Swin-L 1dl: MODEL_ZOO.md:54-69)"""
     from rba_amd.maskformer_model import MaskFormer
     g = golden(name)
     m = MaskFormer(A.ARCHS[str(g["arch"])])
@@ -192,3 +194,13 @@ def test_metric_exchange_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('"ok": true') == 2
+
+
+def test_bench_self_launch_refuses_without_devices():
+    """`python bench.py --gpus 2` outside torchrun spawns its own ranks; with fewer visible devices than ranks it says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RBA_BENCH_SHARE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible: the launch would really run")
+    assert r.returncode != 0 and "visible HIP device" in r.stderr

@@ -97,25 +97,55 @@ def test_evaluator_surface_tiny(golden, tmp_path):
 
 
 def _full_size(golden, fixture, arch_name, tol_rba):
+    """Whole-map parity at a BASELINE size on BOTH K1 paths (fused x4 up-sample = the product default; materialised planes =
+    the path bench.py times): sampled pixels, a strided 64x128 sub-grid, row / column / 16x16-block sums of the score map and
+    the COMPLETE argmax map -- a flip is forgiven only at a pixel whose two best classes are closer than 1e-4 in the
+    reference's own output (their indices are in the fixture), and the count of flips is asserted, not printed."""
     g = golden(fixture)
     model, a, sd = build(arch_name, int(g["seed"]))
     h, w = (int(v) for v in g["hw"])
     gen = torch.Generator().manual_seed(int(g["img_seed"]))
     image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
     mask_cls, mask_pred, _, _ = model.predict([{"image": image}])
-    rba, arg = model.rba_scores([{"image": image}], return_argmax=True)[0]
     ys, xs, ys4, xs4 = (T(g[k]).long() for k in ("ys", "xs", "ys4", "xs4"))
+    gy, gx = T(g["gy"]).long(), T(g["gx"]).long()
     e_logits = maxerr(mask_cls[0], g["pred_logits"])
     e_masks = maxerr(mask_pred[0].cpu()[:, ys4, xs4], g["pred_masks_s"])
-    e_rba = maxerr(rba.cpu()[ys, xs], g["rba_s"])
-    sem_s = T(g["sem_s"])
-    top2 = sem_s.topk(2, dim=0).values
-    flips = arg.cpu().long()[ys, xs] != T(g["argmax_s"]).long()
-    bad = int((flips & ((top2[0] - top2[1]) > 1e-4)).sum())
-    print(f"{fixture}: |d logits| {e_logits:.2e} |d masks| {e_masks:.2e} |d rba| {e_rba:.2e} argmax flips {int(flips.sum())} (bad {bad}); "
-          f"attn-mask margin of the reference run {float(g['attn_mask_margin']):.1e}")
-    assert e_rba < tol_rba and bad == 0
-    assert abs(float(rba.double().sum()) - float(g["rba_stats"][0])) < 1e-4 * h * w * 0.05
+    assert e_logits < 1e-4 and e_masks < 5e-4, (e_logits, e_masks)
+    ref_arg = T(g["argmax_full"].astype(np.int64))
+    tie = torch.zeros(h * w, dtype=torch.bool)
+    tie[T(g["neartie_idx"])] = True
+    tie = tie.view(h, w)
+    hb, wb = h // 16 * 16, w // 16 * 16
+    for fused in (True, False):
+        model.fused_upsample = fused
+        rba, arg = model.rba_scores([{"image": image}], return_argmax=True)[0]
+        rba, arg = rba.cpu(), arg.cpu().long()
+        assert rba.shape == (h, w) and arg.shape == (h, w)
+        e_rba = max(maxerr(rba[ys, xs], g["rba_s"]), maxerr(rba[gy][:, gx], g["grid_rba"]))
+        d = rba.double()
+        e_row = (d.sum(1) - T(g["row_sum"])).abs().max().item() / w             # mean error per pixel of the worst row
+        e_col = (d.sum(0) - T(g["col_sum"])).abs().max().item() / h
+        e_blk = (d[:hb, :wb].reshape(hb // 16, 16, wb // 16, 16).sum((1, 3)) - T(g["blk_sum"])).abs().max().item() / 256
+        flips = arg != ref_arg
+        bad = int((flips & ~tie).sum())
+        n_flips = int(flips.sum())
+        hist = torch.bincount(arg.flatten(), minlength=a["num_classes"])
+        d_hist = int((hist - T(g["argmax_hist"])).abs().sum())
+        print(f"{fixture} fused_upsample={fused}: |d logits| {e_logits:.2e} |d masks| {e_masks:.2e} |d rba| {e_rba:.2e} "
+              f"row/col/block mean err {e_row:.1e}/{e_col:.1e}/{e_blk:.1e}; argmax flips {n_flips} of {h * w} "
+              f"(outside the {int(tie.sum())} near-tie pixels: {bad}); attn-mask margin of the reference run "
+              f"{float(g['attn_mask_margin']):.1e}")
+        assert e_rba < tol_rba
+        assert max(e_row, e_col) < 2e-5 and e_blk < 5e-5, (e_row, e_col, e_blk)
+        assert bad == 0 and n_flips <= int(tie.sum())
+        assert d_hist <= 2 * n_flips
+        # sem_seg on the same sub-grid through the evaluator-facing forward (materialises [19, H, W])
+        if fused:
+            out = model([{"image": image}], return_argmax=True)[0]
+            assert maxerr(out["sem_seg"].cpu()[:, gy][:, :, gx], g["grid_sem"]) < 1e-4
+            assert torch.equal(out["rba"].cpu(), rba) and torch.equal(out["argmax"].cpu().long(), arg)
+            del out
 
 
 def test_full_size_swin_b_1dl_1024x2048(golden):
@@ -127,6 +157,11 @@ def test_swin_l_1dl_512x1024(golden):
     """BASELINE config C4's architecture (Swin-L: channel counts 192..1536, not multiples of the GEMM tile) against the reference's
     own modules at 512x1024."""
     _full_size(golden, "g5_swin_l_1dl_512x1024", "swin_l_1dl", 1e-4)
+
+
+def test_full_size_swin_l_1dl_1024x2048(golden):
+    """BASELINE config C4 at its real size: Swin-L, 1 decoder layer, 1024x2048."""
+    _full_size(golden, "g5_swin_l_1dl_1024x2048", "swin_l_1dl", 1e-4)
 
 
 def test_full_size_swin_b_9dl_720x1280(golden):
@@ -314,3 +349,44 @@ def test_open_panoptic_inference_vs_oracle():
     pan_g, info_g, ood = r["panoptic_seg"]
     assert pan_g.shape == (60, 90) and pan_g.dtype == torch.int32 and maxerr(ood, r["rba"].cpu()) < 1e-4
     assert sorted(s["id"] for s in info_g) == list(range(1, len(info_g) + 1)) and int(pan_g.max()) <= len(info_g)
+
+
+def test_bench_self_launch_two_ranks_share_device():
+    """`python bench.py --gpus 2` OUTSIDE torchrun spawns its own two ranks (here both on device 0, gloo): one JSON line with
+    n_gpus = 2, the metric exchange timed, and pooled metrics equal to the single-process metric over both ranks' images."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    from rba_amd.metrics import ood_metrics
+    h, w, steps, warm, nimg = 512, 1024, 2, 1, 2
+    env = dict(os.environ, RBA_BENCH_SHARE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
+                        "--streams", "1", "--n-images", str(nimg), "--height", str(h), "--width", str(w), "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == steps and res["scaling"] == "weak"
+    assert res["metric_exchange_ms"] > 0 and res["value"] > 0 and res["roofline"]["frac"] > 0
+    # single process: the last timed image of each rank (bench.py: image (warmup + steps - 1) % n_images, seed 1234 + 1000 rank + i)
+    model, a, _ = build("swin_b_1dl", 0)
+    model.fused_upsample = False
+    idx = (warm + steps - 1) % nimg
+    ss, ll = [], []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(1234 + rank * 1000 + idx)
+        image = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).cuda()
+        rba = model.rba_scores([{"image": image}])[0]
+        lab, valid = bench.exchange_inputs(rank, h, w, rba.device)
+        ss.append(rba[valid])
+        ll.append(lab[valid])
+    want = ood_metrics(torch.cat(ss), torch.cat(ll))
+    for k in want:
+        assert abs(res["pooled_metrics"][k] - want[k]) < 1e-9, (k, res["pooled_metrics"], want)
