@@ -2,8 +2,10 @@
  * rba_hip.h -- C ABI of librba_hip.so, the MI355X (gfx950) kernels on RbA's inference hot path.
  *
  * Conventions (all entry points):
- *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, no global state,
- *     re-entrant; tensors are dense row-major ("contiguous") in the index order written next to them;
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated; no environment variables are read and
+ *     there is no mutable global state (the only process-wide side effect is that the first launch of a kernel that needs
+ *     more than 64 KiB of LDS sets that kernel's hipFuncAttributeMaxDynamicSharedMemorySize once); re-entrant; tensors
+ *     are dense row-major ("contiguous") in the index order written next to them;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
  *   - return value is a hipError_t as int (0 = hipSuccess); argument errors return hipErrorInvalidValue (1);
  *   - fp32 everywhere (the reference op refuses half: pixel_decoder/msdeformattn.py:323,329).

@@ -1,4 +1,5 @@
-"""Build librba_hip.so (gfx950) in-tree with hipcc.  `python -m rba_amd.csrc.build [--force]`.
+"""Build librba_hip.so (gfx950) in-tree with hipcc.  `python -m rba_amd.csrc.build [--force] [--tune]`
+(--tune also builds tune/librba_tune.so, the tools-only library of probes and experimental kernel variants).
 Each .hip file is compiled to an object in parallel (hipcc --offload-arch=gfx950 -c), then linked with hipcc -shared."""
 import os
 import subprocess
@@ -6,9 +7,11 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["rba_reduce.hip", "rba_reduce_tune.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn.hip", "mask_logits.hip",
-           "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "gaussian_blur.hip", "open_panoptic.hip"]
-HEADERS = ["common.h", "rba_reduce_kernels.h", os.path.join("..", "..", "include", "rba_hip.h")]
+SOURCES = ["rba_reduce.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn.hip", "mask_logits.hip",
+           "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "split_linear_dma.hip", "gaussian_blur.hip", "open_panoptic.hip"]
+HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", os.path.join("..", "..", "include", "rba_hip.h")]
+TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip")]
+TUNE_LIB = os.path.join(HERE, "tune", "librba_tune.so")
 LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -50,5 +53,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_tune(force: bool = False, verbose: bool = True) -> str:
+    """librba_tune.so: probes, ablation builds and losing kernel variants, for tools/ only (never loaded by rba_amd)."""
+    deps = [os.path.join(HERE, f) for f in TUNE_SOURCES + HEADERS]
+    if not force and not _stale(TUNE_LIB, deps):
+        return TUNE_LIB
+    cmd = [HIPCC] + FLAGS + ["-shared"] + [os.path.join(HERE, f) for f in TUNE_SOURCES] + ["-o", TUNE_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return TUNE_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--tune" in sys.argv:
+        print(build_tune(force="--force" in sys.argv))

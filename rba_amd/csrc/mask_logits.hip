@@ -203,15 +203,9 @@ extern "C" int rba_mask_logits_f32(const float* embed, const float* feat, float*
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
   if (Q <= 112 && C % 4 == 0 && C <= 360 && N % 4 == 0 && ((((uintptr_t)feat | (uintptr_t)out | (uintptr_t)embed) & 15) == 0)) {
-    static const int variant = getenv("RBA_K4_VARIANT") ? atoi(getenv("RBA_K4_VARIANT")) : 0;   // tuning hook
-    if (variant == 1) return launch_mfma<4, 2>(embed, feat, out, B, Q, C, N, st);
-    if (variant == 2) return launch_mfma<8, 4>(embed, feat, out, B, Q, C, N, st);
-    if (variant == 3) return launch_mfma<4, 4>(embed, feat, out, B, Q, C, N, st);
-    if (variant != 9) {
-      // 8 waves (512 columns) per block when that still gives every CU a block, else 4 waves
-      if ((N + 511) / 512 * B >= 256) return launch_mfma<8, 2>(embed, feat, out, B, Q, C, N, st);
-      return launch_mfma<4, 4>(embed, feat, out, B, Q, C, N, st);
-    }
+    // 8 waves (512 columns) per block when that still gives every CU a block, else 4 waves
+    if ((N + 511) / 512 * B >= 256) return launch_mfma<8, 2>(embed, feat, out, B, Q, C, N, st);
+    return launch_mfma<4, 4>(embed, feat, out, B, Q, C, N, st);
   }
   const bool vec2 = (N % 2 == 0) && ((((uintptr_t)feat | (uintptr_t)out) & 7) == 0);
   if (vec2) return launch<52, 2>(embed, feat, out, B, Q, C, N, st);

@@ -9,7 +9,7 @@
 // launch: 4*Q*HW + 4*Q*K + 4*HW (+ 4*K*HW with sem_seg, + 4*HW with argmax).  Measured: ~170 us = 62 % of 8 TB/s at
 // Q=100, K=19, 1024x2048, HBM traffic 1.005x algorithmic; the remaining gap to the 128 us of the load pattern is VALU
 // time (see DESIGN.md and profiles/r01_k1_bandwidth_probes.txt).  Kernels live in rba_reduce_kernels.h; probes and
-// experimental variants in rba_reduce_tune.hip.
+// experimental variants in tune/rba_reduce_tune.hip (built into librba_tune.so for tools/, not into this library).
 #include "rba_reduce_kernels.h"
 
 using namespace rba_k1;
@@ -25,18 +25,6 @@ static int reduce_impl(const float* mask, const float* cls_prob, float* rba, flo
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (HW % 4 == 0) && ((((uintptr_t)mask | (uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
-  // opt-in (RBA_K1_VARIANT=mfma, A/B hook): score-only RbA with 16 <= K <= 20 on the matrix pipe (wave-private LDS
-  // transposition).  Inside the pipeline it measured 195 us against 172 us for the VALU kernel below, so it is not the default.
-  static const bool k1_mfma = getenv("RBA_K1_VARIANT") && getenv("RBA_K1_VARIANT")[0] == 'm';
-  if (k1_mfma && vec4 && mode == 0 && !sem_seg && !argmax && K >= 16 && K <= 20 && Q <= 800) {
-    switch (K - 16) {
-      case 0: return launch_reduce_mfma_wl<0, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
-      case 1: return launch_reduce_mfma_wl<1, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
-      case 2: return launch_reduce_mfma_wl<2, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
-      case 3: return launch_reduce_mfma_wl<3, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
-      default: return launch_reduce_mfma_wl<4, 2>(mask, cls_prob, rba, Q, K, HW, 8, st);
-    }
-  }
   // K = 19 / 20 (Cityscapes without / with void): compile-time K, packed FMAs, 2-deep prefetch ring, 4 workgroups per CU
   if (K == 19 && vec4) return launch_reduce_pk<19, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, mode, counters, st);
   if (K == 20 && vec4) return launch_reduce_pk<20, 2, 4>(mask, cls_prob, rba, sem_seg, argmax, Q, HW, mode, counters, st);

@@ -1,0 +1,27 @@
+// K6 -- fp32-accurate Linear on the bf16 matrix pipe ("bf16x6"): product dispatch of rba_split_linear_f32 onto the all-LDS-DMA
+// kernels of split_linear_dma.h.  (reference: the nn.Linear calls of backbone/swin.py:44-71, :131-171, :319-343.)
+// Configurations (tools/gemm_v4_sweep.py on every Swin-B / Swin-L / C5 token shape, profiles/r02_split_linear.txt):
+//   * default: 128 x 128 tile, 4 MFMA waves (32 rows x 128 columns each) + 4 loader waves, two 16-wide k sub-stages per barrier,
+//     ring of two super-buffers (80 KB LDS, two workgroups per CU);
+//   * fewer than 256 such tiles (Swin stage 4 at one image): 128 x 64 tiles, persistent workgroups -- twice the workgroups, so every
+//     CU still gets two.
+#include "split_linear_dma.h"
+
+extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
+                                    int K, int act, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0 && act >= 0 && act <= 2);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_planes && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_planes | (uintptr_t)out) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_planes);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  int rc;
+  if (tiles128 < 256 && N > 64 && (K >> 5) >= 2)
+    rc = launch_v5_act<1, 2, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 2, st);
+  else
+    rc = launch_v4_act<1, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, st);
+  if (rc) return rc;
+  return rba_launch_status();
+}

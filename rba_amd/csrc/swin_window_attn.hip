@@ -374,18 +374,10 @@ extern "C" int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias,
   if (hd == 32) {                                   // matrix-pipe path for the window sizes in use
     const int NT = (N + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
-    if (NT == 9) {
-      static const int variant = getenv("RBA_K5_WAVES") ? atoi(getenv("RBA_K5_WAVES")) : 9;   // tuning hook (tools/k5_sweep.py)
-      if (variant == 4) return launch_mfma<9, 4>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
-      if (variant == 5) return launch_mfma<9, 5>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
-      if (variant == 3) return launch_mfma<9, 3>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
-      if (variant == 1) goto v1_path;
-      return launch_mfma<9, 9>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
-    }
+    if (NT == 9) return launch_mfma<9, 9>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
     if (NT == 4) return launch_mfma<4, 4>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
     if (NT == 3) return launch_mfma<3, 3>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
   }
-v1_path:
   const dim3 grid(Wp / ws, Hp / ws, B * nH);
 #define RBA_L(D) hipLaunchKernelGGL(swin_window_attn_kernel<D>, grid, dim3(threads), shm, (hipStream_t)stream, qkv, qkv_bias, bias, out, H, W, Hp, Wp, nH, ws, shift, scale)
   if (hd == 16) RBA_L(16);

@@ -1,7 +1,7 @@
 // K1 tuning translation unit: bandwidth probes of the access pattern, VALU-isolation probes and the experimental kernel variants
 // (matrix-pipe, LDS-staged, lockstep ...) behind rba_reduce_f32_tune, used by tools/k1_sweep.py.  Nothing here is on the product
 // path; results are recorded in profiles/r01_k1_variant_sweep.txt and profiles/r01_k1_bandwidth_probes.txt.
-#include "rba_reduce_kernels.h"
+#include "../rba_reduce_kernels.h"
 
 using namespace rba_k1;
 

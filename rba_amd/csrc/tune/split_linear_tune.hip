@@ -1,0 +1,96 @@
+// Tuning entry points of K6's LDS-DMA kernels (tools/gemm_v4_sweep.py, tools/gemm_v5_timing.py): every tile configuration,
+// the ablation builds and the persistent variant.  Built into librba_tune.so (python -m rba_amd.csrc.build --tune); the product
+// library contains only the configurations rba_split_linear_f32 dispatches to.
+#include "../split_linear_dma.h"
+
+// Timing build of one v5 configuration (tools only): dbg[8 wg + {0..3}] = MFMA wave 0 {barrier wait, compute, epilogue, total}
+// cycles, dbg[8 wg + {4..7}] = loader wave 0 {vmcnt wait, barrier wait, issue, total} (s_memtime ticks).
+extern "C" int rba_split_linear_v5_timing(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
+                                          int K, int cfg, unsigned long long* dbg, void* stream) {
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_planes);
+#define RBA_T(RT, CT, G, D, L, WPC, MW)                                                                                              \
+  {                                                                                                                              \
+    constexpr int BM = 32 * RT * MW, BN = 32 * CT;                                                                               \
+    constexpr size_t dyn = (size_t)(D + 1) * G * (BM * 4 + 6 * BN) * 16;                                                         \
+    const int64_t MT = (M + BM - 1) / BM;                                                                                        \
+    const int NT = (N + BN - 1) / BN;                                                                                            \
+    (void)hipFuncSetAttribute((const void*)split_linear_v5_kernel<0, RT, CT, G, D, L, true, MW>,                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                                            \
+    int64_t grid = 256 * WPC;                                                                                                    \
+    grid = MT * NT < grid ? MT * NT : grid;                                                                                      \
+    if (((MT * NT) & 7) == 0 && grid >= 8) grid &= ~(int64_t)7;                                                                 \
+    hipLaunchKernelGGL((split_linear_v5_kernel<0, RT, CT, G, D, L, true, MW>), dim3((unsigned)grid), dim3(64 * (MW + L)), dyn,  \
+                       (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT, dbg);                                   \
+  }
+  if (cfg == 5401421) RBA_T(1, 4, 2, 1, 4, 2, 4)
+  else if (cfg == 5401413) RBA_T(1, 4, 1, 3, 4, 2, 4)
+  else if (cfg == 6402421) RBA_T(2, 4, 2, 1, 4, 1, 4)
+  else if (cfg == 8401421) RBA_T(1, 4, 2, 1, 4, 1, 8)
+  else if (cfg == 8801421) RBA_T(1, 4, 2, 1, 8, 1, 8)
+  else return (int)hipErrorInvalidValue;
+#undef RBA_T
+  return rba_launch_status();
+}
+
+// cfg = 100000 L + 1000 RT + 100 CT + 10 G + D (+ 10000 PROBE for the ablation builds)
+extern "C" int rba_split_linear_v4_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
+                                       int K, int act, int cfg, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0 && act >= 0 && act <= 2);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_planes && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_planes | (uintptr_t)out) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_planes);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (cfg) {
+    case 1421: rc = launch_v4_act<1, 4, 2, 1>(act, x, wp, bias, out, M, N, K, st); break;
+    case 1412: rc = launch_v4_act<1, 4, 1, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 1413: rc = launch_v4_act<1, 4, 1, 3>(act, x, wp, bias, out, M, N, K, st); break;
+    case 1221: rc = launch_v4_act<1, 2, 2, 1>(act, x, wp, bias, out, M, N, K, st); break;
+    case 1222: rc = launch_v4_act<1, 2, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 1612: rc = launch_v4_act<1, 6, 1, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 2411: rc = launch_v4_act<2, 4, 1, 1>(act, x, wp, bias, out, M, N, K, st); break;
+    case 201421: rc = launch_v4_act<1, 4, 2, 1, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 401421: rc = launch_v4_act<1, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 201412: rc = launch_v4_act<1, 4, 1, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 201413: rc = launch_v4_act<1, 4, 1, 3, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 401413: rc = launch_v4_act<1, 4, 1, 3, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 101413: rc = launch_v4_act<1, 4, 1, 3, 1>(act, x, wp, bias, out, M, N, K, st); break;
+    case 201612: rc = launch_v4_act<1, 6, 1, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 201222: rc = launch_v4_act<1, 2, 2, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 202411: rc = launch_v4_act<2, 4, 1, 1, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 402411: rc = launch_v4_act<2, 4, 1, 1, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    // persistent (v5): 5000000 + 100000 L + ...; 6000000 + ...: one workgroup per CU
+    case 5201421: rc = launch_v5_act<1, 4, 2, 1, 2>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5401421: rc = launch_v5_act<1, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5201413: rc = launch_v5_act<1, 4, 1, 3, 2>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5401413: rc = launch_v5_act<1, 4, 1, 3, 4>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5401412: rc = launch_v5_act<1, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5201612: rc = launch_v5_act<1, 6, 1, 2, 2>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5401222: rc = launch_v5_act<1, 2, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 5201222: rc = launch_v5_act<1, 2, 2, 2, 2>(act, x, wp, bias, out, M, N, K, 2, st); break;
+    case 7401421: rc = launch_v5_act<1, 4, 2, 1, 4, 4, true>(act, x, wp, bias, out, M, N, K, 2, st); break;    // 16-byte stores
+    case 8801421: rc = launch_v5_act<1, 4, 2, 1, 8, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;          // 8 + 8 waves
+    case 8801413: rc = launch_v5_act<1, 4, 1, 3, 8, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 8801621: rc = launch_v5_act<1, 6, 2, 1, 8, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 5801421: rc = launch_v5_act<1, 4, 2, 1, 8, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;          // 4 + 8 waves, 1 per CU
+    case 5401422: rc = launch_v5_act<1, 4, 2, 2, 4, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 8401421: rc = launch_v5_act<1, 4, 2, 1, 4, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;          // 8 MFMA waves, 256 x 128
+    case 8401413: rc = launch_v5_act<1, 4, 1, 3, 4, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 8401412: rc = launch_v5_act<1, 4, 1, 2, 4, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 8201421: rc = launch_v5_act<1, 4, 2, 1, 2, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 8401621: rc = launch_v5_act<1, 6, 2, 1, 4, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;          // 256 x 192
+    case 8401821: rc = launch_v5_act<1, 8, 2, 1, 4, 8>(act, x, wp, bias, out, M, N, K, 1, st); break;          // 256 x 256
+    case 6402412: rc = launch_v5_act<2, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 6402421: rc = launch_v5_act<2, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 6401422: rc = launch_v5_act<1, 4, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
+#define RBA_PROBE(P) case 1421 + 10000 * P: rc = launch_v4<0, 1, 4, 2, 1, P>(x, wp, bias, out, M, N, K, st); break;
+    RBA_PROBE(1) RBA_PROBE(2) RBA_PROBE(3) RBA_PROBE(4) RBA_PROBE(7) RBA_PROBE(8) RBA_PROBE(9) RBA_PROBE(15) RBA_PROBE(31) RBA_PROBE(16) RBA_PROBE(17)
+#undef RBA_PROBE
+    default: return (int)hipErrorInvalidValue;
+  }
+  if (rc) return rc;
+  return rba_launch_status();
+}

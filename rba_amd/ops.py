@@ -368,13 +368,13 @@ def split_linear_supported(N, K):
 
 
 def split_linear_pays(M, N, K, gelu=False):
-    """Where the bf16x6 kernel beats hipBLASLt's fp32 GEMM on MI355X (tools/gemm_sweep.py, profiles/r01_split_linear.txt):
-    1.25-1.5x whenever its 128 x 128 tiles fill the chip (>= 256 tiles) and K >= 128; always when that holds and the exact
-    GELU is fused into its epilogue.  Below that (Swin stage 4 at one image: 128 tiles) hipBLASLt's smaller tiles win."""
-    if not split_linear_supported(N, K) or K < 128:
+    """Where the bf16x6 kernel beats hipBLASLt's fp32 GEMM on MI355X (tools/gemm_v4_sweep.py, profiles/r02_split_linear.txt):
+    1.3-1.7x whenever there are at least 64 tiles of 128 x 128 (below 256 tiles the library switches to 128 x 64 tiles so that
+    every CU still gets work) and K >= 64.  Smaller problems (the single-level encoder at one image: 32 tiles) stay on hipBLASLt."""
+    if not split_linear_supported(N, K) or K < 64:
         return False
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    return tiles >= 256
+    return tiles >= 64
 
 
 @_hip_op

@@ -7,9 +7,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from rba_amd import _lib
+import _tune
 
-lib = _lib.load()
+lib = _tune.load()
 fn = lib.rba_reduce_f32_tune
 fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 Q, H, W = 100, 1024, 2048

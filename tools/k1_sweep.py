@@ -8,9 +8,9 @@ import torch
 
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rba_amd import _lib
+import _tune
 
-lib = _lib.load()
+lib = _tune.load()
 fn = lib.rba_reduce_f32_tune
 fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 fn.restype = ctypes.c_int

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time K4 (rba_mask_logits_f32): RBA_K4_VARIANT = 0 (mfma 8 waves PF2, default), 1, 2, 3 (mfma variants), 9 (v1 VALU)."""
+"""Time K4 (rba_mask_logits_f32) on the model shapes (the round-1 variant hook was removed with the losing variants)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,4 +16,4 @@ for (h, w) in ((256, 512), (184, 320)):
         if i >= 2: ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     fl = 2 * 100 * 256 * h * w
-    print(f"variant {os.environ.get('RBA_K4_VARIANT', '0')}: {h}x{w}: {ts[len(ts)//2]:7.1f} us  {fl / ts[len(ts)//2] / 1e6:6.1f} TFLOP/s  max|d| {(out.double() - ref).abs().max().item():.2e}")
+    print(f"{h}x{w}: {ts[len(ts)//2]:7.1f} us  {fl / ts[len(ts)//2] / 1e6:6.1f} TFLOP/s  max|d| {(out.double() - ref).abs().max().item():.2e}")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time K5 (rba_swin_window_attn_f32) on the four Swin-B stage shapes of a 1024x2048 image.
-RBA_K5_WAVES selects the tuning variant (1 = v1 VALU kernel, 3/4/5/9 = MFMA kernel with that many waves)."""
+(the round-1 RBA_K5_WAVES variant hook was removed with the losing variants)."""
 import os
 import sys
 
@@ -34,4 +34,4 @@ for (H, W, nH), reps, weight in zip(stages, (5, 5, 10, 10), (2, 2, 18, 2)):
         ts.sort()
         line.append(f"{H}x{W}/s{shift}: {ts[len(ts) // 2]:6.1f}us")
         tot += ts[len(ts) // 2] * weight / 2
-print(f"RBA_K5_WAVES={os.environ.get('RBA_K5_WAVES', '3')}: " + "  ".join(line) + f"  | per-image total {tot / 1e3:.2f} ms")
+print("  ".join(line) + f"  | per-image total {tot / 1e3:.2f} ms")

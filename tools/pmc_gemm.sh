@@ -1,10 +1,10 @@
-# PMC passes for the split-linear kernel (one shape): bash tools/pmc_gemm.sh M N K
+# PMC passes for the split-linear kernel (one shape): bash tools/pmc_gemm.sh M N K [v4 cfg]
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-M=${1:-8192}; N=${2:-2048}; K=${3:-512}
+M=${1:-8192}; N=${2:-2048}; K=${3:-512}; CFG=${4:-}
 run() { # name counters...
   n=$1; shift
-  timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/gp_$n -o p -- python $R/tools/gemm_one.py $M $N $K 3 > $R/gpurun_out/gp_$n.log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/gp_$n -o p -- python $R/tools/gemm_one.py $M $N $K 3 $CFG > $R/gpurun_out/gp_$n.log 2>&1
 }
 run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 run b SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
