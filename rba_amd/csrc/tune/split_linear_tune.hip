@@ -1,7 +1,7 @@
 // Tuning entry points of K6's LDS-DMA kernels (tools/gemm_v4_sweep.py, tools/gemm_v5_timing.py): every tile configuration,
 // the ablation builds and the persistent variant.  Built into librba_tune.so (python -m rba_amd.csrc.build --tune); the product
 // library contains only the configurations rba_split_linear_f32 dispatches to.
-#include "../split_linear_dma.h"
+#include "split_linear_experiments.h"
 
 // Timing build of one v5 configuration (tools only): dbg[8 wg + {0..3}] = MFMA wave 0 {barrier wait, compute, epilogue, total}
 // cycles, dbg[8 wg + {4..7}] = loader wave 0 {vmcnt wait, barrier wait, issue, total} (s_memtime ticks).
@@ -86,6 +86,23 @@ extern "C" int rba_split_linear_v4_f32(const float* x, const void* weight_planes
     case 6402412: rc = launch_v5_act<2, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
     case 6402421: rc = launch_v5_act<2, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
     case 6401422: rc = launch_v5_act<1, 4, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    // v8 (A direct, flag-synchronised ring, no barrier): 9500000 + 100 CT + 10 R + L
+    case 9500432: rc = launch_v8_act<4, 3, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9500434: rc = launch_v8_act<4, 3, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9500422: rc = launch_v8_act<4, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9500424: rc = launch_v8_act<4, 2, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9500232: rc = launch_v8_act<2, 3, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9500234: rc = launch_v8_act<2, 3, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9500431: rc = launch_v8_act<4, 3, 1>(act, x, wp, bias, out, M, N, K, st); break;
+    // v7 (A direct to registers): 9000000 + 100 CT + 10 D + L
+    case 9000412: rc = launch_v7_act<4, 1, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000414: rc = launch_v7_act<4, 1, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000422: rc = launch_v7_act<4, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000424: rc = launch_v7_act<4, 2, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000222: rc = launch_v7_act<2, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000224: rc = launch_v7_act<2, 2, 4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000622: rc = launch_v7_act<6, 2, 2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 9000822: rc = launch_v7_act<8, 1, 2>(act, x, wp, bias, out, M, N, K, st); break;
 #define RBA_PROBE(P) case 1421 + 10000 * P: rc = launch_v4<0, 1, 4, 2, 1, P>(x, wp, bias, out, M, N, K, st); break;
     RBA_PROBE(1) RBA_PROBE(2) RBA_PROBE(3) RBA_PROBE(4) RBA_PROBE(7) RBA_PROBE(8) RBA_PROBE(9) RBA_PROBE(15) RBA_PROBE(31) RBA_PROBE(16) RBA_PROBE(17)
 #undef RBA_PROBE
