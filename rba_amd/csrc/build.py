@@ -55,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 def build_tune(force: bool = False, verbose: bool = True) -> str:
     """librba_tune.so: probes, ablation builds and losing kernel variants, for tools/ only (never loaded by rba_amd)."""
-    deps = [os.path.join(HERE, f) for f in TUNE_SOURCES + HEADERS + [os.path.join("tune", "split_linear_experiments.h")]]
+    deps = [os.path.join(HERE, f) for f in TUNE_SOURCES + HEADERS + [os.path.join("tune", "split_linear_experiments.h"), os.path.join("tune", "rba_reduce_experiments.h")]]
     if not force and not _stale(TUNE_LIB, deps):
         return TUNE_LIB
     cmd = [HIPCC] + FLAGS + ["-shared"] + [os.path.join(HERE, f) for f in TUNE_SOURCES] + ["-o", TUNE_LIB]

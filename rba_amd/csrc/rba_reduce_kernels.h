@@ -599,4 +599,5 @@ int launch_reduce_mfma_wl(const float* mask, const float* prob, float* rba, int 
 }
 
 
+
 }  // namespace rba_k1

@@ -1,0 +1,391 @@
+// K1 experiments of round 2 that did NOT beat rba_reduce_pk_kernel (165 us, 63 % of 8 TB/s, tools/k1_sweep.py; counters in
+// profiles/r02_k1_matrix_pipe.txt): two formulations of the class contraction on the matrix pipe that need NO LDS transposition.
+//   mx (variant 200): bf16x6 MFMAs, 8 query planes x 4 pixels per lane = the 32x32x16 B fragment.   232-264 us (loads alone 198)
+//   mf (variant 210): exact-fp32 MFMAs, v_permlane32_swap builds the B fragment of two pixel halves. 270-278 us (loads alone 204)
+// Both are correct (max |d rba| 7.6e-6 at Q = 100, K = 19, 1024 x 2048) and both lose for the same reason: 64-128 accumulator
+// registers leave two waves per SIMD, and with 8 waves per CU even their bare load streams reach only 4.1-4.3 TB/s, where the VALU
+// kernel's 16 waves reach 6.6 TB/s.  Built only into librba_tune.so.
+#pragma once
+#include "../rba_reduce_kernels.h"
+
+namespace rba_k1 {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K1 on the matrix pipe without any transposition ("mx").  sem[k, p] = sum_q P[q, k] * sigmoid(mask[q, p]) is a GEMM with the
+// classes on M (19 padded to 32), the pixels on N and the queries on the reduction axis.  The B operand of
+// v_mfma_f32_32x32x16_bf16 wants, per lane, 8 CONSECUTIVE k (= queries) of ONE column (= pixel): lanes 0-31 hold k 0..7 and lanes
+// 32-63 k 8..15 of column lane % 32.  A lane that issues eight 16-byte loads -- plane q0 + 8 (lane / 32) + j, j = 0..7, at pixels
+// 4 (lane % 32) .. + 3 -- holds exactly that fragment for FOUR MFMAs (one per pixel of its quadruple): the loads stay 16 B per lane
+// and fully coalesced (two 512-byte runs per wave instruction), nothing goes through LDS, and the 19 x 100 multiply-adds per
+// pixel leave the VALU, which keeps the sigmoid (4 instructions) and the split of sigma into three bf16 (hi + mid + lo = sigma
+// exactly, as in K6; the class probabilities are split once per workgroup into LDS): ~9.5 VALU per mask element instead of ~16.
+// Six bf16 products per fp32 product keep fp32 accuracy (measured: |d sem| <= 2e-6 like the VALU kernel).
+// One wave = 128 pixels x all queries; accumulators D[class][pixel]: lane holds pixel 4 (lane % 32) + i of MFMA i, classes
+// 8 (r / 4) + 4 (lane / 32) + r % 4; the class reduction finishes with one cross-half shuffle.  Score only (no sem_seg / argmax
+// output): the bench / rba_scores() path.  Tiles are handed out per WAVE, four at a time, by an atomic counter (no barrier).
+typedef __bf16 mx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mx_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t mx_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t mx_pack(float x0, float x1) {
+  mx_bf16x2 v = {(__bf16)x0, (__bf16)x1};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// two values at a time, everything that has a packed form as v_pk_*: sigmoid = v_pk_mul, 2 v_exp, v_pk_add, 2 v_rcp (raw
+// v_exp_f32: exp2 of -x log2(e); an overflow to inf gives rcp(inf) = 0, an underflow to 0 gives 1 -- the limits of the sigmoid);
+// split = v_cvt_pk_bf16_f32, two unpack ops, v_pk_add (exact remainder), twice, and a last v_cvt_pk: 15 VALU per pair.
+__device__ __forceinline__ f32x2 mx_sigmoid2(f32x2 x) {
+  const f32x2 t = x * (f32x2){-1.44269504088896340736f, -1.44269504088896340736f};
+  const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + (f32x2){1.0f, 1.0f};
+  return (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ void mx_split2(f32x2 v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = mx_pack(v.x, v.y);
+  const f32x2 r = v - (f32x2){__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  m = mx_pack(r.x, r.y);
+  const f32x2 q = r - (f32x2){__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  l = mx_pack(q.x, q.y);
+}
+__device__ __forceinline__ void mx_split8(const float (&x)[8], mx_bf16x8& p0, mx_bf16x8& p1, mx_bf16x8& p2) {
+  mx_u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t a, b, c;
+    mx_split2((f32x2){x[2 * i], x[2 * i + 1]}, a, b, c);
+    h[i] = a;
+    m[i] = b;
+    l[i] = c;
+  }
+  p0 = __builtin_bit_cast(mx_bf16x8, h);
+  p1 = __builtin_bit_cast(mx_bf16x8, m);
+  p2 = __builtin_bit_cast(mx_bf16x8, l);
+}
+
+constexpr int MX_CHUNK = 4;                                        // 128-pixel tiles per dequeue (even: the step loop is unrolled by 2)
+
+// PROBE (tune builds; wrong results): 1 = loads only (the arithmetic replaced by one add per loaded register), 2 = arithmetic only
+// (every step re-uses the first tile's loads)
+template <int WPS, int PROBE = 0>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_mx_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                               float* __restrict__ rba, int Q, int K, int64_t HW, int ntiles, int mode,
+                                                               unsigned int* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) mx_u32x4 mx_pfrag[];          // [G][3 planes][64 lanes]: A fragments of P
+  const int G = (Q + 15) >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  for (int idx = tid; idx < G * 64; idx += 256) {
+    const int g = idx >> 6, l = idx & 63, m = l & 31, h = l >> 5;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = 16 * g + 8 * h + i;
+      x[i] = (q < Q && m < K) ? prob[q * K + m] : 0.f;
+    }
+    mx_bf16x8 p0, p1, p2;
+    mx_split8(x, p0, p1, p2);
+    mx_pfrag[(g * 3 + 0) * 64 + l] = __builtin_bit_cast(mx_u32x4, p0);
+    mx_pfrag[(g * 3 + 1) * 64 + l] = __builtin_bit_cast(mx_u32x4, p1);
+    mx_pfrag[(g * 3 + 2) * 64 + l] = __builtin_bit_cast(mx_u32x4, p2);
+  }
+  __syncthreads();
+
+  const int nchunks = (ntiles + MX_CHUNK - 1) / MX_CHUNK;
+  const int S = MX_CHUNK * G;                                      // (tile, query group) steps per chunk
+  auto dequeue = [&]() -> int {
+    unsigned int c = 0;
+    if (lane == 0) c = atomicAdd(counters, 1u);
+    return (int)__builtin_amdgcn_readfirstlane(c);
+  };
+  // loads of step (tile t, group g): plane q = 16 g + 8 lh + j (clamped: the P fragment is zero there), pixels 4 l31 .. + 3 of tile t
+  auto load = [&](f32x4 (&buf)[8], int t, int g) {
+    if (PROBE == 2) { t = 0; g = 0; }
+    int64_t pix = (int64_t)t * 128 + 4 * l31;
+    pix = pix < HW ? pix : HW - 4;
+    const float* base = mask + pix;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int q = 16 * g + 8 * lh + j;
+      q = q < Q ? q : Q - 1;
+      buf[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (int64_t)q * HW));
+    }
+  };
+  mx_f32x16 acc[4];
+  auto compute = [&](const f32x4 (&buf)[8], int t, int g) {
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    if (PROBE == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] += buf[j][i];
+    } else {
+    mx_bf16x8 a[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = __builtin_bit_cast(mx_bf16x8, mx_pfrag[(g * 3 + p) * 64 + lane]);
+    // sigma and its three bf16 planes for all four pixels first, then the 24 MFMAs round-robin over the four accumulators: a
+    // dependent MFMA would otherwise stall the in-order wave (and every VALU instruction behind it) for its full latency
+    mx_bf16x8 b[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mx_u32x4 h, m, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t ha, ma, la;
+        mx_split2(mx_sigmoid2((f32x2){buf[2 * j][i], buf[2 * j + 1][i]}), ha, ma, la);
+        h[j] = ha;
+        m[j] = ma;
+        l[j] = la;
+      }
+      b[i][0] = __builtin_bit_cast(mx_bf16x8, h);
+      b[i][1] = __builtin_bit_cast(mx_bf16x8, m);
+      b[i][2] = __builtin_bit_cast(mx_bf16x8, l);
+    }
+#define RBA_MX(pa, pb) \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[i][pb], acc[i], 0, 0, 0);
+    RBA_MX(2, 0) RBA_MX(0, 2) RBA_MX(1, 1) RBA_MX(1, 0) RBA_MX(0, 1) RBA_MX(0, 0)      // smallest terms first
+#undef RBA_MX
+    }
+    if (g == G - 1) {                                              // ---- epilogue of tile t
+      // classes of this lane: 8 (r / 4) + 4 lh + r % 4; rows >= K are exactly 0 (zero P fragment): tanh(0) = 0 and 0 add nothing
+      float out[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float part = 0.f;
+        if (mode == 1) {
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, 8 * (r >> 2) + 4 * lh + (r & 3) < K ? acc[i][r] : -3.0e38f);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, RBA_WAVE));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part += 8 * (r >> 2) + 4 * lh + (r & 3) < K ? __expf(acc[i][r] - mx) : 0.f;
+          part += __shfl_xor(part, 32, RBA_WAVE);
+          out[i] = -(mx + __logf(part));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part += mode == 0 ? rba_tanh(acc[i][r]) : acc[i][r];
+          part += __shfl_xor(part, 32, RBA_WAVE);
+          out[i] = -part;
+        }
+      }
+      const int64_t pix = (int64_t)t * 128 + 4 * l31;
+      if (lh == 0 && pix < HW) *reinterpret_cast<f32x4*>(rba + pix) = (f32x4){out[0], out[1], out[2], out[3]};
+    }
+  };
+
+  f32x4 bufA[8], bufB[8];
+  int chunk = dequeue();
+  while (chunk < nchunks) {
+    const int nxt_chunk = dequeue();                               // one chunk ahead: its first loads overlap this chunk's last step
+    const int t0 = chunk * MX_CHUNK;
+    int t = t0, g = 0;
+    load(bufA, t < ntiles ? t : ntiles - 1, 0);
+    for (int s = 0; s < S; s += 2) {
+      int t1 = t, g1 = g + 1;
+      if (g1 == G) { g1 = 0; ++t1; }
+      load(bufB, t1 < ntiles ? t1 : ntiles - 1, g1);
+      if (t < ntiles) compute(bufA, t, g);
+      int t2 = t1, g2 = g1 + 1;
+      if (g2 == G) { g2 = 0; ++t2; }
+      if (s + 2 < S) load(bufA, t2 < ntiles ? t2 : ntiles - 1, g2);
+      if (t1 < ntiles) compute(bufB, t1, g1);
+      t = t2;
+      g = g2;
+    }
+    chunk = nxt_chunk;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int done = atomicAdd(counters + 1, 1u);
+    if (done == gridDim.x - 1) {                                   // every wave of every workgroup has fetched its last chunk
+      atomicExch(counters, 0u);
+      atomicExch(counters + 1, 0u);
+    }
+  }
+}
+
+template <int WPS, int PROBE = 0>
+int launch_reduce_mx(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int mode, unsigned int* counters,
+                     hipStream_t st) {
+  const int64_t tiles = (HW + 127) / 128;
+  if (tiles > 0x7fffffffLL || Q > 1024) return (int)hipErrorInvalidValue;
+  const int G = (Q + 15) / 16;
+  const size_t dyn = (size_t)G * 3 * 64 * 16;
+  const int64_t chunks = (tiles + MX_CHUNK - 1) / MX_CHUNK;
+  int64_t grid = 256 * WPS;
+  grid = chunks < grid * 4 ? (chunks + 3) / 4 : grid;
+  grid = grid < 1 ? 1 : grid;
+  hipLaunchKernelGGL((rba_reduce_mx_kernel<WPS, PROBE>), dim3((unsigned)grid), dim3(256), dyn, st, mask, prob, rba, Q, K, HW, (int)tiles, mode,
+                     counters);
+  return rba_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K1 with the class contraction on the EXACT-fp32 matrix pipe ("mf"): v_mfma_f32_32x32x2_f32, D[class][pixel] += P[q][class] *
+// sigma[q][pixel] for TWO queries per instruction, bitwise a k-ordered fmaf chain -- the same ascending-q order as the VALU kernels,
+// no operand splitting.  Loads keep the VALU kernels' pattern (lane l = pixels 4 l .. 4 l + 3 of ONE plane, 1 KiB contiguous per
+// wave instruction).  The MFMA B operand wants lanes 0-31 = query k0 and lanes 32-63 = query k1 of the SAME 32 pixels: one
+// v_permlane32_swap of the sigma registers of planes q and q + 1 produces exactly that for BOTH pixel halves of the wave's 256-pixel
+// tile (upper half of the first register <-> lower half of the second), so nothing goes through LDS and the VALU keeps only the
+// sigmoid (4 instructions per element) and one swap per dword.  Matrix-pipe time at Q = 100, K = 19 (padded to 32 rows): 93 us;
+// VALU ~35 us; both hide behind the 128 us the load pattern needs.  8 accumulators x 16 registers (AGPRs): 2 waves per SIMD,
+// latency covered by a 4-pair (8 KiB per wave) register ring.  Score only (no sem_seg / argmax output).
+typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MF_RING = 4;                                          // plane pairs in flight per wave
+constexpr int MF_CHUNK = 2;                                         // 256-pixel tiles per dequeue
+
+// Inline asm: with the builtin (ROCm 7.2) hipcc used the FIRST result register for both outputs (both MFMAs of a pair got the same
+// operand).  The two v_nop are the VALU-write -> permlane-read wait states, the trailing s_nop the VALU-write -> MFMA-operand ones.
+__device__ __forceinline__ void mf_swap(float& lo, float& hi) {     // lanes 32-63 of lo <-> lanes 0-31 of hi
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float mf_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+template <int WPS, int PROBE = 0>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_mf_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                               float* __restrict__ rba, int Q, int K, int64_t HW, int ntiles, int mode,
+                                                               unsigned int* __restrict__ counters) {
+  extern __shared__ float mf_afrag[];                               // [NPpad][64]: A operand of pair p, lane l: P[2 p + l / 32][l % 32]
+  const int NP = (Q + 1) >> 1, NPpad = (NP + MF_RING - 1) / MF_RING * MF_RING;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int idx = tid; idx < NPpad * 64; idx += 256) {
+    const int p = idx >> 6, l = idx & 63, q = 2 * p + (l >> 5), m = l & 31;
+    mf_afrag[idx] = (q < Q && m < K) ? prob[q * K + m] : 0.f;
+  }
+  __syncthreads();
+  const int nchunks = (ntiles + MF_CHUNK - 1) / MF_CHUNK;
+  auto dequeue = [&]() -> int {
+    unsigned int c = 0;
+    if (lane == 0) c = atomicAdd(counters, 1u);
+    return (int)__builtin_amdgcn_readfirstlane(c);
+  };
+  auto load = [&](f32x4 (&r)[2], int tile, int pair) {
+    if (PROBE == 2) { tile = 0; pair = 0; }
+    tile = tile < ntiles ? tile : ntiles - 1;
+    int64_t pix = (int64_t)tile * 256 + 4 * lane;
+    pix = pix < HW ? pix : HW - 4;
+    const int q0 = 2 * pair < Q ? 2 * pair : Q - 1, q1 = 2 * pair + 1 < Q ? 2 * pair + 1 : Q - 1;    // clamped planes meet a zero A operand
+    r[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mask + (int64_t)q0 * HW + pix));
+    r[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mask + (int64_t)q1 * HW + pix));
+  };
+  mf_f32x16 accA[4], accB[4];
+  auto compute = [&](const f32x4 (&r)[2], int tile, int pair) {
+    if (pair == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accA[c][i] = accB[c][i] = 0.f;
+    }
+    if (PROBE == 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { accA[c][0] += r[0][c]; accB[c][0] += r[1][c]; }
+    } else {
+      const float a = mf_afrag[pair * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s0 = mf_sigmoid(r[0][c]), s1 = mf_sigmoid(r[1][c]);
+        mf_swap(s0, s1);
+        accA[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s0, accA[c], 0, 0, 0);
+        accB[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s1, accB[c], 0, 0, 0);
+      }
+    }
+    if (pair == NPpad - 1 && tile < ntiles) {                       // ---- epilogue: rows (classes) >= K are exactly zero
+      f32x4 out;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float pa = 0.f, pb = 0.f;
+        if (mode == 1) {
+          float ma = -3.0e38f, mb = -3.0e38f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const bool ok = 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3) < K;
+            ma = fmaxf(ma, ok ? accA[c][i] : -3.0e38f);
+            mb = fmaxf(mb, ok ? accB[c][i] : -3.0e38f);
+          }
+          mf_swap(ma, mb);
+          const float mx = fmaxf(ma, mb);                           // lanes 0-31: max over all classes of set A, lanes 32-63: set B
+          float mxa = mx, mxb = mx;
+          mf_swap(mxa, mxb);                                        // now every lane has set A's max in mxa and set B's in mxb
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const bool ok = 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3) < K;
+            pa += ok ? __expf(accA[c][i] - mxa) : 0.f;
+            pb += ok ? __expf(accB[c][i] - mxb) : 0.f;
+          }
+          mf_swap(pa, pb);
+          out[c] = -(mx + __logf(pa + pb));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            pa += mode == 0 ? rba_tanh(accA[c][i]) : accA[c][i];
+            pb += mode == 0 ? rba_tanh(accB[c][i]) : accB[c][i];
+          }
+          mf_swap(pa, pb);                                          // lanes 0-31: both halves' set-A parts, lanes 32-63: set-B parts
+          out[c] = -(pa + pb);
+        }
+      }
+      const int64_t pix = (int64_t)tile * 256 + 4 * lane;
+      if (pix < HW) *reinterpret_cast<f32x4*>(rba + pix) = out;
+    }
+  };
+
+  f32x4 ring[MF_RING][2];
+  int chunk = dequeue();
+  int lt = chunk * MF_CHUNK, lp = 0;                                // loader cursor (tile, pair), MF_RING steps ahead of the compute cursor
+  int nxt_chunk = dequeue();
+#pragma unroll
+  for (int k = 0; k < MF_RING; ++k) load(ring[k], lt, lp++);        // NPpad >= MF_RING: still inside the first tile
+  while (chunk < nchunks) {
+    int ct = chunk * MF_CHUNK, cp = 0;
+    const int chunk_end = (chunk + 1) * MF_CHUNK;
+    const int S = MF_CHUNK * NPpad;
+    for (int s = 0; s < S; s += MF_RING) {
+#pragma unroll
+      for (int k = 0; k < MF_RING; ++k) {
+        compute(ring[k], ct, cp);
+        if (++cp == NPpad) { cp = 0; ++ct; }
+        // the loader cursor crosses into the next chunk MF_RING steps before this chunk ends
+        load(ring[k], lt, lp);
+        if (++lp == NPpad) {
+          lp = 0;
+          if (++lt == chunk_end) lt = nxt_chunk * MF_CHUNK;         // run on into the next chunk (load() clamps when there is none)
+        }
+      }
+    }
+    chunk = nxt_chunk;
+    nxt_chunk = dequeue();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int done = atomicAdd(counters + 1, 1u);
+    if (done == gridDim.x - 1) {
+      atomicExch(counters, 0u);
+      atomicExch(counters + 1, 0u);
+    }
+  }
+}
+
+template <int WPS, int PROBE = 0>
+int launch_reduce_mf(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, int mode, unsigned int* counters,
+                     hipStream_t st) {
+  const int64_t tiles = (HW + 255) / 256;
+  if (tiles > 0x3fffffffLL || Q > 2048 || K > 32) return (int)hipErrorInvalidValue;
+  const int NP = (Q + 1) / 2, NPpad = (NP + MF_RING - 1) / MF_RING * MF_RING;
+  const size_t dyn = (size_t)NPpad * 64 * 4;
+  const int64_t chunks = (tiles + MF_CHUNK - 1) / MF_CHUNK;
+  int64_t grid = 256 * WPS;
+  grid = chunks < grid * 4 ? (chunks + 3) / 4 : grid;
+  grid = grid < 1 ? 1 : grid;
+  hipLaunchKernelGGL((rba_reduce_mf_kernel<WPS, PROBE>), dim3((unsigned)grid), dim3(256), dyn, st, mask, prob, rba, Q, K, HW, (int)tiles,
+                     mode, counters);
+  return rba_launch_status();
+}
+
+
+}  // namespace rba_k1

@@ -1,7 +1,7 @@
 // K1 tuning translation unit: bandwidth probes of the access pattern, VALU-isolation probes and the experimental kernel variants
 // (matrix-pipe, LDS-staged, lockstep ...) behind rba_reduce_f32_tune, used by tools/k1_sweep.py.  Nothing here is on the product
 // path; results are recorded in profiles/r01_k1_variant_sweep.txt and profiles/r01_k1_bandwidth_probes.txt.
-#include "../rba_reduce_kernels.h"
+#include "rba_reduce_experiments.h"
 
 using namespace rba_k1;
 
@@ -746,6 +746,27 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       const int fine = (all - coarse) * 4;
       hipLaunchKernelGGL((rba_reduce_hybrid_kernel<19, 2, 4>), dim3(1024), dim3(256), 0, st, mask, cls_prob, rba, Q, HW, coarse, fine, ctr);
       return rba_launch_status();
+    }
+    case 210: case 211: case 212: {   // exact-fp32 MFMA kernel (rba_reduce_mf_kernel) / loads only / arithmetic only
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      if (variant == 210) return launch_reduce_mf<2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
+      if (variant == 211) return launch_reduce_mf<2, 1>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
+      return launch_reduce_mf<2, 2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
+    }
+    case 202: case 203: {   // ablations of the mx kernel: loads only / arithmetic only
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      return variant == 202 ? launch_reduce_mx<2, 1>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st)
+                            : launch_reduce_mx<2, 2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
+    }
+    case 200: case 201: {   // matrix-pipe kernel without transposition (rba_reduce_mx_kernel), 2 / 3 workgroups per CU
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      static bool zeroed2 = false;
+      if (!zeroed2) { hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st); zeroed2 = true; }
+      return variant == 200 ? launch_reduce_mx<2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st)
+                            : launch_reduce_mx<3>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
     }
     case 121: {   // the product kernel: packed, dynamic tile assignment through a (here: static device) workspace
       unsigned int* ctr = nullptr;
