@@ -27,6 +27,7 @@
  *                                  (backbone/swin.py:44-71, 131-171, 251-284)
  *   rba_skinny_linear_f32       <- nn.Linear / in_proj / MLP on the decoder's [100, B, 256] query tensors
  *                                  (mask2former_transformer_decoder.py:25-212)
+ *   rba_bn_relu_conv1x1_f32     <- BNReluConv(hidden_dim, 2, k=1) `ood_pred` head (mask2former_transformer_decoder.py:216-230, 467-468)
  *   rba_split_linear_f32        <- nn.Linear on the backbone's token tensors: qkv / proj / Mlp.fc1(+GELU) / Mlp.fc2 /
  *                                  PatchMerging.reduction (backbone/swin.py:44-71, 131-171, 319-343)
  *   rba_gaussian_blur_f32       <- transforms.GaussianBlur(7, sigma=1) on the anomaly map (support.py:366-383)
@@ -177,6 +178,14 @@ int rba_gaussian_blur_f32(const float* in, float* out, int H, int W, int kernel_
 int rba_threshold_u8(const float* score, uint8_t* out, int64_t n, float threshold, void* stream);
 int rba_morph3x3_u8(const uint8_t* in, uint8_t* out, int H, int W, int dilate, void* stream);
 int rba_ccl4_roots_i32(const uint8_t* mask, int32_t* roots, int H, int W, void* stream);
+
+/* DenseHybrid anomaly head (mask2former_transformer_decoder.py:216-230, 365-366, 467-468; maskformer_model.py:303-305).
+ * rba_bn_relu_conv1x1_f32:      out[b,o,p] = bias[o] + sum_c weight[o,c] * relu(x[b,c,p] * scale[c] + shift[c]); x [B,C,P], out [B,O,P],
+ *                               O in {1,2,4}; scale/shift = eval-mode BatchNorm2d folded by the caller; bias may be NULL.
+ * rba_resample_bilinear_ac_f32: F.interpolate(mode="bilinear", align_corners=True): x [C,h,w] -> out [C,H,W]. */
+int rba_bn_relu_conv1x1_f32(const float* x, const float* scale, const float* shift, const float* weight, const float* bias, float* out,
+                            int B, int C, int O, int64_t P, void* stream);
+int rba_resample_bilinear_ac_f32(const float* x, float* out, int C, int h, int w, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

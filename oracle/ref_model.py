@@ -89,6 +89,35 @@ def swin_backbone(x, sd, a, p="backbone"):
     return outs
 
 
+def resnet_backbone(x, sd, a, p="backbone"):
+    """Detectron2 v0.6 ResNet (modeling/backbone/resnet.py: BasicStem, BottleneckBlock, build_resnet_backbone) as configured by
+    configs/cityscapes/semantic-segmentation/Base-Cityscapes-SemanticSegmentation.yaml:8-15, inference mode.  Detectron2 is not in
+    the reference tree: restated from its published definition -- PARITY UNPINNED (no reference-generated fixture exists)."""
+    r = a["resnet"]
+
+    def convbn(x, q, stride=1, padding=0, relu=False):
+        y = F.conv2d(x, sd[q + ".weight"], None, stride=stride, padding=padding)
+        y = F.batch_norm(y, sd[q + ".norm.running_mean"], sd[q + ".norm.running_var"], sd[q + ".norm.weight"], sd[q + ".norm.bias"],
+                         False, 0.1, 1e-5)
+        return F.relu(y) if relu else y
+
+    x = F.max_pool2d(convbn(x, p + ".stem.conv1", 2, 3, True), kernel_size=3, stride=2, padding=1)
+    outs = {}
+    blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}[r["depth"]]
+    for i, nb in enumerate(blocks):
+        for b in range(nb):
+            q = f"{p}.res{i + 2}.{b}"
+            stride = (1 if i == 0 else 2) if b == 0 else 1
+            s1, s3 = (stride, 1) if r["stride_in_1x1"] else (1, stride)
+            out = convbn(x, q + ".conv1", s1, 0, True)
+            out = convbn(out, q + ".conv2", s3, 1, True)
+            out = convbn(out, q + ".conv3")
+            short = convbn(x, q + ".shortcut", stride) if (q + ".shortcut.weight") in sd else x
+            x = F.relu(out + short)
+        outs[f"res{i + 2}"] = x
+    return outs
+
+
 # ------------------------------------------------------------------------ pixel decoder
 def _gn(x, sd, p, groups=32):
     return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
@@ -214,6 +243,14 @@ def transformer_decoder(multi_scale, mask_features, sd, a, p="sem_seg_head.predi
     return cls, masks
 
 
+def ood_pred_head(mask_features, sd, p="sem_seg_head.predictor.ood_pred"):
+    """DenseHybrid head BNReluConv(hidden_dim, 2, k=1, bias=True) on the mask features, inference mode
+    (mask2former_transformer_decoder.py:216-230, 365-366, 467-468): BatchNorm2d (running statistics) -> ReLU -> 1x1 conv."""
+    x = F.batch_norm(mask_features, sd[p + ".norm.running_mean"], sd[p + ".norm.running_var"], sd[p + ".norm.weight"],
+                     sd[p + ".norm.bias"], False, 0.01, 1e-5)
+    return F.conv2d(F.relu(x), sd[p + ".conv.weight"], sd[p + ".conv.bias"])
+
+
 # ------------------------------------------------------------------------------ meta arch
 @torch.no_grad()
 def forward(image, sd, a, taps=None):
@@ -226,11 +263,16 @@ def forward(image, sd, a, taps=None):
     h, w = x.shape[-2:]
     H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
     x = F.pad(x, (0, W - w, 0, H - h))[None]
-    feats = swin_backbone(x, sd, a)
+    feats = resnet_backbone(x, sd, a) if a.get("resnet") else swin_backbone(x, sd, a)
     mask_features, multi_scale = pixel_decoder(feats, sd, a)
     cls, masks = transformer_decoder(multi_scale, mask_features, sd, a, taps=taps)
     up = R.upsample_bilinear(masks, (H, W))[0]
     sem = R.semantic_inference(cls[0], up)[:, :h, :w]
     if taps is not None:
         taps.update(feats=feats, mask_features=mask_features, multi_scale=multi_scale)
-    return dict(pred_logits=cls[0], pred_masks=masks[0], sem_seg=sem, rba=R.rba_score(sem), argmax=sem.max(dim=0)[1])
+    out = dict(pred_logits=cls[0], pred_masks=masks[0], sem_seg=sem, rba=R.rba_score(sem), argmax=sem.max(dim=0)[1])
+    if a.get("dense_hybrid", False):
+        # maskformer_model.py:303-305 (up-sampled to the image size with align_corners=True) + evaluate_ood.py:161-173
+        ood = F.interpolate(ood_pred_head(mask_features, sd), size=(h, w), mode="bilinear", align_corners=True)
+        out.update(ood_pred=ood, densehybrid=R.densehybrid_score(sem, ood))
+    return out

@@ -30,6 +30,14 @@ def rba_score(sem_seg: torch.Tensor) -> torch.Tensor:
     return -sem_seg.tanh().sum(dim=0)
 
 
+def densehybrid_score(sem_seg: torch.Tensor, ood_pred: torch.Tensor) -> torch.Tensor:
+    """get_densehybrid_score (evaluate_ood.py:161-173): -logsumexp_k(sem_seg) + log(softmax(ood_pred, 1)[:, 1] + 1e-9);
+    sem_seg [K,H,W], ood_pred [1,2,H,W] -> [1,H,W]."""
+    p1 = torch.logsumexp(sem_seg, dim=0)
+    p2 = F.softmax(ood_pred, dim=1)[:, 1]
+    return (-p1) + (p2 + 1e-9).log()
+
+
 def upsample_bilinear(x: torch.Tensor, size) -> torch.Tensor:
     """F.interpolate(mode="bilinear", align_corners=False) (maskformer_model.py:294-299;
     msdeformattn.py:358; mask2former_transformer_decoder.py:483)."""

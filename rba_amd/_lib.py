@@ -36,6 +36,8 @@ SIGNATURES = {
     "rba_group_norm_nhwc_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
     "rba_resample_bilinear_nhwc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_bn_relu_conv1x1_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp],
+    "rba_resample_bilinear_ac_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_gaussian_blur_f32": [_vp, _vp, _i, _i, _i, ctypes.c_float, _vp],
     "rba_threshold_u8": [_vp, _vp, _i64, ctypes.c_float, _vp],
     "rba_morph3x3_u8": [_vp, _vp, _i, _i, _i, _vp],
@@ -45,7 +47,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 150        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 160        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -10,6 +10,20 @@ import torch
 
 FEATURE_NAMES = ("res2", "res3", "res4", "res5")
 FEATURE_STRIDES = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+# MODEL.RESNETS of Base-Cityscapes-SemanticSegmentation.yaml:8-15 (+ Detectron2 defaults RES2_OUT_CHANNELS 256, WIDTH_PER_GROUP 64)
+RESNET50 = dict(depth=50, stem_out=64, res2_out=256, width=64, stride_in_1x1=False)
+RESNET_STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def feature_channels(a: dict) -> dict:
+    """channels of res2..res5 for the arch's backbone"""
+    if a.get("resnet"):
+        return {f: a["resnet"]["res2_out"] * 2 ** k for k, f in enumerate(FEATURE_NAMES)}
+    return {f: a["embed_dim"] * 2 ** k for k, f in enumerate(FEATURE_NAMES)}
+
+
+def backbone_name(a: dict) -> str:
+    return "build_resnet_backbone" if a.get("resnet") else "D2SwinTransformer"
 
 # Named architectures of BASELINE.json's configs (values from ckpts/*/config.yaml and the
 # configs/cityscapes/semantic-segmentation/swin/ chains of the reference).
@@ -29,11 +43,24 @@ ARCHS = {
     "tiny3": dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=6,
                   conv_dim=64, mask_dim=64, nheads=2, num_queries=16, num_classes=19,
                   dim_feedforward=128, enc_layers=2, dec_layers=4, enc_in=["res3", "res4", "res5"]),
+    # BASELINE config C1: ResNet-50 Mask2Former (maskformer2_R50_bs16_90k.yaml) with DEC_LAYERS 2 and the single-level encoder
+    "r50_1dl": dict(resnet=RESNET50, conv_dim=256, mask_dim=256, nheads=8, num_queries=100, num_classes=19,
+                    dim_feedforward=2048, enc_layers=6, dec_layers=1, enc_in=["res5"]),
+    # ... and as the file defines it: 9 decoder layers, 3-level encoder
+    "r50_9dl": dict(resnet=RESNET50, conv_dim=256, mask_dim=256, nheads=8, num_queries=100, num_classes=19,
+                    dim_feedforward=2048, enc_layers=6, dec_layers=9, enc_in=["res3", "res4", "res5"]),
+    # tiny1 with the DenseHybrid `ood_pred` head
+    "tiny1_dh": dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=6,
+                     conv_dim=64, mask_dim=64, nheads=2, num_queries=16, num_classes=19,
+                     dim_feedforward=128, enc_layers=2, dec_layers=1, enc_in=["res5"], dense_hybrid=True),
 }
 
 _DEFAULTS = dict(patch_size=4, mlp_ratio=4.0, enc_points=4, enc_dim_feedforward=1024,
                  pixel_mean=[123.675, 116.28, 103.53], pixel_std=[58.395, 57.12, 57.375],
                  size_divisibility=32, common_stride=4,
+                 # DenseHybrid `ood_pred` head on the mask features (MODEL.MASK_FORMER.DENSE_HYBRID_LOSS, config.py:220)
+                 dense_hybrid=False,
+                 resnet=None,                     # dict(depth, stem_out, res2_out, width, stride_in_1x1) for build_resnet_backbone
                  # panoptic inference (maskformer_model.py:202-220; config.py:57-59, 243)
                  panoptic_on=False, open_panoptic=True, object_mask_threshold=0.0, overlap_threshold=0.0,
                  thing_classes=[11, 12, 13, 14, 15, 16, 17, 18])   # Cityscapes train ids of the "thing" classes
@@ -51,8 +78,8 @@ def arch_from_cfg(cfg) -> dict:
     M = cfg.MODEL
     if M.META_ARCHITECTURE != "MaskFormer":
         raise ValueError(f"unsupported META_ARCHITECTURE {M.META_ARCHITECTURE!r}")
-    if M.BACKBONE.NAME != "D2SwinTransformer":
-        raise NotImplementedError(f"backbone {M.BACKBONE.NAME!r}: only D2SwinTransformer is on the hot path")
+    if M.BACKBONE.NAME not in ("D2SwinTransformer", "build_resnet_backbone"):
+        raise NotImplementedError(f"backbone {M.BACKBONE.NAME!r}: D2SwinTransformer and build_resnet_backbone are provided")
     if M.SEM_SEG_HEAD.PIXEL_DECODER_NAME != "MSDeformAttnPixelDecoder":
         raise NotImplementedError(M.SEM_SEG_HEAD.PIXEL_DECODER_NAME)
     if M.MASK_FORMER.TRANSFORMER_DECODER_NAME != "MultiScaleMaskedTransformerDecoder":
@@ -61,20 +88,30 @@ def arch_from_cfg(cfg) -> dict:
         raise NotImplementedError(M.MASK_FORMER.TRANSFORMER_IN_FEATURE)
     S = M.SWIN
     unsupported = []
-    if S.APE:
-        unsupported.append("SWIN.APE")
-    if not S.PATCH_NORM:
-        unsupported.append("SWIN.PATCH_NORM=False")
-    if not S.QKV_BIAS:
-        unsupported.append("SWIN.QKV_BIAS=False")
-    if S.QK_SCALE is not None:
-        unsupported.append("SWIN.QK_SCALE")
+    resnet = None
+    if M.BACKBONE.NAME == "build_resnet_backbone":
+        Rn = M.RESNETS
+        if Rn.DEPTH not in RESNET_STAGE_BLOCKS or Rn.get("NUM_GROUPS", 1) != 1 or Rn.get("RES5_DILATION", 1) != 1:
+            unsupported.append("RESNETS: only bottleneck depths 50/101/152, one group, no dilation")
+        if any(Rn.get("DEFORM_ON_PER_STAGE", [False])):
+            unsupported.append("RESNETS.DEFORM_ON_PER_STAGE")
+        if list(Rn.OUT_FEATURES) != list(FEATURE_NAMES):
+            unsupported.append("RESNETS.OUT_FEATURES != res2..res5")
+        resnet = dict(depth=Rn.DEPTH, stem_out=Rn.STEM_OUT_CHANNELS, res2_out=Rn.get("RES2_OUT_CHANNELS", 256),
+                      width=Rn.get("WIDTH_PER_GROUP", 64), stride_in_1x1=bool(Rn.STRIDE_IN_1X1))
+    else:
+        if S.APE:
+            unsupported.append("SWIN.APE")
+        if not S.PATCH_NORM:
+            unsupported.append("SWIN.PATCH_NORM=False")
+        if not S.QKV_BIAS:
+            unsupported.append("SWIN.QKV_BIAS=False")
+        if S.QK_SCALE is not None:
+            unsupported.append("SWIN.QK_SCALE")
     if M.MASK_FORMER.PRE_NORM:
         unsupported.append("MASK_FORMER.PRE_NORM")
     if M.MASK_FORMER.ENFORCE_INPUT_PROJ:
         unsupported.append("MASK_FORMER.ENFORCE_INPUT_PROJ")
-    if M.MASK_FORMER.get("DENSE_HYBRID_LOSS", False):
-        unsupported.append("MASK_FORMER.DENSE_HYBRID_LOSS (ood_pred head)")
     if M.SEM_SEG_HEAD.NORM != "GN":
         unsupported.append(f"SEM_SEG_HEAD.NORM={M.SEM_SEG_HEAD.NORM!r}")
     if M.SEM_SEG_HEAD.CONVS_DIM != M.MASK_FORMER.HIDDEN_DIM:
@@ -98,6 +135,7 @@ def arch_from_cfg(cfg) -> dict:
         enc_in=list(M.SEM_SEG_HEAD.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES),
         common_stride=M.SEM_SEG_HEAD.COMMON_STRIDE, size_divisibility=M.MASK_FORMER.SIZE_DIVISIBILITY,
         pixel_mean=list(M.PIXEL_MEAN), pixel_std=list(M.PIXEL_STD),
+        dense_hybrid=bool(M.MASK_FORMER.get("DENSE_HYBRID_LOSS", False)), resnet=resnet,
         panoptic_on=bool(T.PANOPTIC_ON), open_panoptic=bool(M.MASK_FORMER.get("OPEN_PANOPTIC", True)),
         object_mask_threshold=float(T.OBJECT_MASK_THRESHOLD), overlap_threshold=float(T.OVERLAP_THRESHOLD)))
 
@@ -112,22 +150,8 @@ def num_fpn_levels(a: dict) -> int:
     return n
 
 
-def state_dict_shapes(arch: dict) -> dict:
-    """{key: (shape, dtype)} of the reference MaskFormer state dict restricted to this path
-    (everything except ``criterion.empty_weight``)."""
-    a = complete(arch)
+def _swin_shapes(a, out, lin, norm):
     f32, i64 = torch.float32, torch.int64
-    out = {}
-
-    def lin(p, o, i, bias=True):
-        out[p + ".weight"] = ((o, i), f32)
-        if bias:
-            out[p + ".bias"] = ((o,), f32)
-
-    def norm(p, c):
-        out[p + ".weight"] = ((c,), f32)
-        out[p + ".bias"] = ((c,), f32)
-
     E, ws, ps = a["embed_dim"], a["window_size"], a["patch_size"]
     out["backbone.patch_embed.proj.weight"] = ((E, 3, ps, ps), f32)
     out["backbone.patch_embed.proj.bias"] = ((E,), f32)
@@ -150,10 +174,53 @@ def state_dict_shapes(arch: dict) -> dict:
             norm(f"backbone.layers.{i}.downsample.norm", 4 * C)
         norm(f"backbone.norm{i}", C)
 
+
+
+def state_dict_shapes(arch: dict) -> dict:
+    """{key: (shape, dtype)} of the reference MaskFormer state dict restricted to this path
+    (everything except ``criterion.empty_weight``)."""
+    a = complete(arch)
+    f32, i64 = torch.float32, torch.int64
+    out = {}
+
+    def lin(p, o, i, bias=True):
+        out[p + ".weight"] = ((o, i), f32)
+        if bias:
+            out[p + ".bias"] = ((o,), f32)
+
+    def norm(p, c):
+        out[p + ".weight"] = ((c,), f32)
+        out[p + ".bias"] = ((c,), f32)
+
+    if a.get("resnet"):
+        r = a["resnet"]
+
+        def convbn(p, co, ci, k):              # Detectron2 Conv2d(bias=False, norm=BN): weight + norm.{weight,bias,running_*}
+            out[p + ".weight"] = ((co, ci, k, k), f32)
+            norm(p + ".norm", co)
+            out[p + ".norm.running_mean"] = ((co,), f32)
+            out[p + ".norm.running_var"] = ((co,), f32)
+            out[p + ".norm.num_batches_tracked"] = ((), i64)
+
+        convbn("backbone.stem.conv1", r["stem_out"], 3, 7)
+        cin, cout, bott = r["stem_out"], r["res2_out"], r["width"]
+        for i, nblocks in enumerate(RESNET_STAGE_BLOCKS[r["depth"]]):
+            for b in range(nblocks):
+                p = f"backbone.res{i + 2}.{b}"
+                if cin != cout:
+                    convbn(p + ".shortcut", cout, cin, 1)
+                convbn(p + ".conv1", bott, cin, 1)
+                convbn(p + ".conv2", bott, bott, 3)
+                convbn(p + ".conv3", cout, bott, 1)
+                cin = cout
+            cout, bott = cout * 2, bott * 2
+    else:
+        _swin_shapes(a, out, lin, norm)
+
     d, md, M = a["conv_dim"], a["mask_dim"], a["nheads"]
     L, P = len(a["enc_in"]), a["enc_points"]
     pd = "sem_seg_head.pixel_decoder"
-    chans = {f: E * 2 ** k for k, f in enumerate(FEATURE_NAMES)}
+    chans = feature_channels(a)
     for idx, f in enumerate(a["enc_in"][::-1]):
         out[f"{pd}.input_proj.{idx}.0.weight"] = ((d, chans[f], 1, 1), f32)
         out[f"{pd}.input_proj.{idx}.0.bias"] = ((d,), f32)
@@ -197,6 +264,13 @@ def state_dict_shapes(arch: dict) -> dict:
     lin(pr + ".mask_embed.layers.0", d, d)
     lin(pr + ".mask_embed.layers.1", d, d)
     lin(pr + ".mask_embed.layers.2", md, d)
+    if a["dense_hybrid"]:                  # BNReluConv(hidden_dim, 2, k=1, bias=True) (mask2former_transformer_decoder.py:216-230, 365-366)
+        norm(pr + ".ood_pred.norm", d)
+        out[pr + ".ood_pred.norm.running_mean"] = ((d,), f32)
+        out[pr + ".ood_pred.norm.running_var"] = ((d,), f32)
+        out[pr + ".ood_pred.norm.num_batches_tracked"] = ((), i64)
+        out[pr + ".ood_pred.conv.weight"] = ((2, d, 1, 1), f32)
+        out[pr + ".ood_pred.conv.bias"] = ((2,), f32)
     return out
 
 

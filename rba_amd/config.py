@@ -67,6 +67,10 @@ _DEFAULTS = {
                  "NUM_HEADS": [3, 6, 12, 24], "WINDOW_SIZE": 7, "MLP_RATIO": 4.0, "QKV_BIAS": True, "QK_SCALE": None,
                  "DROP_RATE": 0.0, "ATTN_DROP_RATE": 0.0, "DROP_PATH_RATE": 0.3, "APE": False, "PATCH_NORM": True,
                  "OUT_FEATURES": ["res2", "res3", "res4", "res5"], "USE_CHECKPOINT": False},
+        # detectron2/config/defaults.py MODEL.RESNETS (build_resnet_backbone: BASELINE config C1)
+        "RESNETS": {"DEPTH": 50, "OUT_FEATURES": ["res4"], "NUM_GROUPS": 1, "NORM": "FrozenBN", "WIDTH_PER_GROUP": 64,
+                    "STRIDE_IN_1X1": True, "RES5_DILATION": 1, "RES2_OUT_CHANNELS": 256, "STEM_OUT_CHANNELS": 64,
+                    "DEFORM_ON_PER_STAGE": [False, False, False, False]},
         "SEM_SEG_HEAD": {"NAME": "MaskFormerHead", "IN_FEATURES": ["res2", "res3", "res4", "res5"], "NUM_CLASSES": 19,
                          "IGNORE_VALUE": 255, "LOSS_WEIGHT": 1.0, "CONVS_DIM": 256, "MASK_DIM": 256, "NORM": "GN",
                          "PIXEL_DECODER_NAME": "MSDeformAttnPixelDecoder", "TRANSFORMER_ENC_LAYERS": 6,

@@ -70,6 +70,15 @@ def get_neg_logit_sum(model, x, **kwargs):
     return -out[0]["sem_seg"].sum(dim=0)
 
 
+def get_densehybrid_score(model, x, **kwargs):
+    """-logsumexp_k(sem_seg) + log(softmax(ood_pred)[:, 1] + 1e-9) -> [1,H,W] (evaluate_ood.py:161-173)."""
+    with torch.no_grad():
+        out, ood_pred = model([{"image": x[0].to(model.device)}], return_ood_pred=True)
+    p1 = torch.logsumexp(out[0]["sem_seg"], dim=0)
+    p2 = torch.softmax(ood_pred, dim=1)[:, 1]                      # p(~din | x)
+    return (-p1) + (p2 + 1e-9).log()
+
+
 # K1 epilogue each score function selects: lets OODEvaluator take score + argmax from ONE forward (support.py) without
 # guessing from the function's name
 get_RbA.rba_score_mode = "rba"
@@ -78,7 +87,8 @@ get_neg_logit_sum.rba_score_mode = "neg_logit_sum"
 
 
 # ------------------------------------------------------------------------------------------------- command line
-SCORE_FUNCS = {"rba": get_RbA, "pebal": get_energy, "energy": get_energy, "neg_logit_sum": get_neg_logit_sum}
+SCORE_FUNCS = {"rba": get_RbA, "pebal": get_energy, "energy": get_energy, "neg_logit_sum": get_neg_logit_sum,
+               "dense_hybrid": get_densehybrid_score}
 
 
 def build_parser():

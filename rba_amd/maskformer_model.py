@@ -10,7 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .arch import complete
+from .arch import backbone_name as _backbone_name, complete
+from .modeling.backbone import resnet as _resnet  # noqa: F401  (registers build_resnet_backbone)
 from .modeling.backbone import swin as _swin  # noqa: F401  (registers D2SwinTransformer)
 from .modeling.meta_arch import mask_former_head as _head  # noqa: F401
 from .registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY
@@ -18,11 +19,11 @@ from .registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGIS
 
 @META_ARCH_REGISTRY.register()
 class MaskFormer(nn.Module):
-    def __init__(self, arch, backbone_name="D2SwinTransformer", head_name="MaskFormerHead"):
+    def __init__(self, arch, backbone_name=None, head_name="MaskFormerHead"):
         super().__init__()
         a = complete(arch)
         self.arch = a
-        self.backbone = BACKBONE_REGISTRY.get(backbone_name)(a)
+        self.backbone = BACKBONE_REGISTRY.get(backbone_name or _backbone_name(a))(a)
         self.sem_seg_head = SEM_SEG_HEADS_REGISTRY.get(head_name)(a)
         self.num_queries = a["num_queries"]
         self.size_divisibility = a["size_divisibility"] if a["size_divisibility"] > 0 else self.backbone.size_divisibility
@@ -53,12 +54,16 @@ class MaskFormer(nn.Module):
 
     # ------------------------------------------------------------------ network
     @torch.no_grad()
-    def predict(self, batched_inputs):
-        """-> (pred_logits [B,Q,K+1], pred_masks [B,Q,H/4,W/4], image_sizes, padded (H,W))."""
+    def _predict_outputs(self, batched_inputs):
         batch, sizes = self.preprocess(batched_inputs)
         features = self.backbone(batch)
-        outputs = self.sem_seg_head(features)
-        return outputs["pred_logits"], outputs["pred_masks"], sizes, tuple(batch.shape[-2:])
+        return self.sem_seg_head(features), sizes, tuple(batch.shape[-2:])
+
+    @torch.no_grad()
+    def predict(self, batched_inputs):
+        """-> (pred_logits [B,Q,K+1], pred_masks [B,Q,H/4,W/4], image_sizes, padded (H,W))."""
+        outputs, sizes, padded = self._predict_outputs(batched_inputs)
+        return outputs["pred_logits"], outputs["pred_masks"], sizes, padded
 
     def _post(self, mask_cls, mask_pred, image_size, padded, want_sem_seg, want_argmax, score="rba"):
         """Up-sample (:294-299), semantic inference (:381-386), crop (:330-332), RbA (evaluate_ood.py:150)."""
@@ -140,9 +145,15 @@ class MaskFormer(nn.Module):
     def forward(self, batched_inputs, include_void=False, return_separately=False, return_aux=False,
                 return_ood_pred=False, return_argmax=False, panoptic_ood_threshold=-0.3, panoptic_pixel_min=200,
                 return_panoptic_ood=False, **kwargs):
-        if include_void or return_separately or return_aux or return_ood_pred or kwargs:
+        if include_void or return_separately or return_aux or kwargs:
             raise NotImplementedError("only the semantic and (open-set) panoptic inference paths of MaskFormer.forward are provided")
-        mask_cls, mask_pred, sizes, padded = self.predict(batched_inputs)
+        outputs, sizes, padded = self._predict_outputs(batched_inputs)
+        mask_cls, mask_pred = outputs["pred_logits"], outputs["pred_masks"]
+        ood_pred = None
+        if return_ood_pred:                                     # :303-305: up-sampled to the FIRST image's size, align_corners=True
+            if "ood_pred" not in outputs:
+                raise KeyError("ood_pred: the model has no DenseHybrid head (MODEL.MASK_FORMER.DENSE_HYBRID_LOSS)")
+            ood_pred = ops.resample_bilinear_ac(outputs["ood_pred"].contiguous(), sizes[0])
         results = []
         for i, inp in enumerate(batched_inputs):
             rba, sem, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, True, return_argmax)
@@ -161,6 +172,8 @@ class MaskFormer(nn.Module):
                 r["panoptic_seg"] = self.panoptic_inference(mask_cls[i], mp, self.open_panoptic, panoptic_ood_threshold,
                                                             panoptic_pixel_min, return_panoptic_ood)
             results.append(r)
+        if return_ood_pred:
+            return results, ood_pred                            # :350-351
         return results
 
     @torch.no_grad()

@@ -6,7 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...arch import FEATURE_NAMES, num_fpn_levels
+from ...arch import FEATURE_NAMES, feature_channels, num_fpn_levels
 from ...registry import SEM_SEG_HEADS_REGISTRY
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from .ops.ms_deform_attn import MSDeformAttn
@@ -107,8 +107,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         super().__init__()
         a = arch
         d = a["conv_dim"]
-        E = a["embed_dim"]
-        chans = {f: E * 2 ** k for k, f in enumerate(FEATURE_NAMES)}
+        chans = feature_channels(a)
         self.in_features = list(FEATURE_NAMES)
         self.transformer_in_features = list(a["enc_in"])
         self.transformer_num_feature_levels = len(a["enc_in"])

@@ -97,6 +97,23 @@ class MLP(nn.Module):
         return x
 
 
+class BNReluConv(nn.Module):
+    """BatchNorm2d -> ReLU -> Conv2d(k=1) with the reference's sub-module names (norm / conv; reference :216-230), evaluated in
+    inference mode by one HIP kernel: the running statistics are folded into a per-channel scale and shift."""
+
+    def __init__(self, num_maps_in, num_maps_out):
+        super().__init__()
+        self.norm = nn.BatchNorm2d(num_maps_in, momentum=0.01)
+        self.conv = nn.Conv2d(num_maps_in, num_maps_out, kernel_size=1, bias=True)
+
+    def forward(self, x):
+        n = self.norm
+        scale = n.weight * torch.rsqrt(n.running_var + n.eps)
+        shift = n.bias - n.running_mean * scale
+        return ops.bn_relu_conv1x1(x.contiguous(), scale.contiguous(), shift.contiguous(),
+                                   self.conv.weight.flatten(1).contiguous(), self.conv.bias)
+
+
 @TRANSFORMER_DECODER_REGISTRY.register()
 class MultiScaleMaskedTransformerDecoder(nn.Module):
     def __init__(self, arch):
@@ -115,6 +132,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.level_embed = nn.Embedding(self.num_feature_levels, d)
         self.class_embed = nn.Linear(d, a["num_classes"] + 1)
         self.mask_embed = MLP(d, d, a["mask_dim"], 3)
+        self.ood_prediction = bool(a.get("dense_hybrid", False))
+        if self.ood_prediction:                                  # DenseHybrid head (reference :365-366)
+            self.ood_pred = BNReluConv(d, 2)
         # inference-only shortcut, exact: intermediate heads evaluate mask logits only where the attention mask samples them
         # (aux_outputs then carry pred_logits only)
         self.sparse_intermediate_heads = True
@@ -201,9 +221,12 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 output, mask_features, size_list[(i + 1) % self.num_feature_levels], need_attn_mask=not last, need_masks=last)
             predictions_class.append(cls)
             predictions_mask.append(msk)
-        return {
+        out = {
             "pred_logits": predictions_class[-1],
             "pred_masks": predictions_mask[-1],
             "aux_outputs": [({"pred_logits": a, "pred_masks": b} if b is not None else {"pred_logits": a})
                             for a, b in zip(predictions_class[:-1], predictions_mask[:-1])],
         }
+        if self.ood_prediction:
+            out["ood_pred"] = self.ood_pred(mask_features)                           # reference :467-468
+        return out

@@ -512,6 +512,48 @@ def resample_bilinear_nhwc(x, size, add=None):
 
 
 @_hip_op
+def bn_relu_conv1x1(x, scale, shift, weight, bias=None):
+    """conv1x1(relu(x * scale[c] + shift[c])) for x [B,C,...] -> [B,O,...] (O = weight.shape[0] in {1,2,4}): the DenseHybrid
+    `ood_pred` head BNReluConv(hidden_dim, 2, k=1) in eval mode (mask2former_transformer_decoder.py:216-230, 467-468)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(scale, "scale", dim=1)
+    _chk(shift, "shift", dim=1)
+    _chk(weight, "weight", dim=2)
+    if x.dim() < 3:
+        raise RbaHipError("x must be [B,C,...]")
+    B, C = x.shape[:2]
+    O = weight.shape[0]
+    P = x.numel() // (B * C) if B * C else 0
+    if scale.numel() != C or shift.numel() != C or weight.shape[1] != C or O not in (1, 2, 4):
+        raise RbaHipError("bn_relu_conv1x1 needs scale/shift [C] and weight [O,C] with O in {1,2,4}")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+    out = torch.empty((B, O) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_bn_relu_conv1x1_f32(_p(x), _p(scale), _p(shift), _p(weight), _p(bias), _p(out), B, C, O, P, _stream()),
+               "rba_bn_relu_conv1x1_f32")
+    return out
+
+
+@_hip_op
+def resample_bilinear_ac(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=True) for x [C,h,w] or [B,C,h,w] (maskformer_model.py:305)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    if x.dim() not in (3, 4):
+        raise RbaHipError("x must be [C,h,w] or [B,C,h,w]")
+    H, W = int(size[0]), int(size[1])
+    lead = x.shape[:-2]
+    C = 1
+    for s_ in lead:
+        C *= int(s_)
+    h, w = x.shape[-2:]
+    out = torch.empty(tuple(lead) + (H, W), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_resample_bilinear_ac_f32(_p(x), _p(out), C, h, w, H, W, _stream()), "rba_resample_bilinear_ac_f32")
+    return out
+
+
+@_hip_op
 def gaussian_blur(score, kernel_size=7, sigma=1.0):
     """transforms.GaussianBlur(kernel_size, sigma) of a score map [H,W] (reflect padding): the evaluator's optional smoothing."""
     lib = _lib.load()

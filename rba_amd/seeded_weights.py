@@ -10,7 +10,8 @@ its shape and the seed -- not on iteration order, device or module layout.
 The scale per tensor class keeps activations O(1) through the 24 Swin blocks:
 
 * norm weights (LayerNorm / GroupNorm ``weight``)      1 + 0.1 n
-* 1-d biases                                           0.05 n
+* 1-d biases (and BatchNorm running_mean)              0.05 n
+* BatchNorm ``running_var``                            0.5 + |1 + 0.3 n|
 * ``class_embed.bias``         0.05 n, void column + 5 (most queries predict "no object",
   as in a trained model, so RbA stays in the un-saturated range)
 * ``relative_position_bias_table``                     0.5 n
@@ -67,6 +68,8 @@ def seeded_tensor(key: str, like: torch.Tensor, seed: int = 0, meta: dict = None
         n_points = meta.get("n_points", 4)
         n_levels = like.numel() // (n_heads * n_points * 2)
         out = deform_ring_bias(n_heads, n_levels, n_points) + 0.1 * n
+    elif key.endswith("running_var"):
+        out = 0.5 + (1.0 + 0.3 * n).abs()         # BatchNorm running variance: positive
     elif _is_norm_weight(key, like):
         out = 1.0 + 0.1 * n
     elif key.endswith("class_embed.bias"):

@@ -175,6 +175,9 @@ ARCHS = {
     "tiny3": dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=6,
                   conv_dim=64, mask_dim=64, nheads=2, num_queries=16, num_classes=19,
                   dim_feedforward=128, enc_layers=2, dec_layers=4, enc_in=["res3", "res4", "res5"]),
+    "tiny1_dh": dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=6,
+                     conv_dim=64, mask_dim=64, nheads=2, num_queries=16, num_classes=19,
+                     dim_feedforward=128, enc_layers=2, dec_layers=1, enc_in=["res5"], dense_hybrid=True),
     # ckpts/swin_b_1dl/config.yaml
     "swin_b_1dl": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=12,
                        conv_dim=256, mask_dim=256, nheads=8, num_queries=100, num_classes=19,
@@ -214,7 +217,7 @@ class RefModel(nn.Module):
             a["conv_dim"], True, num_classes=a["num_classes"], hidden_dim=a["conv_dim"],
             num_queries=a["num_queries"], nheads=a["nheads"], dim_feedforward=a["dim_feedforward"],
             dec_layers=a["dec_layers"], pre_norm=False, mask_dim=a["mask_dim"], enforce_input_project=False,
-            ood_prediction=False, num_feature_levels=len(a["enc_in"]))
+            ood_prediction=bool(a.get("dense_hybrid", False)), num_feature_levels=len(a["enc_in"]))
         self.sem_seg_head = head
 
 
@@ -238,7 +241,13 @@ def ref_forward(model, image, taps=None):
     rba = -sem.tanh().sum(dim=0)                           # evaluate_ood.py:150
     if taps is not None:
         taps.update(feats=feats, mask_features=mask_features, multi_scale=multi_scale, out=out)
-    return dict(pred_logits=mask_cls, pred_masks=mask_pred[0], sem_seg=sem, rba=rba, argmax=sem.argmax(0))
+    res = dict(pred_logits=mask_cls, pred_masks=mask_pred[0], sem_seg=sem, rba=rba, argmax=sem.argmax(0))
+    if "ood_pred" in out:                                  # maskformer_model.py:303-305 + evaluate_ood.py:161-173
+        ood = F.interpolate(out["ood_pred"], size=(h, w), mode="bilinear", align_corners=True)
+        p1 = torch.logsumexp(sem, dim=0)
+        p2 = F.softmax(ood, dim=1)[:, 1]
+        res.update(ood_pred_low=out["ood_pred"][0], ood_pred=ood[0], densehybrid=((-p1) + (p2 + 1e-9).log())[0])
+    return res
 
 
 def rand_image(h, w, seed):
@@ -395,6 +404,9 @@ def g_end_to_end(R, arch, h, w, seed, img_seed, full_outputs, name, npix=4096):
             arrs[f"multi_scale_{i}"] = np_(v[0])
         for i, aux in enumerate(taps["out"]["aux_outputs"]):
             arrs[f"aux{i}_pred_logits"] = np_(aux["pred_logits"][0])
+        for k in ("ood_pred_low", "ood_pred", "densehybrid"):
+            if k in o:
+                arrs[k] = np_(o[k])
     else:
         g = torch.Generator().manual_seed(123)
         ys = torch.randint(0, h, (npix,), generator=g)
@@ -481,6 +493,7 @@ def main():
         "g3swin": lambda: g_swin_parts(R),
         "g4tiny1": lambda: g_end_to_end(R, "tiny1", 60, 90, 0, 1234, True, "g4_tiny1_60x90"),
         "g4tiny3": lambda: g_end_to_end(R, "tiny3", 60, 90, 0, 1234, True, "g4_tiny3_60x90"),
+        "g4tiny1dh": lambda: g_end_to_end(R, "tiny1_dh", 60, 90, 0, 1234, True, "g4_tiny1_dh_60x90"),
         "g6": lambda: g_metrics(R),
     }
     if args.full:

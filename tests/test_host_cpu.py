@@ -67,7 +67,7 @@ def test_relative_position_index_matches_reference(golden):
     assert np.array_equal(relative_position_index(6).numpy(), g["wa_sd.relative_position_index"])
 
 
-@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90", "g5_swin_b_1dl_1024x2048", "g5_swin_b_9dl_720x1280",
+@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90", "g4_tiny1_dh_60x90", "g5_swin_b_1dl_1024x2048", "g5_swin_b_9dl_720x1280",
                                   "g5_swin_l_1dl_1024x2048"])
 def test_model_state_dict_contract(golden, name):
     """our module tree has exactly the reference's state-dict keys and shapes (the model_final.pth contract) -- the toy
@@ -204,3 +204,62 @@ def test_bench_self_launch_refuses_without_devices():
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
         pytest.skip("two devices visible: the launch would really run")
     assert r.returncode != 0 and "visible HIP device" in r.stderr
+
+
+def test_dense_hybrid_config_flag(tmp_path):
+    """MODEL.MASK_FORMER.DENSE_HYBRID_LOSS (config.py:220) switches the `ood_pred` head on; its keys join the state-dict contract"""
+    import yaml
+    from rba_amd.config import load_cfg
+    cfg = {"MODEL": {"META_ARCHITECTURE": "MaskFormer", "BACKBONE": {"NAME": "D2SwinTransformer"},
+                     "MASK_FORMER": {"DENSE_HYBRID_LOSS": True}}}
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(cfg))
+    a = A.arch_from_cfg(load_cfg(str(tmp_path / "config.yaml")))
+    assert a["dense_hybrid"] is True
+    keys = A.state_dict_shapes(a)
+    assert "sem_seg_head.predictor.ood_pred.conv.weight" in keys and keys["sem_seg_head.predictor.ood_pred.conv.weight"][0] == (2, 256, 1, 1)
+    assert "sem_seg_head.predictor.ood_pred.norm.running_var" in keys
+
+
+def test_resnet50_config_and_state_dict_contract(tmp_path):
+    """BASELINE config C1: maskformer2_R50_bs16_90k.yaml on Base-Cityscapes-SemanticSegmentation.yaml (build_resnet_backbone) parses
+    to the ResNet-50 architecture, and the module tree has Detectron2's key layout (backbone.stem.conv1.{weight,norm.*},
+    backbone.res{2..5}.{i}.{shortcut,conv1,conv2,conv3}.*)."""
+    import yaml
+    from rba_amd.config import load_cfg
+    from rba_amd.maskformer_model import MaskFormer
+    cfg = {"MODEL": {"META_ARCHITECTURE": "MaskFormer", "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 0},
+                     "RESNETS": {"DEPTH": 50, "STEM_OUT_CHANNELS": 64, "STRIDE_IN_1X1": False, "NORM": "SyncBN",
+                                 "OUT_FEATURES": ["res2", "res3", "res4", "res5"]},
+                     "SEM_SEG_HEAD": {"DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res5"]},
+                     "MASK_FORMER": {"DEC_LAYERS": 2}}}
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(cfg))
+    a = A.arch_from_cfg(load_cfg(str(tmp_path / "config.yaml")))
+    assert a["resnet"] == A.RESNET50 and a["dec_layers"] == 1 and a["enc_in"] == ["res5"]
+    m = MaskFormer(a)
+    sd = m.state_dict()
+    shapes = A.state_dict_shapes(a)
+    assert sorted(sd) == sorted(shapes)
+    assert all(tuple(sd[k].shape) == tuple(shapes[k][0]) for k in sd)
+    for k in ("backbone.stem.conv1.weight", "backbone.stem.conv1.norm.running_var", "backbone.res2.0.shortcut.weight",
+              "backbone.res3.0.conv2.weight", "backbone.res5.2.conv3.norm.bias"):
+        assert k in sd, k
+    assert "backbone.res2.1.shortcut.weight" not in sd
+    assert tuple(sd["backbone.res5.0.conv2.weight"].shape) == (512, 512, 3, 3)
+    assert tuple(sd["sem_seg_head.pixel_decoder.input_proj.0.0.weight"].shape) == (256, 2048, 1, 1)
+    assert tuple(sd["sem_seg_head.pixel_decoder.adapter_1.weight"].shape) == (256, 256, 1, 1)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference tree not present on this box")
+def test_reference_resnet_and_densehybrid_configs_parse():
+    """the reference's own R50 / R101 files (BASELINE config C1) and its DenseHybrid fine-tuning file resolve to our architectures"""
+    from rba_amd.config import load_cfg
+    base = "/root/reference/configs/cityscapes/semantic-segmentation/"
+    a = A.arch_from_cfg(load_cfg(base + "maskformer2_R50_bs16_90k.yaml"))
+    assert a["resnet"] == A.RESNET50 and a["dec_layers"] == 9 and a["enc_in"] == ["res3", "res4", "res5"]
+    swin_only = ("object_mask_threshold", "overlap_threshold", "depths", "embed_dim", "num_heads", "window_size", "patch_size", "mlp_ratio")
+    assert {k: v for k, v in a.items() if k not in swin_only} == \
+        {k: v for k, v in A.complete(A.ARCHS["r50_9dl"]).items() if k not in swin_only}
+    a = A.arch_from_cfg(load_cfg(base + "maskformer2_R101_bs16_90k_1dl.yaml"))
+    assert a["resnet"]["depth"] == 101 and a["dec_layers"] == 1
+    a = A.arch_from_cfg(load_cfg(base + "densehybrid/maskformer2_swin_base_IN21k_384_bs16_90k_1dl_densehybrid_cocomix_finetune.yaml"))
+    assert a["dense_hybrid"] is True and a["embed_dim"] == 128 and a["dec_layers"] == 1

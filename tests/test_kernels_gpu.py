@@ -587,3 +587,29 @@ def test_split_linear_full_size_properties(ops):
     assert (y1 + y2 - b - y12).abs().max().item() < 2e-5
     rows = torch.randint(0, M, (256,), device="cuda", generator=g)
     assert maxerr(y1[rows], F.linear(x1[rows].double(), w.double(), b.double())) < 1e-5
+
+
+# ----------------------------------------------------------------------------------- DenseHybrid head kernels
+@pytest.mark.parametrize("B,C,O,h,w", [(1, 64, 2, 16, 24), (2, 256, 2, 9, 7), (1, 32, 1, 5, 5), (1, 48, 4, 8, 16)])
+def test_bn_relu_conv1x1(ops, B, C, O, h, w):
+    """BNReluConv(C, O, k=1) in eval mode (mask2former_transformer_decoder.py:216-230) against torch's batch_norm/relu/conv2d"""
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, C, h, w, generator=g)
+    bw, bb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    mean, var = 0.2 * torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    cw, cb = torch.randn(O, C, 1, 1, generator=g) * C ** -0.5, torch.randn(O, generator=g)
+    ref = F.conv2d(F.relu(F.batch_norm(x.double(), mean.double(), var.double(), bw.double(), bb.double(), False, 0.0, 1e-5)),
+                   cw.double(), cb.double())
+    scale = bw * torch.rsqrt(var + 1e-5)
+    shift = bb - mean * scale
+    out = ops.bn_relu_conv1x1(dev(x), dev(scale), dev(shift), dev(cw.flatten(1).contiguous()), dev(cb))
+    assert out.shape == (B, O, h, w) and maxerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("C,h,w,H,W", [(2, 16, 24, 60, 90), (3, 5, 7, 5, 7), (1, 4, 4, 1, 9), (2, 8, 8, 3, 2)])
+def test_resample_bilinear_align_corners(ops, C, h, w, H, W):
+    """F.interpolate(mode="bilinear", align_corners=True) (maskformer_model.py:305)"""
+    x = torch.randn(C, h, w, generator=torch.Generator().manual_seed(C + h))
+    ref = F.interpolate(x[None].double(), size=(H, W), mode="bilinear", align_corners=True)[0]
+    out = ops.resample_bilinear_ac(dev(x), (H, W))
+    assert out.shape == (C, H, W) and maxerr(out, ref) < 2e-6

@@ -54,6 +54,24 @@ def test_tiny_vs_golden(golden, name):
         assert torch.equal(rba, out["rba"]) and torch.equal(arg, out["argmax"])
 
 
+def test_dense_hybrid_tiny(golden):
+    """DenseHybrid: `ood_pred` head (BNReluConv on the mask features), MaskFormer.forward(return_ood_pred=True) and
+    get_densehybrid_score against the reference decoder built with ood_prediction=True (evaluate_ood.py:161-173)."""
+    from rba_amd import evaluate_ood as E
+    g = golden("g4_tiny1_dh_60x90")
+    model, a, _ = build("tiny1_dh", int(g["seed"]))
+    image = T(g["image"])
+    out, ood = model([{"image": image}], return_ood_pred=True)
+    assert ood.shape == (1, 2, 60, 90)
+    assert maxerr(ood[0], g["ood_pred"]) < 5e-5
+    assert maxerr(out[0]["sem_seg"], g["sem_seg"]) < 1e-4
+    score = E.get_densehybrid_score(model, image[None])
+    assert score.shape == (1, 60, 90) and maxerr(score[0], g["densehybrid"]) < 1e-4
+    model2, _, _ = build("tiny1", int(g["seed"]))
+    with pytest.raises(KeyError):
+        model2([{"image": image}], return_ood_pred=True)
+
+
 def test_evaluator_surface_tiny(golden, tmp_path):
     """get_model(config.yaml, model_final.pth) -> get_RbA / get_logits / OODEvaluator, as evaluate_ood.py drives them."""
     import yaml
@@ -266,10 +284,11 @@ def test_requested_output_resolution(golden):
         model([{"image": image}], return_aux=True)
 
 
-def test_c1_random_tensor_256x512_vs_oracle():
-    """BASELINE config C1's input (torch.randn(1,3,256,512), seed 0) through the product vs the CPU oracle (Swin-B 1dl; see
-    tests/test_oracle_golden.py::test_c1_plumbing_cpu_forward_256x512 for why not ResNet-50)."""
-    model, a, sd = build("swin_b_1dl", 0)
+@pytest.mark.parametrize("arch", ["r50_1dl", "swin_b_1dl"])
+def test_c1_random_tensor_256x512_vs_oracle(arch):
+    """BASELINE config C1 (ResNet-50 Mask2Former, 1 decoder layer, 100 queries, torch.randn(1,3,256,512) seed 0): the product against
+    the CPU oracle -- ResNet-50 restated from Detectron2's definition (parity unpinned), and Swin-B 1dl on the same input."""
+    model, a, sd = build(arch, 0)
     x = torch.randn(3, 256, 512, generator=torch.Generator().manual_seed(0))
     out = model([{"image": x}], return_argmax=True)[0]
     ref = ref_model.forward(x, sd, a)

@@ -90,7 +90,7 @@ def test_swin_parts(golden):
     assert ((H + 1) // 2, (W + 1) // 2) == (Wh, Ww)
 
 
-@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90"])
+@pytest.mark.parametrize("name", ["g4_tiny1_60x90", "g4_tiny3_60x90", "g4_tiny1_dh_60x90"])
 def test_end_to_end_tiny(golden, name):
     g = golden(name)
     a = A.complete(A.ARCHS[str(g["arch"])])
@@ -113,6 +113,10 @@ def test_end_to_end_tiny(golden, name):
     gap = np.sort(g["sem_seg"], axis=0)
     flips = o["argmax"].numpy() != g["argmax"]
     assert not (flips & ((gap[-1] - gap[-2]) > 1e-5)).any()
+    if "densehybrid" in g.files:                       # DenseHybrid head + score (evaluate_ood.py:161-173) of the reference decoder
+        close(ref_model.ood_pred_head(taps["mask_features"], sd)[0], g["ood_pred_low"], 2e-5)
+        close(o["ood_pred"][0], g["ood_pred"], 2e-5)
+        close(o["densehybrid"][0], g["densehybrid"], 2e-5)
 
 
 @pytest.mark.parametrize("case", "abcd")
@@ -163,18 +167,44 @@ def test_end_to_end_full_size(golden, fixture, arch_name):
     assert abs(o["rba"].double().sum().item() - g["rba_stats"][0]) < 1e-5 * h * w
 
 
-def test_c1_plumbing_cpu_forward_256x512():
-    """BASELINE config C1 ("CPU reference forward + RbA score, 1x256x512 random tensor, 1 decoder layer, 100 queries"): the
-    CPU path end to end.  The ResNet-50 of that config is Detectron2 code that is not in the container, so the
-    plumbing is exercised with the Swin-B 1dl architecture."""
-    a = A.complete(A.ARCHS["swin_b_1dl"])
+@pytest.mark.parametrize("arch", ["r50_1dl", "swin_b_1dl"])
+def test_c1_plumbing_cpu_forward_256x512(arch):
+    """BASELINE config C1 ("ResNet-50 Mask2Former, 1 decoder layer, 100 queries, 1x256x512 random tensor, CPU reference forward +
+    RbA score"): the CPU path end to end on the ResNet-50 architecture (Detectron2's backbone restated, parity unpinned) and, for
+    comparison, on Swin-B 1dl."""
+    a = A.complete(A.ARCHS[arch])
     sd = A.seeded_weights(a, 0)
     x = torch.randn(3, 256, 512, generator=torch.Generator().manual_seed(0))
-    o = ref_model.forward(x, sd, a)
+    taps = {}
+    o = ref_model.forward(x, sd, a, taps)
+    if arch == "r50_1dl":
+        assert [tuple(taps["feats"][f].shape[1:]) for f in ("res2", "res3", "res4", "res5")] == [(256, 64, 128), (512, 32, 64),
+                                                                                                 (1024, 16, 32), (2048, 8, 16)]
     assert o["pred_logits"].shape == (100, 20) and o["pred_masks"].shape == (100, 64, 128)
     assert o["sem_seg"].shape == (19, 256, 512) and o["rba"].shape == (256, 512) and o["argmax"].shape == (256, 512)
     assert torch.isfinite(o["rba"]).all() and float(o["rba"].max()) <= 0.0 and float(o["rba"].min()) > -19.0
     assert float(o["sem_seg"].min()) >= 0.0
+
+
+def test_resnet50_matches_torch_module_graph():
+    """The oracle's functional ResNet-50 against an independent nn.Module graph of the same Detectron2 definition (the product's
+    module tree on CPU with plain BatchNorm/conv calls): stride placement (STRIDE_IN_1X1 False -> the 3x3 conv strides), projection
+    shortcuts only where the shape changes, max-pool after the stem."""
+    import torch.nn.functional as F
+    from rba_amd.modeling.backbone.resnet import ResNet
+    a = A.complete(A.ARCHS["r50_1dl"])
+    sd = A.seeded_weights(a, 1)
+    net = ResNet(a).eval()
+    bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    missing = net.load_state_dict(bsd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys)
+    x = torch.randn(1, 3, 96, 160, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        got = net(x)
+    want = ref_model.resnet_backbone(x, sd, a)
+    for f in want:
+        assert got[f].shape == want[f].shape
+        assert (got[f] - want[f]).abs().max() < 2e-4 * max(1.0, float(want[f].abs().max())), f
 
 
 def test_gaussian_blur_oracle_vs_scipy():
