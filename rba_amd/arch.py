@@ -62,6 +62,9 @@ _DEFAULTS = dict(patch_size=4, mlp_ratio=4.0, enc_points=4, enc_dim_feedforward=
                  dense_hybrid=False,
                  resnet=None,                     # dict(depth, stem_out, res2_out, width, stride_in_1x1) for build_resnet_backbone
                  # panoptic inference (maskformer_model.py:202-220; config.py:57-59, 243)
+                 # sem_seg_postprocess on the mask logits BEFORE semantic inference (maskformer_model.py:205-209: the flag, or implied
+                 # by panoptic / instance inference); only matters when a requested output size differs from the image size
+                 postprocess_before_inference=False,
                  panoptic_on=False, open_panoptic=True, object_mask_threshold=0.0, overlap_threshold=0.0,
                  thing_classes=[11, 12, 13, 14, 15, 16, 17, 18])   # Cityscapes train ids of the "thing" classes
 
@@ -136,6 +139,7 @@ def arch_from_cfg(cfg) -> dict:
         common_stride=M.SEM_SEG_HEAD.COMMON_STRIDE, size_divisibility=M.MASK_FORMER.SIZE_DIVISIBILITY,
         pixel_mean=list(M.PIXEL_MEAN), pixel_std=list(M.PIXEL_STD),
         dense_hybrid=bool(M.MASK_FORMER.get("DENSE_HYBRID_LOSS", False)), resnet=resnet,
+        postprocess_before_inference=bool(T.get("SEM_SEG_POSTPROCESSING_BEFORE_INFERENCE", False) or T.PANOPTIC_ON or T.INSTANCE_ON),
         panoptic_on=bool(T.PANOPTIC_ON), open_panoptic=bool(M.MASK_FORMER.get("OPEN_PANOPTIC", True)),
         object_mask_threshold=float(T.OBJECT_MASK_THRESHOLD), overlap_threshold=float(T.OVERLAP_THRESHOLD)))
 

@@ -32,6 +32,7 @@ class MaskFormer(nn.Module):
         self.fused_upsample = True      # K1 reads the low-res logits and up-samples on the fly (rba_reduce_up4)
         # panoptic inference (maskformer_model.py:202-220): off unless TEST.PANOPTIC_ON
         self.panoptic_on, self.open_panoptic = bool(a["panoptic_on"]), bool(a["open_panoptic"])
+        self.sem_seg_postprocess_before_inference = bool(a["postprocess_before_inference"]) or self.panoptic_on
         self.object_mask_threshold, self.overlap_threshold = float(a["object_mask_threshold"]), float(a["overlap_threshold"])
         self.thing_classes = frozenset(int(c) for c in a["thing_classes"])
         self.eval()
@@ -156,12 +157,19 @@ class MaskFormer(nn.Module):
             ood_pred = ops.resample_bilinear_ac(outputs["ood_pred"].contiguous(), sizes[0])
         results = []
         for i, inp in enumerate(batched_inputs):
-            rba, sem, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, True, return_argmax)
             height, width = inp.get("height", sizes[i][0]), inp.get("width", sizes[i][1])
-            if (height, width) != sizes[i]:       # sem_seg_postprocess resize to the requested output resolution
-                sem = ops.resample_bilinear(sem, (height, width))
-                rba = -sem.tanh().sum(dim=0)
-                arg = sem.argmax(0).to(torch.int32) if return_argmax else None
+            if (height, width) != sizes[i] and self.sem_seg_postprocess_before_inference:
+                # :316-320: crop + resize the MASK LOGITS to the requested resolution first, semantic inference on those
+                up = ops.resample_bilinear(mask_pred[i].contiguous(), padded)[:, : sizes[i][0], : sizes[i][1]].contiguous()
+                up = ops.resample_bilinear(up, (height, width))
+                prob = F.softmax(mask_cls[i], dim=-1)[..., :-1].contiguous()
+                rba, sem, arg = ops.rba_reduce(up, prob, True, return_argmax)
+            else:
+                rba, sem, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, True, return_argmax)
+                if (height, width) != sizes[i]:   # :330-332: sem_seg_postprocess of the class maps to the requested resolution
+                    sem = ops.resample_bilinear(sem, (height, width))
+                    rba = -sem.tanh().sum(dim=0)
+                    arg = sem.argmax(0).to(torch.int32) if return_argmax else None
             r = {"sem_seg": sem, "rba": rba}
             if return_argmax:
                 r["argmax"] = arg

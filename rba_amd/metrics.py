@@ -90,5 +90,5 @@ def select_labelled(anomaly_score: torch.Tensor, ood_gts: torch.Tensor):
     """Keep pixels labelled 0 (inlier) or 1 (OoD); everything else (255) is ignored (support.py:275-285)."""
     s = anomaly_score.reshape(-1)
     g = ood_gts.reshape(-1)
-    m = (g == 0) | (g == 1)
-    return s[m], (g[m] == 1)
+    idx = torch.nonzero((g == 0) | (g == 1)).reshape(-1)          # one compaction, two gathers
+    return s[idx], (g[idx] == 1)

@@ -7,6 +7,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...arch import FEATURE_NAMES, feature_channels, num_fpn_levels
+from ...lru import ShapeCache
 from ...registry import SEM_SEG_HEADS_REGISTRY
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from .ops.ms_deform_attn import MSDeformAttn
@@ -77,7 +78,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         self.encoder = MSDeformAttnTransformerEncoder(
             (d_model, dim_feedforward, num_feature_levels, nhead, enc_n_points), num_encoder_layers)
         self.level_embed = nn.Parameter(torch.zeros(num_feature_levels, d_model))
-        self._ref_cache = {}
+        self._ref_cache = ShapeCache(8)
 
     def forward(self, srcs, pos_embeds):
         """msdeformattn.py:70-98; returns (memory [B,S,C], shapes list, level_start list)."""
@@ -86,12 +87,12 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
                          for l, p in enumerate(pos_embeds)], 1)
-        key = (tuple(shapes), dev)
-        if key not in self._ref_cache:
-            sh = torch.as_tensor(shapes, dtype=torch.long, device=dev)
-            lsi = torch.cat((sh.new_zeros((1,)), sh.prod(1).cumsum(0)[:-1]))
-            self._ref_cache[key] = (sh, lsi, MSDeformAttnTransformerEncoder.get_reference_points(shapes, dev))
-        sh, lsi, ref = self._ref_cache[key]
+        def build():
+            sh_ = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+            lsi_ = torch.cat((sh_.new_zeros((1,)), sh_.prod(1).cumsum(0)[:-1]))
+            return sh_, lsi_, MSDeformAttnTransformerEncoder.get_reference_points(shapes, dev)
+
+        sh, lsi, ref = self._ref_cache.get((tuple(shapes), dev), build)
         B = src.shape[0]
         if B > 1:
             ref = ref.expand(B, -1, -1, -1).contiguous()

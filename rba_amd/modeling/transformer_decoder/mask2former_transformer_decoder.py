@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
+from ...lru import ShapeCache
 from ...registry import TRANSFORMER_DECODER_REGISTRY
 from .position_encoding import PositionEmbeddingSine
 
@@ -138,7 +139,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # inference-only shortcut, exact: intermediate heads evaluate mask logits only where the attention mask samples them
         # (aux_outputs then carry pred_logits only)
         self.sparse_intermediate_heads = True
-        self._plan_cache, self._gather_by_level = {}, {}
+        self._plan_cache = ShapeCache(8)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # v1 checkpoints call query_feat "static_query" (reference :237-258)
@@ -153,19 +154,22 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         columns): exactly 2x2 source pixels.  Returns the flat source indices [4, h*w] or None when the factor is not an
         even integer (then the dense path is used)."""
         key = (tuple(feat_hw), tuple(target_hw), device)
-        if key not in self._plan_cache:
-            (H, W), (h, w) = feat_hw, target_hw
-            plan = None
-            if h > 0 and w > 0 and H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and 4 * h * w < H * W:
-                fy, fx = H // h, W // w
-                r0 = torch.arange(h, device=device) * fy + fy // 2 - 1
-                c0 = torch.arange(w, device=device) * fx + fx // 2 - 1
-                idx = [((r0 + dr)[:, None] * W + (c0 + dc)[None, :]).reshape(-1) for dr in (0, 1) for dc in (0, 1)]
-                plan = torch.stack(idx).contiguous()
-            self._plan_cache[key] = plan
-        return self._plan_cache[key]
 
-    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True, need_masks=True):
+        def build():
+            (H, W), (h, w) = feat_hw, target_hw
+            if not (h > 0 and w > 0 and H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and 4 * h * w < H * W):
+                return False
+            fy, fx = H // h, W // w
+            r0 = torch.arange(h, device=device) * fy + fy // 2 - 1
+            c0 = torch.arange(w, device=device) * fx + fx // 2 - 1
+            idx = [((r0 + dr)[:, None] * W + (c0 + dc)[None, :]).reshape(-1) for dr in (0, 1) for dc in (0, 1)]
+            return torch.stack(idx).contiguous()
+
+        plan = self._plan_cache.get(key, build)
+        return None if plan is False else plan
+
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True, need_masks=True,
+                                 gathered=None):
         """output [B,Q,C] -> class logits [B,Q,K+1], mask logits [B,Q,H/4,W/4] (None unless need_masks), attention-mask
         logits [B,Q,h*w] (reference :472-489; the threshold itself happens inside K3).  When only the attention mask is
         consumed (every call but the last) the mask logits are evaluated just at the 2x2 source pixels each attention
@@ -179,9 +183,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         if plan is not None:
             B, C = mask_features.shape[:2]
             lvl = tuple(attn_mask_target_size)
-            if lvl not in self._gather_by_level:          # mask_features is the same tensor for every layer: gather once per level
-                self._gather_by_level[lvl] = mask_features.flatten(2).index_select(2, plan.reshape(-1)).contiguous()   # [B,C,4hw]
-            cols = self._gather_by_level[lvl]
+            gathered = {} if gathered is None else gathered    # per-call dict owned by forward(): the module stays re-entrant
+            if lvl not in gathered:                   # mask_features is the same tensor for every layer: gather once per level
+                gathered[lvl] = mask_features.flatten(2).index_select(2, plan.reshape(-1)).contiguous()   # [B,C,4hw]
+            cols = gathered[lvl]
             v = ops.mask_logits(mask_embed, cols).view(B, -1, 4, plan.shape[1])
             attn_logits = 0.5 * (0.5 * v[:, :, 0] + 0.5 * v[:, :, 1]) + 0.5 * (0.5 * v[:, :, 2] + 0.5 * v[:, :, 3])
             return outputs_class, None, attn_logits.contiguous()
@@ -206,9 +211,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         output = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
         mask_features = mask_features.contiguous()
         predictions_class, predictions_mask = [], []
-        self._gather_by_level = {}
+        gathered = {}
         cls, msk, attn_logits = self.forward_prediction_heads(output, mask_features, size_list[0], self.num_layers > 0,
-                                                              need_masks=self.num_layers == 0)
+                                                              need_masks=self.num_layers == 0, gathered=gathered)
         predictions_class.append(cls)
         predictions_mask.append(msk)
         for i in range(self.num_layers):
@@ -218,7 +223,8 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             output = self.transformer_ffn_layers[i](output)
             last = i == self.num_layers - 1
             cls, msk, attn_logits = self.forward_prediction_heads(
-                output, mask_features, size_list[(i + 1) % self.num_feature_levels], need_attn_mask=not last, need_masks=last)
+                output, mask_features, size_list[(i + 1) % self.num_feature_levels], need_attn_mask=not last, need_masks=last,
+                gathered=gathered)
             predictions_class.append(cls)
             predictions_mask.append(msk)
         out = {

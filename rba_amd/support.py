@@ -53,27 +53,41 @@ class OODEvaluator:
                                use_gaussian_smoothing=False, upper_limit=450):
         """Batch-1 scoring loop (support.py:353-399).  Returns numpy arrays like the reference."""
         anomaly_score, ood_gts, predictions = [], [], []
+        on_gpu = torch.device(device).type == "cuda"
+
+        def to_host(t):
+            """device -> pinned host buffer without blocking the launch thread (the reference's .cpu() per image, support.py:375,
+            390, stalls the stream once per image); everything is synchronised once after the loop"""
+            if not (on_gpu and t.is_cuda):
+                return t.cpu()
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            return h
+
         for jj, (x, y) in enumerate(loader):
             if jj >= upper_limit:
                 break
-            x = x.to(device)
+            x = x.to(device, non_blocking=True)
             ood_gts.append(np.asarray(y.cpu()))
             mode = getattr(self.anomaly_score_func, "rba_score_mode", None)     # set on rba_amd.evaluate_ood's score functions
             if return_preds and mode is not None and hasattr(self.model, "rba_scores"):
                 # one forward instead of the reference's two (support.py:380,386)
                 score, preds = self.model.rba_scores([{"image": x[0]}], return_argmax=True, score=mode)[0]
-                predictions.append(preds.to(torch.int64).unsqueeze(0).cpu().numpy())
+                predictions.append(to_host(preds.to(torch.int64).unsqueeze(0)))
             else:
                 score = self.get_anomaly_score(x)
                 if return_preds:
                     logits = self.get_logits(x)
-                    predictions.append(logits[:, :19].max(dim=1)[1].cpu().numpy())
+                    predictions.append(to_host(logits[:, :19].max(dim=1)[1]))
             if use_gaussian_smoothing:                                  # transforms.GaussianBlur(7, sigma=1), support.py:366-383
                 score = ops.gaussian_blur(score.contiguous(), 7, 1.0)
-            anomaly_score.append(score.cpu().numpy())
-        ood_gts, anomaly_score = np.array(ood_gts), np.array(anomaly_score)
+            anomaly_score.append(to_host(score))
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        ood_gts = np.array(ood_gts)
+        anomaly_score = np.array([t.numpy() for t in anomaly_score])
         if return_preds:
-            return anomaly_score, ood_gts, np.array(predictions)
+            return anomaly_score, ood_gts, np.array([t.numpy() for t in predictions])
         return anomaly_score, ood_gts
 
     def evaluate_ood_bootstrapped(self, dataset, ratio, trials, device=torch.device("cpu"), batch_size=1, num_workers=10):

@@ -227,6 +227,15 @@ def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
     mtime = (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns
     E.main(argv)
     assert (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns == mtime
+    # every pipelining mode of the scoring loop gives the same pooled metrics: decode threads, HIP streams, hipGraph replay
+    for k, extra in enumerate((["--num_workers", "0", "--streams", "1"], ["--num_workers", "3", "--streams", "2", "--graph", "1"],
+                               ["--num_workers", "2", "--streams", "1", "--graph", "1"])):
+        out = tmp_path / f"results_{k}"
+        E.main(argv[:4] + ["--out_path", str(out), "--verbose", "false"] + extra)
+        with open(out / "tiny" / "results.pkl", "rb") as f:
+            alt = pickle.load(f)
+        for name in res:
+            assert all(abs(alt[name][m] - res[name][m]) < 1e-12 for m in res[name]), (extra, name, alt[name], res[name])
 
 
 @pytest.mark.parametrize("name", ["tiny1", "tiny3"])
@@ -282,6 +291,17 @@ def test_requested_output_resolution(golden):
     assert maxerr(out["rba"], ref_ops.rba_score(want)) < 1e-4
     with pytest.raises(NotImplementedError):
         model([{"image": image}], return_aux=True)
+    # TEST.SEM_SEG_POSTPROCESSING_BEFORE_INFERENCE (maskformer_model.py:205-209, 316-320): the mask logits are cropped and resized
+    # first, the class contraction runs at the requested resolution -- a different result (sigmoid does not commute with resizing)
+    model.sem_seg_postprocess_before_inference = True
+    out2 = model([{"image": image, "height": 120, "width": 200}], return_argmax=True)[0]
+    up = ref_ops.upsample_bilinear(T(g["pred_masks"])[None], (64, 96))[0][:, :60, :90]
+    up = ref_ops.upsample_bilinear(up[None], (120, 200))[0]
+    want2 = ref_ops.semantic_inference(T(g["pred_logits"]), up)
+    assert maxerr(out2["sem_seg"], want2) < 2e-4 and maxerr(out2["rba"], ref_ops.rba_score(want2)) < 2e-4
+    assert (want2 - want).abs().max() > 1e-3
+    same = model([{"image": image}])[0]                           # no size request: the flag changes nothing
+    assert maxerr(same["sem_seg"], g["sem_seg"]) < 1e-4
 
 
 @pytest.mark.parametrize("arch", ["r50_1dl", "swin_b_1dl"])
