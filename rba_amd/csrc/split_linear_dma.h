@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256 + 64 * L) void split_linear_v4_kernel(const flo
     }
   };
 
+  if (PROBE & 32) { if (wave < 4) __builtin_amdgcn_s_setprio(1); }                 // tune builds: static priority for the MFMA waves
+  if (PROBE & 64) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }                //              ... or for the loader waves
   if (L > 0 && wave >= 4) {                                                        // ---------------- loader waves
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d, d);

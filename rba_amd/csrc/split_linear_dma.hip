@@ -1,8 +1,9 @@
 // K6 -- fp32-accurate Linear on the bf16 matrix pipe ("bf16x6"): product dispatch of rba_split_linear_f32 onto the all-LDS-DMA
 // kernels of split_linear_dma.h.  (reference: the nn.Linear calls of backbone/swin.py:44-71, :131-171, :319-343.)
 // Configurations (tools/gemm_v4_sweep.py on every Swin-B / Swin-L / C5 token shape, profiles/r02_split_linear.txt):
-//   * default: 128 x 128 tile, 4 MFMA waves (32 rows x 128 columns each) + 4 loader waves, two 16-wide k sub-stages per barrier,
-//     ring of two super-buffers (80 KB LDS, two workgroups per CU);
+//   * default: 128 x 128 tile, 4 MFMA waves (32 rows x 128 columns each) + 4 loader waves, one 16-wide k sub-stage per barrier, DMA two
+//     stages ahead into a ring of three 20 KB stage buffers (60 KB LDS: two workgroups per CU and room for another stream's kernels --
+//     with the equally fast 80 KB ring the two-stream bench lost 2 %);
 //   * fewer than 256 such tiles (Swin stage 4 at one image): 128 x 64 tiles, persistent workgroups -- twice the workgroups, so every
 //     CU still gets two.
 #include "split_linear_dma.h"
@@ -21,7 +22,7 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
   if (tiles128 < 256 && N > 64 && (K >> 5) >= 2)
     rc = launch_v5_act<1, 2, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 2, st);
   else
-    rc = launch_v4_act<1, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, st);
+    rc = launch_v4_act<1, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, st);
   if (rc) return rc;
   return rba_launch_status();
 }

@@ -86,6 +86,9 @@ extern "C" int rba_split_linear_v4_f32(const float* x, const void* weight_planes
     case 6402412: rc = launch_v5_act<2, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
     case 6402421: rc = launch_v5_act<2, 4, 2, 1, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
     case 6401422: rc = launch_v5_act<1, 4, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 1, st); break;
+    case 9990032: rc = launch_v4<0, 1, 4, 1, 2, 32, 4>(x, wp, bias, out, M, N, K, st); break;   // 401412 + s_setprio 1 in the MFMA waves
+    case 9990064: rc = launch_v4<0, 1, 4, 1, 2, 64, 4>(x, wp, bias, out, M, N, K, st); break;   // 401412 + s_setprio 1 in the loader waves
+    case 401412: rc = launch_v4_act<1, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, st); break;
     // v8 (A direct, flag-synchronised ring, no barrier): 9500000 + 100 CT + 10 R + L
     case 9500432: rc = launch_v8_act<4, 3, 2>(act, x, wp, bias, out, M, N, K, st); break;
     case 9500434: rc = launch_v8_act<4, 3, 4>(act, x, wp, bias, out, M, N, K, st); break;
