@@ -181,11 +181,13 @@ int launch_mfma(const float* embed, const float* feat, float* out, int B, int Q,
   const size_t shm = (size_t)C * 113 * sizeof(float);
   if (shm > 160 * 1024) return (int)hipErrorInvalidValue;
   auto kern = mask_logits_mfma_kernel<WAVES, PF>;
-  static size_t shm_enabled = 0;                      // raise the dynamic-LDS cap once per instantiation, not per launch
-  if (shm > 64 * 1024 && shm > shm_enabled) {
+  static size_t shm_enabled[64];                      // raise the dynamic-LDS cap once per instantiation AND device, not per launch
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+  if (shm > 64 * 1024 && shm > shm_enabled[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return (int)e;
-    shm_enabled = shm;
+    shm_enabled[dev] = shm;
   }
   const int64_t per_block = 64LL * WAVES;
   dim3 grid((unsigned)((N + per_block - 1) / per_block), B);

@@ -77,6 +77,20 @@ __device__ __forceinline__ float gelu_erf(float v) {
   return 0.5f * v * one_plus_erf;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: set it once per device (one process per GPU
+// is the deployment model, but a process that touches a second device must not inherit the first one's "already set")
+template <typename KernelT>
+static inline int ensure_dynamic_lds(KernelT kernel, size_t bytes, unsigned char (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+  if (!done[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = 1;
+  }
+  return 0;
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, u32x4_t* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -551,9 +565,8 @@ int launch_v5(const float* x, const u32x4_t* wp, const float* bias, float* out, 
   const int64_t MT = (M + BM - 1) / BM;
   const int NT = (N + BN - 1) / BN;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)split_linear_v5_kernel<ACT, RT, CT, G, D, L, false, MW, WIDE>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-  if (attr != hipSuccess) return (int)attr;
+  static unsigned char attr_done[64];
+  if (const int rc = ensure_dynamic_lds(split_linear_v5_kernel<ACT, RT, CT, G, D, L, false, MW, WIDE>, dyn, attr_done)) return rc;
   const int64_t tiles = MT * NT;
   int64_t grid = (int64_t)256 * wgs_per_cu;
   grid = tiles < grid ? tiles : grid;
@@ -580,9 +593,8 @@ int launch_v4(const float* x, const u32x4_t* wp, const float* bias, float* out, 
   const int64_t MT = (M + BM - 1) / BM;
   const int NT = (N + BN - 1) / BN;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)split_linear_v4_kernel<ACT, RT, CT, G, D, PROBE, L>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-  if (attr != hipSuccess) return (int)attr;
+  static unsigned char attr_done[64];
+  if (const int rc = ensure_dynamic_lds(split_linear_v4_kernel<ACT, RT, CT, G, D, PROBE, L>, dyn, attr_done)) return rc;
   hipLaunchKernelGGL((split_linear_v4_kernel<ACT, RT, CT, G, D, PROBE, L>), dim3((unsigned)(MT * NT)), dim3(256 + 64 * L), dyn, stream, x, wp, bias, out,
                      (int)M, N, K, (int)MT, NT);
   return 0;

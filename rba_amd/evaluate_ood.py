@@ -108,7 +108,6 @@ def build_parser():
     p.add_argument("--selected_datasets", nargs="*", type=str, default=[])
     p.add_argument("--score_func", type=str, default="rba", choices=sorted(SCORE_FUNCS))
     p.add_argument("--upper_limit", type=int, default=1300)
-    p.add_argument("--graph", type=int, default=0, help="1: replay the forward of each image shape from a captured hipGraph (measured: no gain, the loop is GPU bound)")
     p.add_argument("--streams", type=int, default=2, help="HIP streams the batch-1 forwards alternate on (1 = the reference's serial loop)")
     return p
 
@@ -120,7 +119,8 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     Pipeline (the reference feeds its loop from DataLoader(batch_size, num_workers), :210-211): images are decoded ahead of the GPU
     by `--num_workers` threads (datasets.prefetch), copied to the GPU and scored batch-1 on alternating HIP streams (`--streams`,
     default 2) so that the host-side launch work and the under-occupied kernels of one image overlap the other image; score maps and
-    labels never leave the GPU (the metric is a GPU sort)."""
+    labels never leave the GPU (the metric is a GPU sort).  (Replaying the forward from a captured hipGraph was measured too: no gain,
+    the loop is GPU bound -- profiles/r02_evaluator.json -- so it is not offered.)"""
     import time
     from . import distributed as D
     from .datasets import prefetch
@@ -137,8 +137,6 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
     scores, labels = [], []
     seen_shapes = set()
-    use_graph = on_gpu and bool(getattr(args, "graph", 0)) and not args.store_anomaly_scores
-    graphs = {}                                                    # (shape, stream slot) -> GraphedScore | False (capture failed)
     t0 = time.perf_counter()
     k = 0
     for xb, yb in loader:
@@ -162,21 +160,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
             with ctx:
                 x = xb[j].to(dev, non_blocking=True)
                 y = yb[j].to(dev, non_blocking=True)
-                s = None
-                if use_graph and not first_of_shape:
-                    gkey = (shape, k % len(streams))
-                    if gkey not in graphs:
-                        try:
-                            graphs[gkey] = GraphedScore(model, score_func, x, st)
-                        except Exception as e:                     # capture is an optimisation: report once, score eagerly
-                            graphs[gkey] = False
-                            if rank == 0:
-                                print(f"[rba_amd] hipGraph capture failed ({type(e).__name__}: {e}); scoring eagerly")
-                            torch.cuda.synchronize(dev)
-                    if graphs[gkey]:
-                        s = graphs[gkey](x)
-                if s is None:
-                    s = score_func(model, x[None])
+                s = score_func(model, x[None])
                 if args.store_anomaly_scores:
                     vis = os.path.join("anomaly_scores", model_name, dataset_name)
                     os.makedirs(vis, exist_ok=True)
@@ -193,38 +177,10 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if timing is not None:
-        timing.update(images=k, seconds=dt, images_per_s=(k / dt if dt > 0 else 0.0), num_workers=nw, streams=len(streams),
-                      hip_graphs=sum(1 for g in graphs.values() if g))
+        timing.update(images=k, seconds=dt, images_per_s=(k / dt if dt > 0 else 0.0), num_workers=nw, streams=len(streams))
     s_all = torch.cat(scores) if scores else torch.empty(0, device=dev)
     y_all = torch.cat(labels) if labels else torch.empty(0, dtype=torch.bool, device=dev)
     return D.pooled_ood_metrics(s_all, y_all)
-
-
-class GraphedScore:
-    """One score function on one image shape as a captured hipGraph: the ~370 kernel launches of a forward cost the Python thread
-    more than the GPU needs to run them once decode threads compete for the interpreter (evaluator 55 -> graph-replayed images/s in
-    profiles/r02_evaluator.json); a replay is one call.  The input is copied into a static buffer, the score map is a static output
-    that the caller must consume (on the same stream) before the next replay of this instance."""
-
-    def __init__(self, model, score_func, example_x, stream):
-        self.static_x = example_x.clone()
-        if stream == torch.cuda.default_stream(example_x.device):  # capture needs a non-default stream; replay may use any
-            stream = torch.cuda.Stream(device=example_x.device)
-            stream.wait_stream(torch.cuda.current_stream(example_x.device))
-        with torch.cuda.stream(stream):
-            for _ in range(2):                                    # eager warm-up on the capture stream: lazy caches, library plans
-                score_func(model, self.static_x[None])
-        stream.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: the decode threads allocate pinned memory meanwhile, which must not invalidate this thread's capture
-        with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="thread_local"):
-            self.static_out = score_func(model, self.static_x[None])
-        torch.cuda.current_stream(example_x.device).wait_stream(stream)
-
-    def __call__(self, x):
-        self.static_x.copy_(x, non_blocking=True)
-        self.graph.replay()
-        return self.static_out
 
 
 class _nullcontext:

@@ -43,7 +43,7 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
         offsets = ops.linear(query, self.sampling_offsets).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        weights = F.softmax(ops.linear(query, self.attention_weights).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
         if reference_points.shape[-1] != 2:
             raise ValueError(f"Last dim of reference_points must be 2 on this path, got {reference_points.shape[-1]}")
         normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(offsets.dtype)

@@ -367,6 +367,9 @@ def split_linear_supported(N, K):
     return K % 32 == 0 and N >= 1 and K >= 32
 
 
+TILES_MIN = 64
+
+
 def split_linear_pays(M, N, K, gelu=False):
     """Where the bf16x6 kernel beats hipBLASLt's fp32 GEMM on MI355X (tools/gemm_v4_sweep.py, profiles/r02_split_linear.txt):
     1.3-1.7x whenever there are at least 64 tiles of 128 x 128 (below 256 tiles the library switches to 128 x 64 tiles so that
@@ -374,7 +377,7 @@ def split_linear_pays(M, N, K, gelu=False):
     if not split_linear_supported(N, K) or K < 64:
         return False
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    return tiles >= 64
+    return tiles >= TILES_MIN
 
 
 @_hip_op

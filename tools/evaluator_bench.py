@@ -54,10 +54,9 @@ def main():
     a = A.complete(A.ARCHS["swin_b_1dl"])
     torch.save({"model": A.seeded_weights(a, 0)}, os.path.join(mdir, "model_final.pth"))
     res = {"n_images": n, "image": "1024x2048 PNG", "dataset_write_s": round(t_data, 1)}
-    for tag, extra in (("pipelined_graph_2streams", ["--num_workers", "8", "--streams", "2", "--graph", "1"]),
-                       ("pipelined_graph_1stream", ["--num_workers", "8", "--streams", "1", "--graph", "1"]),
-                       ("pipelined_eager_2streams", ["--num_workers", "8", "--streams", "2", "--graph", "0"]),
-                       ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1", "--graph", "0"])):
+    for tag, extra in (("pipelined_2streams", ["--num_workers", "8", "--streams", "2"]),
+                       ("pipelined_1stream", ["--num_workers", "8", "--streams", "1"]),
+                       ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1"])):
         out = os.path.join(work, "results_" + tag)
         timing = {}
         args = E.build_parser().parse_args(["--models_folder", os.path.join(work, "ckpts"), "--datasets_folder", os.path.join(work, "data"),
@@ -67,10 +66,9 @@ def main():
         from rba_amd.datasets import get_dataset
         ds = get_dataset("fishyscapes_laf", args.datasets_folder)
         E.run_evaluations(model, torch.utils.data.Subset(ds, [0, 1]), "warm", "fishyscapes_laf", args)       # warm-up: plans, weight planes
-        # (each run_evaluations call captures its own graphs: the capture cost, ~3 forwards per stream, is inside the timed loop)
         m = E.run_evaluations(model, ds, "swin_b_1dl", "fishyscapes_laf", args, timing=timing)
         res[tag] = {"images_per_s": round(timing["images_per_s"], 2), "seconds": round(timing["seconds"], 3), "metrics": m,
-                    "num_workers": timing["num_workers"], "streams": timing["streams"], "hip_graphs": timing["hip_graphs"]}
+                    "num_workers": timing["num_workers"], "streams": timing["streams"]}
         del model
         torch.cuda.empty_cache()
     print(json.dumps(res))
