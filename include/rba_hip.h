@@ -152,6 +152,16 @@ int rba_split_weight_bf16x3(const float* weight, void* packed, int N, int K, voi
 int rba_split_linear_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
                          int act, void* stream);
 
+/* The same Linear with THREE f16 MFMAs per fp32 product (csrc/split_linear_h3.h): x = h + 2^-11 l with h = f16(x),
+ * l = f16((x - h) 2^11); x w = h_x h_w + 2^-11 (h_x l_w + l_x h_w) to 2^-22 relative per term (as accurate as an fp32 GEMM,
+ * whose accumulation rounding dominates), for |x|, |w| < 65504 -- beyond f16's range the output row is NaN.
+ * rba_split_weight_f16x2:     weight [N,K] fp32 -> `packed`, 4*Np*K bytes: [Np/128][K/16][2][128][2][8] f16, sub-stage 2b+g of the
+ *                             32-wide k block b holds for row r, in slot h ^ ((r >> 3) & 1), k = 32b + 16h + 8g + (0..7).  K % 32 == 0.
+ * rba_split_linear_f16x3_f32: as rba_split_linear_f32 with `weight_packed` from rba_split_weight_f16x2. */
+int rba_split_weight_f16x2(const float* weight, void* packed, int N, int K, void* stream);
+int rba_split_linear_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                               int act, void* stream);
+
 /* The same GEMM with NHWC rows in and NCHW out: out[(b*N + n)*P + p] = sum_k x[b*P + p, k] * weight[n, k] + bias[n],
  * P = rows_per_image, M % P == 0 (the mask-feature 1x1 convolution of pixel_decoder/msdeformattn.py:298-306). */
 int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N,

@@ -6,7 +6,7 @@
 //     with the equally fast 80 KB ring the two-stream bench lost 2 %);
 //   * fewer than 256 such tiles (Swin stage 4 at one image): 128 x 64 tiles, persistent workgroups -- twice the workgroups, so every
 //     CU still gets two.
-#include "split_linear_dma.h"
+#include "split_linear_h3.h"
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {
@@ -23,6 +23,36 @@ extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, c
     rc = launch_v5_act<1, 2, 2, 2, 4>(act, x, wp, bias, out, M, N, K, 2, st);
   else
     rc = launch_v4_act<1, 4, 1, 2, 4>(act, x, wp, bias, out, M, N, K, st);
+  if (rc) return rc;
+  return rba_launch_status();
+}
+
+// ---- the f16x3 form (split_linear_h3.h): three f16 MFMAs per fp32 product, |x|, |w| < 65504
+extern "C" int rba_split_weight_f16x2(const float* weight, void* packed, int N, int K, void* stream) {
+  RBA_CHECK_ARG(N >= 0 && K >= 0 && (K % 32) == 0);
+  if (N == 0 || K == 0) return 0;
+  RBA_CHECK_ARG(weight && packed && (((uintptr_t)weight | (uintptr_t)packed) & 15) == 0);
+  rba_begin();
+  const int64_t total = (int64_t)((N + 127) >> 7) * (K >> 4) * 256;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split_weight_f16x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, weight, reinterpret_cast<u32x4_t*>(packed),
+                     N, K);
+  return rba_launch_status();
+}
+
+extern "C" int rba_split_linear_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N,
+                                          int K, int act, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0 && act >= 0 && act <= 2);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  int rc;
+  if (tiles128 >= 320 || N <= 64) rc = launch_h3_act<4>(act, x, wp, bias, out, M, N, K, st);
+  else rc = launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st);
   if (rc) return rc;
   return rba_launch_status();
 }

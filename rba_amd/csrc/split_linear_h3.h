@@ -1,0 +1,284 @@
+// K6, third form ("f16x3"): fp32-accurate Linear on the f16 matrix pipe with THREE products per fp32 product.
+// (reference: the nn.Linear calls of backbone/swin.py:44-71 (Mlp), :131-171 (qkv / proj), :319-343 (PatchMerging).)
+//
+// Arithmetic.  Every fp32 x with |x| < 65504 is  x = h + 2^-11 l + e,  h = f16(x) (rne), l = f16((x - h) 2^11) (x - h is exact
+// in fp32; scaled by 2^11 it has x's own magnitude, so it never falls into f16's subnormals unless x itself is below 6e-5, and
+// even then the scaled residual keeps the bits h lost), |e| <= 2^-23 |x|.  With the weight split the same way,
+//     x w = h_x h_w + 2^-11 (h_x l_w + l_x h_w) + O(2^-22 |x w|)
+// (dropped: l_x l_w 2^-22 and the two e terms).  f16 x f16 products are exact in fp32, so three v_mfma_f32_32x32x16_f16 per k-step,
+// the first into a "main" accumulator and the other two into a "low" accumulator that is added with weight 2^-11 in the epilogue,
+// give the fp32 product to 2^-22 relative PER TERM with unbiased (rne) errors: against fp64 the result is as close as hipBLASLt's
+// fp32 GEMM (whose own accumulation rounding, ~sqrt(K) 2^-24, dominates both) -- tests/test_kernels_gpu.py measures that on
+// every Swin shape.  Domain: |x|, |w| < 65504 (f16's range; beyond it h is inf and the output row is NaN -- loud, never silently
+// wrong; the bf16x6 form of split_linear_dma.h has fp32's full range and stays selectable).
+//
+// Why (profiles/r02_k6_*.txt): the bf16x6 kernel is pinned at the LDS-DMA fill rate of the chip (655 MB per launch through
+// global_load_lds at ~7 TB/s = 93 us for Swin stage-3 fc1, whatever the tiling), and its six MFMAs per product cost 63 us on their
+// own.  Here the matrix work halves (three MFMAs), the weight image shrinks from 6 to 4 bytes per element, and NOTHING goes
+// through LDS-DMA: the activation rows a wave owns are loaded straight into its registers (each lane 64 contiguous bytes per
+// 32-wide k block = one full 128-byte line per row and lane pair) and split there -- activations never touch LDS -- and the
+// packed weight block is copied global -> registers -> LDS by the four waves together, one block ahead.
+//
+// Layout.  Packed weight (rba_split_weight_f16x2): [N/128][K/16][2 planes][128 rows][2 slots] x 16 B, plane 0 = h, plane 1 = l;
+// sub-stage s = 2 b + g of 32-wide block b holds, for row r, slot h ^ ((r >> 3) & 1):  k = 32 b + 16 h + 8 g + (0..7)  -- lane
+// group h = lane / 32 of the MFMA owns bytes [64 h, 64 h + 64) of its row's 128-byte block and uses them in two MFMAs (g = 0, 1).
+#pragma once
+#include "split_linear_dma.h"
+
+namespace {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+// 8 fp32 -> the two f16x8 MFMA operands: h = f16(x), l = f16((x - h) * 2^11) = f16(fma(h, -2^11, 2^11 x)) (the fma is exact).
+// Four VALU per pair: v_cvt_pk_f16_f32, v_pk_mul_f32, and v_fma_mixlo/mixhi_f16 reading the f16 halves of h in place.
+__device__ __forceinline__ void split_h3(const f32x4 u, const f32x4 v, f16x8_t& h, f16x8_t& l) {
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+  u32x4_t hp, lp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2_t a = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]};
+    const uint32_t ap = __builtin_bit_cast(uint32_t, a);
+    const f32x2 t = (f32x2){x[2 * i], x[2 * i + 1]} * 2048.0f;
+    uint32_t r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(ap), "v"(-2048.0f), "v"(t.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(ap), "v"(-2048.0f), "v"(t.y));
+    hp[i] = ap;
+    lp[i] = r;
+  }
+  h = __builtin_bit_cast(f16x8_t, hp);
+  l = __builtin_bit_cast(f16x8_t, lp);
+}
+
+// gelu_erf (split_linear_dma.h) on two values with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32): same formula, same
+// rounding per operation, half the VALU issues
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+  const f32x2 x = (f32x2){fabsf(v.x), fabsf(v.y)} * 0.70710678118654752440f;
+  const f32x2 d = x * 0.3275911f + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2 p = t * 1.061405429f + -1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t + -0.284496736f;
+  p = p * t + 0.254829592f;
+  const f32x2 nx2 = -x * x;
+  const f32x2 ex = {__expf(nx2.x), __expf(nx2.y)};
+  const f32x2 e = p * t * ex;
+  const f32x2 w = {v.x >= 0.f ? 2.0f - e.x : e.x, v.y >= 0.f ? 2.0f - e.y : e.y};
+  return v * 0.5f * w;
+}
+
+// One thread per 16-byte unit of the packed image (see the layout above); rows N .. Np - 1 of the last 128-row tile are zero.
+__global__ void split_weight_f16x2_kernel(const float* __restrict__ w, u32x4_t* __restrict__ packed, int N, int K) {
+  const int S = K >> 4;
+  const int64_t total = (int64_t)((N + 127) >> 7) * S * 256;                        // (tile, sub-stage, row, slot)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int slot = (int)(i & 1), r = (int)((i >> 1) & 127);
+    const int64_t ts = i >> 8;
+    const int s = (int)(ts % S), nt = (int)(ts / S);
+    const int h = slot ^ ((r >> 3) & 1);
+    const int k0 = 32 * (s >> 1) + 16 * h + 8 * (s & 1);
+    const int n = nt * 128 + r;
+    f16x8_t p0, p1;
+    if (n < N) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(w + (int64_t)n * K + k0);
+      split_h3(src[0], src[1], p0, p1);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p0[e] = p1[e] = (_Float16)0.f;
+    }
+    u32x4_t* dst = packed + ts * 512 + r * 2 + slot;
+    dst[0] = __builtin_bit_cast(u32x4_t, p0);
+    dst[256] = __builtin_bit_cast(u32x4_t, p1);
+  }
+}
+
+// ACT: 0 none, 1 exact GELU, 2 ReLU.  CT: 32-column MFMA tiles per wave = tile width / 32 (BN = 32 CT; 128 must be a multiple).
+// Tile 128 x BN, four waves, wave w owns rows 32 w .. 32 w + 31 x all BN columns; two workgroups per CU (256 registers a wave).
+// PROBE (tune builds only, results wrong): bit 0 no weight loads in the loop, bit 1 no activation loads in the loop, bit 2 no epilogue,
+// bit 3 weight fragments read once, bit 4 no activation split, bit 5 no weight ds_write in the loop, bit 6 no barrier in the loop
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false>
+__global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+                                                                const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                                int K, int MT, int NT, unsigned long long* dbg = nullptr) {
+  unsigned long long tm[4];
+  if (TIMING) tm[0] = wall_clock64();
+  constexpr int BM = 128, BN = 32 * CT;
+  constexpr int SUBW = 4 * BN;                                                     // 16-byte units of one sub-stage image
+  constexpr int BLK = 2 * SUBW;                                                    // ... of one 32-wide k block
+  constexpr int UPL = BLK / 256;                                                   // units per lane per block
+  static_assert(BLK % 256 == 0 && 128 % BN == 0, "tile width");
+  __shared__ __attribute__((aligned(16))) u32x4_t lds[2 * BLK];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int nb = MT * NT;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);                     // XCD-aware: one XCD, one run of tiles (n fastest)
+  const int mt = bid / NT, nt = bid - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int NB = K >> 5, S16 = K >> 4;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // ---- weight copy: LDS unit u = tid + 256 q of the block image [g][plane][BN rows][2 slots] <- packed tile (n0 >> 7), sub-stage
+  // 2 b + g, plane, rows (n0 & 127) ..  = one workgroup-uniform base (SGPRs) + a constant per q + ONE per-lane 32-bit offset
+  constexpr int QSTEP = (CT == 4) ? 256 : 512;                                     // source units between consecutive q
+  const char* wbase = reinterpret_cast<const char*>(Wp + (int64_t)(n0 >> 7) * S16 * 512 + (n0 & 127) * 2);
+  uint32_t woff;
+  {
+    const int g = tid / SUBW, rem = tid - g * SUBW, p = rem / (2 * BN), rr = rem - p * (2 * BN);
+    woff = (uint32_t)(g * 512 + p * 256 + rr) * 16u;
+  }
+  // ---- activation rows of this lane: uniform base of the row tile + per-lane 32-bit offset
+  int row = m0 + 32 * wave + l31;
+  row = (row < M ? row : M - 1) - m0;
+  const char* xbase = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
+  const uint32_t xoff = ((uint32_t)row * (uint32_t)K + 16u * lh) * 4u;
+
+  f32x16_t accm[CT], accl[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accm[j][r] = accl[j][r] = 0.f;
+
+  // Software pipeline (branch-free: block indices are clamped, the surplus loads of the last blocks are re-reads nobody uses).
+  // Weight block c: global -> registers issued during block c - 2, registers -> LDS buffer c & 1 at the head of block c - 1
+  // (every wave left that buffer at the barrier that ended block c - 2), read during block c.  Activation block c: global ->
+  // registers (set c & 1) issued during block c - 2, right after that set was split.
+  u32x4_t wr[UPL];
+  f32x4 xr[2][4];
+  const int last = NB - 1;
+  auto wload = [&](int c, u32x4_t (&r)[UPL]) {
+    const char* src = wbase + (int64_t)(c < last ? c : last) * 16384;
+#pragma unroll
+    for (int q = 0; q < UPL; ++q) r[q] = *reinterpret_cast<const u32x4_t*>(src + q * (QSTEP * 16) + woff);
+  };
+  auto xload = [&](int c, f32x4 (&r)[4]) {
+    const char* src = xbase + (c < last ? c : last) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const f32x4*>(src + q * 16 + xoff);
+  };
+  wload(0, wr);
+  xload(0, xr[0]);
+  xload(1, xr[1]);
+#pragma unroll
+  for (int q = 0; q < UPL; ++q) lds[tid + 256 * q] = wr[q];
+  wload(1, wr);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  const int fb = l31 * 2 + (lh ^ ((l31 >> 3) & 1));                                // + g SUBW + (p BN + 32 j) 2
+  if (TIMING) tm[1] = wall_clock64();
+  auto block = [&](int b, const u32x4_t* img, u32x4_t* nxt, f32x4 (&xc)[4]) {
+    // wr holds weight block b + 1: registers -> the other LDS buffer, then refill with block b + 2
+    if (!(PROBE & 32)) {
+#pragma unroll
+      for (int q = 0; q < UPL; ++q) nxt[tid + 256 * q] = wr[q];
+    }
+    if (!(PROBE & 1)) wload(b + 2, wr);
+    f16x8_t ah[2], al[2];
+    if (PROBE & 16) {
+      ah[0] = __builtin_bit_cast(f16x8_t, xc[0]); al[0] = __builtin_bit_cast(f16x8_t, xc[1]);
+      ah[1] = __builtin_bit_cast(f16x8_t, xc[2]); al[1] = __builtin_bit_cast(f16x8_t, xc[3]);
+    } else {
+      split_h3(xc[0], xc[1], ah[0], al[0]);
+      split_h3(xc[2], xc[3], ah[1], al[1]);
+    }
+    if (!(PROBE & 2)) xload(b + 2, xc);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      __builtin_amdgcn_sched_barrier(0);          // keep the fragment reads of g = 1 below the MFMAs of g = 0 (32 registers, not 64)
+      f16x8_t bh[CT], bl[CT];
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const u32x4_t* im = (PROBE & 8) ? lds : img;
+        bh[j] = __builtin_bit_cast(f16x8_t, im[g * SUBW + fb + 64 * j]);
+        bl[j] = __builtin_bit_cast(f16x8_t, im[g * SUBW + fb + 2 * BN + 64 * j]);
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh[j], accm[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl[j], accl[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh[j], accl[j], 0, 0, 0);
+    }
+    if (!(PROBE & 64)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  int b = 0;
+  if (NB & 1) {                                                                    // odd block count: peel one, then pairs
+    block(0, lds, lds + BLK, xr[0]);
+    b = 1;
+    for (; b < NB; b += 2) {
+      block(b, lds + BLK, lds, xr[1]);
+      block(b + 1, lds, lds + BLK, xr[0]);
+    }
+  } else {
+    for (; b < NB; b += 2) {
+      block(b, lds, lds + BLK, xr[0]);
+      block(b + 1, lds + BLK, lds, xr[1]);
+    }
+  }
+
+  // ---- epilogue: lane holds D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] of each 32 x 32 tile
+  if (TIMING) tm[2] = wall_clock64();
+  const bool interior = m0 + BM <= M && n0 + BN <= N;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = n0 + 32 * j + l31;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+    f32x16_t v;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]} + bv;
+      if (ACT == 1) y = gelu_erf2(y);
+      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+      v[r] = y.x;
+      v[r + 1] = y.y;
+    }
+    const int rbase = m0 + 32 * wave + 4 * lh;
+    float* dst = C + (int64_t)rbase * N + col;
+    if (PROBE & 4) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += v[r];
+      if (sum == 1234.5f) dst[0] = sum;
+    } else if (interior) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
+    } else if (col < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = 8 * (r >> 2) + (r & 3);
+        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
+      }
+    }
+  }
+  if (TIMING && tid == 0) {
+    tm[3] = wall_clock64();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dbg[6 * blockIdx.x + i] = tm[i];
+    dbg[6 * blockIdx.x + 4] = xcc;
+    dbg[6 * blockIdx.x + 5] = hw;
+  }
+}
+
+template <int ACT, int CT, int PROBE = 0>
+int launch_h3(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t stream) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3_kernel<ACT, CT, PROBE>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N,
+                     K, (int)MT, NT);
+  return 0;
+}
+
+template <int CT>
+int launch_h3_act(int act, const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t st) {
+  if (act == 1) return launch_h3<1, CT>(x, wp, bias, out, M, N, K, st);
+  if (act == 2) return launch_h3<2, CT>(x, wp, bias, out, M, N, K, st);
+  return launch_h3<0, CT>(x, wp, bias, out, M, N, K, st);
+}
+
+}  // namespace

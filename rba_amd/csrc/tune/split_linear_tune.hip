@@ -2,6 +2,7 @@
 // the ablation builds and the persistent variant.  Built into librba_tune.so (python -m rba_amd.csrc.build --tune); the product
 // library contains only the configurations rba_split_linear_f32 dispatches to.
 #include "split_linear_experiments.h"
+#include "../split_linear_h3.h"
 
 // Timing build of one v5 configuration (tools only): dbg[8 wg + {0..3}] = MFMA wave 0 {barrier wait, compute, epilogue, total}
 // cycles, dbg[8 wg + {4..7}] = loader wave 0 {vmcnt wait, barrier wait, issue, total} (s_memtime ticks).
@@ -112,5 +113,53 @@ extern "C" int rba_split_linear_v4_f32(const float* x, const void* weight_planes
     default: return (int)hipErrorInvalidValue;
   }
   if (rc) return rc;
+  return rba_launch_status();
+}
+
+// f16x3 kernel with an explicit tile width and the ablation builds: cfg = CT + 10 PROBE
+extern "C" int rba_split_linear_h3_tune(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                                        int act, int cfg, void* stream) {
+  RBA_CHECK_ARG(M >= 1 && N >= 1 && K >= 32 && (K % 32) == 0 && act >= 0 && act <= 2);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (cfg) {
+    case 4: rc = launch_h3_act<4>(act, x, wp, bias, out, M, N, K, st); break;
+    case 2: rc = launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st); break;
+    case 1: rc = launch_h3_act<1>(act, x, wp, bias, out, M, N, K, st); break;
+    case 14: rc = launch_h3<1, 4, 1>(x, wp, bias, out, M, N, K, st); break;
+    case 24: rc = launch_h3<1, 4, 2>(x, wp, bias, out, M, N, K, st); break;
+    case 34: rc = launch_h3<1, 4, 3>(x, wp, bias, out, M, N, K, st); break;
+    case 44: rc = launch_h3<1, 4, 4>(x, wp, bias, out, M, N, K, st); break;
+    case 74: rc = launch_h3<1, 4, 7>(x, wp, bias, out, M, N, K, st); break;
+    case 154: rc = launch_h3<1, 4, 15>(x, wp, bias, out, M, N, K, st); break;
+    case 234: rc = launch_h3<1, 4, 23>(x, wp, bias, out, M, N, K, st); break;
+    case 394: rc = launch_h3<1, 4, 39>(x, wp, bias, out, M, N, K, st); break;
+    case 634: rc = launch_h3<1, 4, 63>(x, wp, bias, out, M, N, K, st); break;
+    case 1274: rc = launch_h3<1, 4, 127>(x, wp, bias, out, M, N, K, st); break;
+    case 84: rc = launch_h3<1, 4, 8>(x, wp, bias, out, M, N, K, st); break;
+    case 164: rc = launch_h3<1, 4, 16>(x, wp, bias, out, M, N, K, st); break;
+    case 644: rc = launch_h3<1, 4, 64>(x, wp, bias, out, M, N, K, st); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  if (rc) return rc;
+  return rba_launch_status();
+}
+
+// Timing build of the f16x3 kernel: dbg[6 wg + {0..3}] = s_memrealtime (100 MHz) at entry / loop start / loop end / exit,
+// [4] XCC_ID, [5] HW_ID
+extern "C" int rba_split_linear_h3_timing(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                                          int probe, unsigned long long* dbg, void* stream) {
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 127) / 128;
+  if (probe == 0)
+    hipLaunchKernelGGL((split_linear_h3_kernel<1, 4, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
+                       (int)M, N, K, (int)MT, NT, dbg);
+  else
+    hipLaunchKernelGGL((split_linear_h3_kernel<1, 4, 127, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias,
+                       out, (int)M, N, K, (int)MT, NT, dbg);
   return rba_launch_status();
 }

@@ -187,7 +187,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             ph, pw = h, w
         mfw = self.mask_features.weight
         planes = self._cached(self.mask_features, "_rba_planes",
-                              lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous()))
+                              lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous(), mode="bf16x6"))
         mf = ops.split_linear_nchw_out(prev.view(B * ph * pw, d), planes, self.mask_features.bias, ph * pw,
                                        out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)
         return mf, outs[0], outs[:self.maskformer_num_feature_levels]

@@ -339,15 +339,30 @@ def skinny_linear(x, weight, bias=None, relu=False):
     return out
 
 
+SPLIT_MODE = "f16x3"
+"""Arithmetic of the token Linear (K6).  "f16x3": two f16 pieces per operand, three f16 MFMAs per product -- as accurate as an
+fp32 GEMM for |x|, |w| < 65504 (beyond f16's range the output is NaN, never silently wrong), twice the speed of "bf16x6": three
+bf16 pieces, six MFMAs, fp32's full range."""
+
+
 @_hip_op
-def split_weight(weight):
-    """fp32 weight [N,K] -> the three bf16 planes (hi, mid, lo; their sum is exactly `weight`) packed as the kernel's LDS
-    tiles: [N/128, K/16, 3, 128, 2, 8] bf16, the 8-element half h of row r in slot h ^ ((r >> 3) & 1).  Once per weight load."""
+def split_weight(weight, mode=None):
+    """fp32 weight [N,K] -> the packed operand planes of the token Linear, tiled as the kernel's LDS image (once per weight load):
+    mode "bf16x6": three bf16 planes hi, mid, lo (sum exactly `weight`), [N/128, K/16, 3, 128, 2, 8] bf16, the 8-element half h of
+    row r in slot h ^ ((r >> 3) & 1);  mode "f16x3": h = f16(w), l = f16((w - h) 2^11), [N/128, K/16, 2, 128, 2, 8] float16 with
+    the k order of csrc/split_linear_h3.h.  Default: ops.SPLIT_MODE."""
     lib = _lib.load()
     _chk(weight, "weight", dim=2)
     N, K = weight.shape
     if not split_linear_supported(N, K):
         raise RbaHipError("split_weight needs weight [N,K] with K % 32 == 0")
+    mode = SPLIT_MODE if mode is None else mode
+    if mode == "f16x3":
+        packed = torch.empty(((N + 127) // 128, K // 16, 2, 128, 2, 8), dtype=torch.float16, device=weight.device)
+        _lib.check(lib.rba_split_weight_f16x2(_p(weight), _p(packed), N, K, _stream()), "rba_split_weight_f16x2")
+        return packed
+    if mode != "bf16x6":
+        raise RbaHipError(f"unknown split mode {mode!r}")
     packed = torch.empty(((N + 127) // 128, K // 16, 3, 128, 2, 8), dtype=torch.bfloat16, device=weight.device)
     _lib.check(lib.rba_split_weight_bf16x3(_p(weight), _p(packed), N, K, _stream()), "rba_split_weight_bf16x3")
     return packed
@@ -355,11 +370,15 @@ def split_weight(weight):
 
 @_hip_op
 def unpack_split_weight(packed):
-    """Inverse of split_weight's tiling: -> planes [3, Np, K] bf16, Np = N rounded up to 128 (for inspection and tests)."""
-    nt, S = packed.shape[:2]
+    """Inverse of split_weight's tiling: -> planes [3, Np, K] bf16 or [2, Np, K] float16, Np = N rounded up to 128 (for inspection
+    and tests)."""
+    nt, S, P = packed.shape[:3]
     r = torch.arange(128, device=packed.device)
     flip = ((r >> 3) & 1).bool()
     un = torch.where(flip.view(1, 1, 1, 128, 1, 1), packed.flip(4), packed)          # slot -> half
+    if P == 2:        # f16x3: sub-stage 2 b + g, half h holds k = 32 b + 16 h + 8 g + (0..7)
+        un = un.reshape(nt, S // 2, 2, P, 128, 2, 8).permute(3, 0, 4, 1, 5, 2, 6)     # [P, nt, row, b, h, g, 8]
+        return un.reshape(P, nt * 128, S * 16)
     return un.permute(2, 0, 3, 1, 4, 5).reshape(3, nt * 128, S * 16)
 
 
@@ -390,7 +409,7 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False):
     M = x.numel() // K if K else 0
     bias = lin.bias if use_bias else None
     if split_linear_pays(M, N, K, gelu):
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, SPLIT_MODE)
         cache = getattr(lin, "_rba_planes", None)
         if cache is None or cache[0] != key:
             cache = (key, split_weight(w.detach().contiguous()))
@@ -402,24 +421,29 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False):
 
 @_hip_op
 def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False):
-    """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 matrix pipe.
+    """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 / f16 matrix pipe (the planes'
+    dtype says which form they were packed for).
     ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
     lib = _lib.load()
     _chk(x, "x")
-    _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
+    f16 = planes.dtype == torch.float16
+    _chk(planes, "planes", dtype=torch.float16 if f16 else torch.bfloat16, dim=6)
     K = x.shape[-1]
     N = planes.shape[0] * 128 if out_features is None else int(out_features)
     M = x.numel() // K if K else 0
-    if (tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != K or not split_linear_supported(N, K)
-            or (N + 127) // 128 != planes.shape[0]):
+    if (tuple(planes.shape[2:]) != ((2, 128, 2, 8) if f16 else (3, 128, 2, 8)) or planes.shape[1] * 16 != K
+            or not split_linear_supported(N, K) or (N + 127) // 128 != planes.shape[0]):
         raise RbaHipError("split_linear needs x [..., K] and split_weight(W) of a weight [N,K] with K % 32 == 0")
     if bias is not None:
         _chk(bias, "bias", dim=1)
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
     out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.rba_split_linear_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, 1 if gelu else (2 if relu else 0), _stream()),
-               "rba_split_linear_f32")
+    act = 1 if gelu else (2 if relu else 0)
+    if f16:
+        _lib.check(lib.rba_split_linear_f16x3_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, act, _stream()), "rba_split_linear_f16x3_f32")
+    else:
+        _lib.check(lib.rba_split_linear_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, act, _stream()), "rba_split_linear_f32")
     return out
 
 
@@ -451,7 +475,7 @@ def conv3x3_weight(weight):
     N, C, kh, kw = weight.shape
     if (kh, kw) != (3, 3) or C % 32:
         raise RbaHipError("conv3x3_weight needs a [N, C, 3, 3] weight with C % 32 == 0")
-    return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous())
+    return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), mode="bf16x6")
 
 
 @_hip_op

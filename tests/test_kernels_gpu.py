@@ -334,19 +334,29 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
                                                  (2048, 512, 2048, False, True), (3600, 1024, 96, True, False),
                                                  (500, 192, 192, False, True), (900, 576, 192, True, True), (300, 100, 64, False, False),
                                                  (257, 1, 32, False, True)])
-def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias):
-    """Six bf16 MFMAs per product reproduce the fp32 Linear: error against fp64 at the level of an fp32 GEMM's own rounding."""
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias, mode):
+    """Six bf16 MFMAs (three f16 MFMAs) per product reproduce the fp32 Linear: error against fp64 at the level of an fp32 GEMM's own
+    rounding."""
     g = torch.Generator().manual_seed(M + N + K)
     x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
     b = torch.randn(N, generator=g) if has_bias else None
     ref = F.linear(x.double(), w.double(), b.double() if has_bias else None)
     ref = F.gelu(ref) if gelu else ref
-    planes = ops.split_weight(dev(w))
+    planes = ops.split_weight(dev(w), mode=mode)
     Np = (N + 127) // 128 * 128
-    assert planes.shape == (Np // 128, K // 16, 3, 128, 2, 8) and planes.dtype == torch.bfloat16
     flat = ops.unpack_split_weight(planes)
-    assert flat.shape == (3, Np, K)
-    assert torch.equal(flat[:, :N].float().sum(0).cpu(), w), "the three bf16 planes must sum to the fp32 weight exactly"
+    if mode == "bf16x6":
+        assert planes.shape == (Np // 128, K // 16, 3, 128, 2, 8) and planes.dtype == torch.bfloat16
+        assert flat.shape == (3, Np, K)
+        assert torch.equal(flat[:, :N].float().sum(0).cpu(), w), "the three bf16 planes must sum to the fp32 weight exactly"
+    else:
+        assert planes.shape == (Np // 128, K // 16, 2, 128, 2, 8) and planes.dtype == torch.float16
+        assert flat.shape == (2, Np, K)
+        h = w.half()
+        assert torch.equal(flat[0, :N].cpu(), h), "plane 0 = f16(w)"
+        assert torch.equal(flat[1, :N].cpu(), ((w - h.float()) * 2048.0).half()), "plane 1 = f16((w - h) 2^11)"
+        assert ((flat[0, :N].double() + flat[1, :N].double() / 2048.0).cpu() - w.double()).abs().max() <= 2.0 ** -22 * w.abs().max()
     assert not flat[:, N:].float().any(), "padding rows must be zero"
     out = ops.split_linear(dev(x), planes, dev(b) if has_bias else None, gelu=gelu, out_features=N)
     fp32 = F.linear(dev(x), dev(w), dev(b) if has_bias else None)
@@ -363,8 +373,9 @@ def test_split_linear_relu_epilogue(ops):
     g = torch.Generator().manual_seed(3)
     for M, N, K in ((1000, 1024, 256), (300, 256, 1024)):
         x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
-        out = ops.split_linear(dev(x), ops.split_weight(dev(w)), dev(b), relu=True)
-        assert maxerr(out, F.relu(F.linear(x.double(), w.double(), b.double()))) < 2e-5 * (K / 256) ** 0.5 + 2e-6 and float(out.min()) >= 0.0
+        for mode in ("f16x3", "bf16x6"):
+            out = ops.split_linear(dev(x), ops.split_weight(dev(w), mode=mode), dev(b), relu=True)
+            assert maxerr(out, F.relu(F.linear(x.double(), w.double(), b.double()))) < 2e-5 * (K / 256) ** 0.5 + 2e-6 and float(out.min()) >= 0.0
         lin = torch.nn.Linear(K, N).cuda()
         xx = torch.randn(40000, K, device="cuda")
         assert maxerr(ops.linear(xx, lin, relu=True), F.relu(F.linear(xx.double(), lin.weight.double(), lin.bias.double()))) < 3e-5
@@ -377,11 +388,34 @@ def test_split_linear_extreme_values(ops):
     x[:, 7] = 0.0
     w = torch.zeros(128, 64)
     w[torch.arange(128), torch.arange(128) % 64] = 1.0                       # a selection matrix: output must equal the input
-    out = ops.split_linear(dev(x), ops.split_weight(dev(w)))
+    out = ops.split_linear(dev(x), ops.split_weight(dev(w), mode="bf16x6"))
     assert torch.equal(out.cpu(), x[:, torch.arange(128) % 64])
     w2 = torch.randn(128, 64, generator=g).bfloat16().float()               # weights exactly representable in bf16
-    p2 = ops.unpack_split_weight(ops.split_weight(dev(w2)))
+    p2 = ops.unpack_split_weight(ops.split_weight(dev(w2), mode="bf16x6"))
     assert torch.equal(p2[0].float().cpu(), w2) and not p2[1:].float().any()
+
+
+def test_split_linear_f16x3_range(ops):
+    """The f16x3 form over ITS exponent range: 22 bits of every input survive from 1e-7 (f16's subnormals: the 2^11-scaled
+    residual keeps the bits the high piece lost) to 6e4; zeros are exact; beyond 65504 the output is NaN (never a wrong number)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 64, generator=g) * torch.logspace(-7, 4, 64).view(1, 64)
+    x[:, 7] = 0.0
+    x = x.clamp(-6.0e4, 6.0e4)
+    w = torch.zeros(128, 64)
+    w[torch.arange(128), torch.arange(128) % 64] = 1.0
+    out = ops.split_linear(dev(x), ops.split_weight(dev(w), mode="f16x3")).cpu()
+    want = x[:, torch.arange(128) % 64]
+    big = want.abs() >= 6.2e-5                                                # f16 normal range: h carries 11 bits, l the next 11
+    assert ((out - want).abs()[big] <= 2.0 ** -21 * want.abs()[big]).all()
+    assert ((out - want).abs()[~big] <= 2.0 ** -35).all()                   # below: absolute error of the scaled residual's rounding
+    assert torch.equal(out[:, 7], torch.zeros(256))
+    x[3, 5] = 7.0e4                                                           # outside f16: that row's outputs that use it are NaN
+    out = ops.split_linear(dev(x), ops.split_weight(dev(w), mode="f16x3")).cpu()
+    assert torch.isnan(out[3, 5]) and torch.isnan(out[3, 69]) and not torch.isnan(out[4]).any()
+    w2 = torch.randn(128, 64, generator=g).half().float()                    # weights exactly representable in f16
+    p2 = ops.unpack_split_weight(ops.split_weight(dev(w2), mode="f16x3"))
+    assert torch.equal(p2[0].float().cpu(), w2) and not p2[1].float().any()
 
 
 def test_split_linear_dispatch_and_errors(ops):
@@ -390,7 +424,7 @@ def test_split_linear_dispatch_and_errors(ops):
     x = torch.randn(2, 16384, 512, device="cuda")
     assert ops.split_linear_pays(32768, 2048, 512, gelu=True) and not ops.split_linear_pays(100, 2048, 512, gelu=True)
     y = ops.linear(x, lin, gelu=True)
-    assert getattr(lin, "_rba_planes", None) is not None, "bf16x6 path not taken"
+    assert getattr(lin, "_rba_planes", None) is not None and lin._rba_planes[1].dtype == torch.float16, "f16x3 path not taken"
     assert maxerr(y, F.gelu(F.linear(x.double(), lin.weight.double(), lin.bias.double()))) < 3e-5
     planes_before = lin._rba_planes[1]
     with torch.no_grad():
@@ -435,7 +469,7 @@ def test_split_linear_nchw_out(ops, B, P, K, N):
     g = torch.Generator().manual_seed(B + P + K + N)
     x, w, b = torch.randn(B * P, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
     ref = F.linear(x.double(), w.double(), b.double()).view(B, P, N).permute(0, 2, 1)
-    planes = ops.split_weight(dev(w))
+    planes = ops.split_weight(dev(w), mode="bf16x6")
     out = ops.split_linear_nchw_out(dev(x), planes, dev(b), P, out_features=N)
     assert out.shape == (B, N, P) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
     same = ops.split_linear(dev(x), planes, dev(b), out_features=N).view(B, P, N).permute(0, 2, 1)
@@ -569,7 +603,8 @@ def test_k1_full_size_properties(ops):
     assert (r_sat + prob[7].double().tanh().sum()).abs().max().item() < 1e-6
 
 
-def test_split_linear_full_size_properties(ops):
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_split_linear_full_size_properties(ops, mode):
     """K6 at the largest BASELINE GEMM (Swin-B stage 1, M = 131072): exactness on selection weights, additivity in the input,
     and fp64 agreement on sampled rows."""
     g = torch.Generator(device="cuda").manual_seed(6)
@@ -577,11 +612,15 @@ def test_split_linear_full_size_properties(ops):
     x = torch.randn(M, K, device="cuda", generator=g) * torch.logspace(-3, 3, K, device="cuda").view(1, K)
     sel = torch.zeros(N, K, device="cuda")
     sel[torch.arange(N), torch.arange(N) % K] = 1.0
-    out = ops.split_linear(x, ops.split_weight(sel))
-    assert torch.equal(out, x[:, torch.arange(N, device="cuda") % K]), "hi + mid + lo must reproduce every fp32 input exactly"
+    out = ops.split_linear(x, ops.split_weight(sel, mode=mode))
+    want = x[:, torch.arange(N, device="cuda") % K]
+    if mode == "bf16x6":
+        assert torch.equal(out, want), "hi + mid + lo must reproduce every fp32 input exactly"
+    else:
+        assert ((out - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -35).all(), "h + 2^-11 l carries 22 bits of every input"
     w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
     b = torch.randn(N, device="cuda", generator=g)
-    planes = ops.split_weight(w)
+    planes = ops.split_weight(w, mode=mode)
     x1, x2 = torch.randn(M, K, device="cuda", generator=g), torch.randn(M, K, device="cuda", generator=g)
     y1, y2, y12 = ops.split_linear(x1, planes, b), ops.split_linear(x2, planes, b), ops.split_linear(x1 + x2, planes, b)
     assert (y1 + y2 - b - y12).abs().max().item() < 2e-5
