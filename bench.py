@@ -408,9 +408,12 @@ def main():
                 torch.cuda.synchronize()
                 g_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
                 flops32 = 2.0 * M3 * lin.weight.shape[0] * lin.weight.shape[1]
-                gemm = {"bound": "mfma", "kernel": "split_linear_v4_kernel<GELU> (fc1 of Swin stage 3)", "shape_MNK": [M3, lin.weight.shape[0], lin.weight.shape[1]],
-                        "achieved": 6.0 * flops32 / (g_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16, six products per fp32 product)",
-                        "frac": 6.0 * flops32 / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": flops32 / (g_ms * 1e-3) / 1e12,
+                prods = 3.0 if ops.SPLIT_MODE == "f16x3" else 6.0
+                gemm = {"bound": "mfma", "kernel": ("split_linear_h3_kernel<GELU>" if prods == 3.0 else "split_linear_v4_kernel<GELU>") + " (fc1 of Swin stage 3)",
+                        "shape_MNK": [M3, lin.weight.shape[0], lin.weight.shape[1]], "split_mode": ops.SPLIT_MODE,
+                        "achieved": prods * flops32 / (g_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS,
+                        "unit": f"TFLOP/s ({'f16' if prods == 3.0 else 'bf16'} MFMA, {int(prods)} products per fp32 product; dense f16 = bf16 peak)",
+                        "frac": prods * flops32 / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": flops32 / (g_ms * 1e-3) / 1e12,
                         "avg_launch_ms": g_ms, "launches_timed": len(evs)}
         except Exception as e:                                           # informational only
             print(f"[bench] K6 roofline probe skipped ({type(e).__name__}: {e})", file=sys.stderr)

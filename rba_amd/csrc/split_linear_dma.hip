@@ -49,10 +49,13 @@ extern "C" int rba_split_linear_f16x3_f32(const float* x, const void* weight_pac
   rba_begin();
   const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
   hipStream_t st = (hipStream_t)stream;
+  // tools/gemm_h3_sweep.py, profiles/r02_k6_f16x3.txt: short K (<= 256: many short tiles, the activation traffic dominates) runs
+  // the LDS-staged form, long K the straight-to-register form; 128 x 64 tiles when there are fewer than 256 tiles of 128 x 128
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const bool wide = tiles128 >= 256 || N <= 64;
   int rc;
-  if (tiles128 >= 320 || N <= 64) rc = launch_h3_act<4>(act, x, wp, bias, out, M, N, K, st);
-  else rc = launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st);
+  if (K <= 256) rc = wide ? launch_h3l_act<4>(act, x, wp, bias, out, M, N, K, st) : launch_h3l_act<2>(act, x, wp, bias, out, M, N, K, st);
+  else rc = wide ? launch_h3_act<4>(act, x, wp, bias, out, M, N, K, st) : launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st);
   if (rc) return rc;
   return rba_launch_status();
 }

@@ -264,6 +264,184 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __
   }
 }
 
+// ---- f16x3, activations staged through LDS.  Why: a lane of the MFMA A operand is a ROW, so straight-to-register loads touch a
+// different 128-byte line in every lane and the vector L1 serves them one lane per clock -- the direct kernel above spends more
+// cycles in the L1 than in the matrix pipe (ablation: 77 -> 60 us without the activation loads; deeper prefetch changes nothing).
+// Here the 128 x 32 fp32 activation block is loaded like the weight block: 8 adjacent lanes read one row's whole 128-byte line,
+// registers -> LDS (16-byte chunk c of row r at unit 8 r + (c ^ ((r >> 1) & 7)): the 8-lane row writes and the row-per-lane
+// fragment reads are both conflict-free), and each MFMA wave reads its rows' fragments back (4 ds_read_b128 per 32-wide block)
+// and splits them in registers.  LDS: 2 x (16 KB activations + 4 BN x 32 B weights).
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false>
+__global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                                 int K, int MT, int NT, unsigned long long* dbg = nullptr) {
+  unsigned long long tm[4];
+  if (TIMING) tm[0] = wall_clock64();
+  constexpr int BM = 128, BN = 32 * CT;
+  constexpr int SUBW = 4 * BN;                                                     // 16-byte units of one weight sub-stage image
+  constexpr int BLK = 2 * SUBW;                                                    // ... of one 32-wide k block
+  constexpr int UPL = BLK / 256;                                                   // weight units per lane per block
+  constexpr int XBLK = BM * 8;                                                     // activation units per block (128 rows x 128 B)
+  constexpr int BUF = BLK + XBLK;
+  static_assert(BLK % 256 == 0 && 128 % BN == 0, "tile width");
+  __shared__ __attribute__((aligned(16))) u32x4_t lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int nb = MT * NT;
+  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);                     // XCD-aware: one XCD, one run of tiles (n fastest)
+  const int mt = bid / NT, nt = bid - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int NB = K >> 5, S16 = K >> 4;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  constexpr int QSTEP = (CT == 4) ? 256 : 512;
+  const char* wbase = reinterpret_cast<const char*>(Wp + (int64_t)(n0 >> 7) * S16 * 512 + (n0 & 127) * 2);
+  uint32_t woff;
+  {
+    const int g = tid / SUBW, rem = tid - g * SUBW, p = rem / (2 * BN), rr = rem - p * (2 * BN);
+    woff = (uint32_t)(g * 512 + p * 256 + rr) * 16u;
+  }
+  // activation copy: unit u = tid + 256 q -> row (tid >> 3) + 32 q, chunk tid & 7
+  const char* xbase = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
+  uint32_t xoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int r = m0 + (tid >> 3) + 32 * q;
+    r = (r < M ? r : M - 1) - m0;
+    xoff[q] = ((uint32_t)r * (uint32_t)K + 4u * (tid & 7)) * 4u;
+  }
+  const int xdst = BLK + (tid >> 3) * 8 + ((tid & 7) ^ ((tid >> 4) & 7));            // + 256 q   (row = tid >> 3: (row >> 1) & 7)
+  // fragment reads of this lane's row
+  const int frow = 32 * wave + l31;
+  const int fa = BLK + frow * 8, fsw = (frow >> 1) & 7;
+
+  f32x16_t accm[CT], accl[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accm[j][r] = accl[j][r] = 0.f;
+
+  u32x4_t wr[UPL];
+  f32x4 xr[4];
+  const int last = NB - 1;
+  auto gload = [&](int c) {
+    const int cc = c < last ? c : last;
+    const char* ws = wbase + (int64_t)cc * 16384;
+    const char* xs = xbase + cc * 128;
+#pragma unroll
+    for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(ws + q * (QSTEP * 16) + woff);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(xs + xoff[q]);
+  };
+  auto lstore = [&](u32x4_t* buf) {
+#pragma unroll
+    for (int q = 0; q < UPL; ++q) buf[tid + 256 * q] = wr[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) buf[xdst + 256 * q] = __builtin_bit_cast(u32x4_t, xr[q]);
+  };
+  gload(0);
+  lstore(lds);
+  gload(1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  const int fb = l31 * 2 + (lh ^ ((l31 >> 3) & 1));
+  if (TIMING) tm[1] = wall_clock64();
+  for (int b = 0; b < NB; ++b) {
+    const u32x4_t* img = lds + (b & 1) * BUF;
+    // registers hold block b + 1: -> the other buffer (every wave left it at the barrier that ended block b - 1); refill with b + 2
+    if (!(PROBE & 32)) lstore(lds + ((b + 1) & 1) * BUF);
+    if (!(PROBE & 1)) gload(b + 2);
+    f16x8_t ah[2], al[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 u = __builtin_bit_cast(f32x4, img[fa + ((4 * lh + 2 * g) ^ fsw)]);
+      const f32x4 v = __builtin_bit_cast(f32x4, img[fa + ((4 * lh + 2 * g + 1) ^ fsw)]);
+      if (PROBE & 16) {
+        ah[g] = __builtin_bit_cast(f16x8_t, u);
+        al[g] = __builtin_bit_cast(f16x8_t, v);
+      } else {
+        split_h3(u, v, ah[g], al[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8_t bh[CT], bl[CT];
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        bh[j] = __builtin_bit_cast(f16x8_t, img[g * SUBW + fb + 64 * j]);
+        bl[j] = __builtin_bit_cast(f16x8_t, img[g * SUBW + fb + 2 * BN + 64 * j]);
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh[j], accm[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl[j], accl[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < CT; ++j) accl[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh[j], accl[j], 0, 0, 0);
+    }
+    if (!(PROBE & 64)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  if (TIMING) tm[2] = wall_clock64();
+  const bool interior = m0 + BM <= M && n0 + BN <= N;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = n0 + 32 * j + l31;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+    f32x16_t v;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]} + bv;
+      if (ACT == 1) y = gelu_erf2(y);
+      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+      v[r] = y.x;
+      v[r + 1] = y.y;
+    }
+    const int rbase = m0 + 32 * wave + 4 * lh;
+    float* dst = C + (int64_t)rbase * N + col;
+    if (PROBE & 4) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += v[r];
+      if (sum == 1234.5f) dst[0] = sum;
+    } else if (interior) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
+    } else if (col < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = 8 * (r >> 2) + (r & 3);
+        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
+      }
+    }
+  }
+  if (TIMING && tid == 0) {
+    tm[3] = wall_clock64();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dbg[6 * blockIdx.x + i] = tm[i];
+    dbg[6 * blockIdx.x + 4] = dbg[6 * blockIdx.x + 5] = 0;
+  }
+}
+
+template <int ACT, int CT, int PROBE = 0>
+int launch_h3l(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t stream) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3l_kernel<ACT, CT, PROBE>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N,
+                     K, (int)MT, NT, nullptr);
+  return 0;
+}
+
+template <int CT>
+int launch_h3l_act(int act, const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t st) {
+  if (act == 1) return launch_h3l<1, CT>(x, wp, bias, out, M, N, K, st);
+  if (act == 2) return launch_h3l<2, CT>(x, wp, bias, out, M, N, K, st);
+  return launch_h3l<0, CT>(x, wp, bias, out, M, N, K, st);
+}
+
 template <int ACT, int CT, int PROBE = 0>
 int launch_h3(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t stream) {
   const int64_t MT = (M + 127) / 128;

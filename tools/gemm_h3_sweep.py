@@ -76,7 +76,7 @@ for name, M, N, K, act in shapes(which):
     med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
     err = {k: float(((outs[k][rows].double() - ref).pow(2).mean().sqrt() / sc)) for k in outs}
     mx = {k: float(((outs[k][rows].double() - ref).abs().max() / sc)) for k in outs}
-    best = min((k for k in med if k.startswith("h3:") and int(k[3:]) < 10), key=lambda k: med[k], default="product")
+    best = min((k for k in med if k.startswith("h3:") and int(k[3:]) % 1000 < 10), key=lambda k: med[k], default="product")
     tot["bf16x6"] += med["bf16x6"]; tot["blas"] += med["blas"]; tot["best"] += med[best]; tot["product"] += med["product"]
     tf = 2.0 * M * N * K / med[best] / 1e6
     print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d} act={act} " + "  ".join(f"{k}: {med[k]:6.1f}" for k in med) +
