@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      __builtin_amdgcn_sched_barrier(0);
+      if (PROBE & 128) __builtin_amdgcn_sched_barrier(0);
       f16x8_t bh[CT], bl[CT];
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
