@@ -135,6 +135,8 @@ extern "C" int rba_split_linear_h3_tune(const float* x, const void* weight_packe
     case 1324: rc = launch_h3l<1, 4, 32>(x, wp, bias, out, M, N, K, st); break;
     case 1644: rc = launch_h3l<1, 4, 64>(x, wp, bias, out, M, N, K, st); break;
     case 2284: rc = launch_h3l<1, 4, 128>(x, wp, bias, out, M, N, K, st); break;
+    case 4004: rc = launch_h3p_act(act, x, wp, bias, out, M, N, K, st); break;
+    case 4044: rc = launch_h3p<1, 4>(x, wp, bias, out, M, N, K, st); break;
     case 2: rc = launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st); break;
     case 1: rc = launch_h3_act<1>(act, x, wp, bias, out, M, N, K, st); break;
     case 14: rc = launch_h3<1, 4, 1>(x, wp, bias, out, M, N, K, st); break;
