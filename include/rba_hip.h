@@ -174,6 +174,10 @@ int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, con
 int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W, int C,
                          int N, void* stream);
 
+/* The same convolution on the f16x3 kernel: weight_packed = rba_split_weight_f16x2 of the [N, 9*C] matrix above.  C % 32 == 0. */
+int rba_conv3x3_nhwc_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W, int C,
+                               int N, void* stream);
+
 /* Gaussian smoothing of the score map (the evaluator's optional transforms.GaussianBlur(7, sigma=1), support.py:366-383):
  * out[H,W] = correlation of in[H,W] (reflect-padded by kernel_size/2) with the normalised outer-product kernel of
  * exp(-0.5 (x/sigma)^2), x = -(k-1)/2 .. (k-1)/2.  kernel_size odd, <= 15; in != out. */

@@ -60,3 +60,21 @@ extern "C" int rba_split_linear_f16x3_f32(const float* x, const void* weight_pac
   if (rc) return rc;
   return rba_launch_status();
 }
+
+// 3 x 3 / stride 1 / pad 1 convolution over NHWC activations on the f16x3 kernel: weight_packed = rba_split_weight_f16x2 of the
+// [N, 9 C] matrix w[n][(3 ky + kx) C + c].  (msdeformattn.py:278-297 `layer_{j}` output convolutions.)
+extern "C" int rba_conv3x3_nhwc_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W,
+                                          int C, int N, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && C >= 32 && (C % 32) == 0 && N >= 1);
+  const int64_t M = (int64_t)B * H * W;
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out && M * C < (int64_t)1 << 30 && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const int rc = (tiles128 >= 256 || N <= 64) ? launch_h3l_conv<4>(x, wp, bias, out, M, N, H, W, C, (hipStream_t)stream)
+                                              : launch_h3l_conv<2>(x, wp, bias, out, M, N, H, W, C, (hipStream_t)stream);
+  if (rc) return rc;
+  return rba_launch_status();
+}

@@ -271,10 +271,18 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __
 // registers -> LDS (16-byte chunk c of row r at unit 8 r + (c ^ ((r >> 1) & 7)): the 8-lane row writes and the row-per-lane
 // fragment reads are both conflict-free), and each MFMA wave reads its rows' fragments back (4 ds_read_b128 per 32-wide block)
 // and splits them in registers.  LDS: 2 x (16 KB activations + 4 BN x 32 B weights).
-template <int ACT, int CT, int PROBE = 0, bool TIMING = false>
+// CONV: the activation operand is the implicit im2col matrix of a 3 x 3 / stride 1 / pad 1 convolution over NHWC x [B,H,W,Cin]:
+// row m = output pixel, k = (tap, channel) with tap = 3 ky + kx, A[m][k] = x[b, y + ky - 1, x + kx - 1, c] or 0 outside the image.
+// A 32-wide k block lies inside one tap (Cin % 32 == 0), so a block's loads are the usual 128-byte row reads at a
+// workgroup-uniform offset, zeroed per row where the tap leaves the image.
+struct ConvShape {
+  int H, W, Cin;
+};
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                                 int K, int MT, int NT, unsigned long long* dbg = nullptr) {
+                                                                 int K, int MT, int NT, unsigned long long* dbg = nullptr,
+                                                                 ConvShape cs = ConvShape{0, 0, 0}) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int BM = 128, BN = 32 * CT;
@@ -304,13 +312,21 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
     woff = (uint32_t)(g * 512 + p * 256 + rr) * 16u;
   }
   // activation copy: unit u = tid + 256 q -> row (tid >> 3) + 32 q, chunk tid & 7
-  const char* xbase = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
+  const char* xbase = reinterpret_cast<const char*>(CONV ? A : A + (int64_t)m0 * K);
   uint32_t xoff[4];
+  int py[4], px[4];                                                                // CONV: the row's pixel (y, x)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int r = m0 + (tid >> 3) + 32 * q;
-    r = (r < M ? r : M - 1) - m0;
-    xoff[q] = ((uint32_t)r * (uint32_t)K + 4u * (tid & 7)) * 4u;
+    r = r < M ? r : M - 1;
+    if (CONV) {
+      const int pix = r % (cs.H * cs.W);
+      py[q] = pix / cs.W;
+      px[q] = pix - py[q] * cs.W;
+      xoff[q] = ((uint32_t)r * (uint32_t)cs.Cin + 4u * (tid & 7)) * 4u;
+    } else {
+      xoff[q] = ((uint32_t)(r - m0) * (uint32_t)K + 4u * (tid & 7)) * 4u;
+    }
   }
   const int xdst = BLK + (tid >> 3) * 8 + ((tid & 7) ^ ((tid >> 4) & 7));            // + 256 q   (row = tid >> 3: (row >> 1) & 7)
   // fragment reads of this lane's row
@@ -329,11 +345,23 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   auto gload = [&](int c) {
     const int cc = c < last ? c : last;
     const char* ws = wbase + (int64_t)cc * 16384;
-    const char* xs = xbase + cc * 128;
 #pragma unroll
     for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(ws + q * (QSTEP * 16) + woff);
+    if (CONV) {
+      const int k0 = cc * 32, tap = k0 / cs.Cin, ch0 = k0 - tap * cs.Cin;
+      const int ky = tap / 3, dy = ky - 1, dx = tap - 3 * ky - 1;
+      const int delta = ((dy * cs.W + dx) * cs.Cin + ch0) * 4;                      // bytes from the row's own pixel, channel 0
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(xs + xoff[q]);
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = (unsigned)(py[q] + dy) < (unsigned)cs.H && (unsigned)(px[q] + dx) < (unsigned)cs.W;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xbase + (int64_t)(ok ? delta : ch0 * 4) + xoff[q]);
+        xr[q] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const char* xs = xbase + cc * 128;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(xs + xoff[q]);
+    }
   };
   auto lstore = [&](u32x4_t* buf) {
 #pragma unroll
@@ -432,6 +460,18 @@ int launch_h3l(const float* x, const u32x4_t* wp, const float* bias, float* out,
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3l_kernel<ACT, CT, PROBE>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N,
                      K, (int)MT, NT, nullptr);
+  return 0;
+}
+
+// 3 x 3 convolution (pad 1) over NHWC activations as an implicit GEMM: M = B H W output pixels, K = 9 Cin
+template <int CT>
+int launch_h3l_conv(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
+                    hipStream_t stream) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3l_kernel<0, CT, 0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out,
+                     (int)M, N, 9 * Cin, (int)MT, NT, nullptr, ConvShape{H, W, Cin});
   return 0;
 }
 

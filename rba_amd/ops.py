@@ -469,24 +469,27 @@ def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
 
 
 @_hip_op
-def conv3x3_weight(weight):
-    """conv weight [N, C, 3, 3] -> split_weight of the implicit-GEMM matrix [N, 9 C], k = (3 ky + kx) C + c."""
+def conv3x3_weight(weight, mode=None):
+    """conv weight [N, C, 3, 3] -> split_weight (form `mode`, default ops.SPLIT_MODE) of the implicit-GEMM matrix [N, 9 C],
+    k = (3 ky + kx) C + c."""
     _chk(weight, "weight", dim=4)
     N, C, kh, kw = weight.shape
     if (kh, kw) != (3, 3) or C % 32:
         raise RbaHipError("conv3x3_weight needs a [N, C, 3, 3] weight with C % 32 == 0")
-    return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), mode="bf16x6")
+    return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), mode=mode)
 
 
 @_hip_op
 def conv3x3_nhwc(x, planes, bias=None, out_features=None):
-    """3x3, stride 1, pad 1 convolution of NHWC x [B,H,W,C] with conv3x3_weight(W) -> [B,H,W,N] (implicit GEMM, bf16x6)."""
+    """3x3, stride 1, pad 1 convolution of NHWC x [B,H,W,C] with conv3x3_weight(W) -> [B,H,W,N] (implicit GEMM on K6; the planes'
+    dtype says for which form they were packed)."""
     lib = _lib.load()
     _chk(x, "x", dim=4)
-    _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
+    f16 = planes.dtype == torch.float16
+    _chk(planes, "planes", dtype=torch.float16 if f16 else torch.bfloat16, dim=6)
     B, H, W, C = x.shape
     N = planes.shape[0] * 128 if out_features is None else int(out_features)
-    if (tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != 9 * C or C % 16 or (9 * C) % 32
+    if (tuple(planes.shape[2:]) != ((2, 128, 2, 8) if f16 else (3, 128, 2, 8)) or planes.shape[1] * 16 != 9 * C or C % 32
             or (N + 127) // 128 != planes.shape[0]):
         raise RbaHipError("conv3x3_nhwc needs x [B,H,W,C] (C % 32 == 0) and conv3x3_weight(W [N,C,3,3])")
     if bias is not None:
@@ -494,7 +497,8 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
     out = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
-    _lib.check(lib.rba_conv3x3_nhwc_f32(_p(x), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()), "rba_conv3x3_nhwc_f32")
+    fn, name = ((lib.rba_conv3x3_nhwc_f16x3_f32, "rba_conv3x3_nhwc_f16x3_f32") if f16 else (lib.rba_conv3x3_nhwc_f32, "rba_conv3x3_nhwc_f32"))
+    _lib.check(fn(_p(x), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()), name)
     return out
 
 

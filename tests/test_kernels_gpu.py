@@ -451,14 +451,15 @@ def test_split_linear_dispatch_and_errors(ops):
 # ----------------------------------------------------------------------------------- bf16x6 conv3x3 (NHWC) and NCHW-out Linear
 @pytest.mark.parametrize("B,H,W,C,N,has_bias", [(1, 16, 24, 32, 128, False), (2, 9, 13, 64, 256, True), (1, 33, 20, 256, 256, False),
                                                 (1, 5, 3, 32, 40, True), (1, 64, 128, 256, 256, False)])
-def test_conv3x3_nhwc_vs_fp64(ops, B, H, W, C, N, has_bias):
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_conv3x3_nhwc_vs_fp64(ops, B, H, W, C, N, has_bias, mode):
     """Implicit-GEMM 3x3 convolution (pad 1) on NHWC activations against F.conv2d in fp64, borders included."""
     g = torch.Generator().manual_seed(B * 1000 + H * W + C)
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5
     b = torch.randn(N, generator=g) if has_bias else None
     ref = F.conv2d(x.double(), w.double(), b.double() if has_bias else None, padding=1).permute(0, 2, 3, 1)
-    planes = ops.conv3x3_weight(dev(w))
+    planes = ops.conv3x3_weight(dev(w), mode=mode)
     out = ops.conv3x3_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), planes, dev(b) if has_bias else None, out_features=N)
     assert out.shape == (B, H, W, N)
     assert maxerr(out, ref) < 2e-5 * (9 * C / 256) ** 0.5 + 2e-6
