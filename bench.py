@@ -40,7 +40,7 @@ def parse():
                     help="fullres: materialise the x4-upsampled mask logits and run the HBM-bound K1 the metric names; "
                          "up4: K1 reads the low-res logits and upsamples on the fly (less traffic, compute bound)")
     ap.add_argument("--graph", type=int, default=0, help="replay the forward from a captured hipGraph (0 = eager)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="images per GPU per step, each on its own HIP stream (concurrent kernels fill under-occupied "
                          "stage-3/4 launches: +7..10 %% images/s at 2-3, but K1's live timing then includes contention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -108,7 +108,7 @@ def build_parser():
     p.add_argument("--selected_datasets", nargs="*", type=str, default=[])
     p.add_argument("--score_func", type=str, default="rba", choices=sorted(SCORE_FUNCS))
     p.add_argument("--upper_limit", type=int, default=1300)
-    p.add_argument("--streams", type=int, default=2, help="HIP streams the batch-1 forwards alternate on (1 = the reference's serial loop)")
+    p.add_argument("--streams", type=int, default=3, help="HIP streams the batch-1 forwards alternate on (1 = the reference's serial loop)")
     return p
 
 
@@ -118,7 +118,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
 
     Pipeline (the reference feeds its loop from DataLoader(batch_size, num_workers), :210-211): images are decoded ahead of the GPU
     by `--num_workers` threads (datasets.prefetch), copied to the GPU and scored batch-1 on alternating HIP streams (`--streams`,
-    default 2) so that the host-side launch work and the under-occupied kernels of one image overlap the other image; score maps and
+    default 3) so that the host-side launch work and the under-occupied kernels of one image overlap the other image; score maps and
     labels never leave the GPU (the metric is a GPU sort).  (Replaying the forward from a captured hipGraph was measured too: no gain,
     the loop is GPU bound -- profiles/r02_evaluator.json -- so it is not offered.)"""
     import time
@@ -132,7 +132,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     on_gpu = dev.type == "cuda"
     nw = max(0, int(args.num_workers))
     loader = (tuple(t[None] for t in item) for item in prefetch(dataset, mine, nw, pin=on_gpu and nw > 0, label_dtype=torch.uint8))       # batch-1 items [1,3,H,W], [1,H,W]
-    n_streams = max(1, int(getattr(args, "streams", 2))) if on_gpu else 1
+    n_streams = max(1, int(getattr(args, "streams", 3))) if on_gpu else 1
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
     scores, labels = [], []
