@@ -338,194 +338,13 @@ int launch_v8_act(int act, const float* x, const u32x4_t* wp, const float* bias,
 }  // namespace
 
 // ======================================================================================================================
-// f16x3 experiments (round 2).  Both lose to split_linear_h3_kernel / split_linear_h3l_kernel (profiles/r02_k6_f16x3.txt):
-//   * h3p below: fragment reads software-pipelined per 32-column tile, barrier before the last tile -- 83 us vs 74 us on Swin
-//     stage-3 fc1: the compiler re-orders the MFMA groups and waits for the LDS queue to drain at the barrier anyway;
+// f16x3 experiments (round 2) that lose to the product kernels of split_linear_h3.h (profiles/r02_k6_f16x3.txt):
+//   * the software-pipelined kernel (split_linear_h3p_kernel, now in the product) WITHOUT explicit scheduling groups: 83 us vs
+//     74 us on Swin stage-3 fc1 -- the compiler re-serialises reads and MFMAs; with __builtin_amdgcn_sched_group_barrier patterns
+//     69 us; moving the weight staging under the third column tile as well: 72 us;
 //   * starting the second workgroup of every CU 4-32 us late (so that one workgroup's epilogue meets the other's k loop):
 //     74 -> 74 / 75 / 77 / 90 us: a workgroup's k loop is bound by its own dependency chain, not by its neighbour;
 //   * eight waves per 128 x 128 tile (two column halves): no gain on the 256-tile shapes it was meant for (72 vs 72 us).
 #include "../split_linear_h3.h"
 namespace {
-// ---- f16x3, straight-to-register activations, SOFTWARE-PIPELINED fragment reads.  In the kernels above a wave issues its weight
-// fragment reads, waits for LDS, issues 12 MFMAs, reads again, waits again: per 32-wide block ~2800 cycles for 768 cycles of
-// MFMA (tools/gemm_h3_timing.py; the second workgroup of the CU fills some of it, never all).  Here the work of a block is cut
-// into its four 32-column tiles: while the six MFMAs of column tile j run (192 cycles), the four fragment reads of tile j + 1 are
-// in flight into the other half of a two-deep register buffer, the activation split of the NEXT block is interleaved with the
-// MFMAs of tiles 1-2, and the workgroup barrier sits before tile 3 so that the first fragments of the next block are already
-// being read from the other LDS buffer while tile 3 computes.  Register budget: 128 accumulators + 2 x 16 weight fragments +
-// 2 x 16 activation operands + 16 raw activations + 16 weight staging.
-template <int ACT, int PROBE = 0, bool TIMING = false>
-__global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
-                                                                 const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                                 int K, int MT, int NT, unsigned long long* dbg = nullptr) {
-  unsigned long long tm[4];
-  if (TIMING) tm[0] = wall_clock64();
-  constexpr int CT = 4, BM = 128, BN = 128;
-  constexpr int SUBW = 4 * BN, BLK = 2 * SUBW, UPL = BLK / 256;
-  __shared__ __attribute__((aligned(16))) u32x4_t lds[2 * BLK];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
-  const int nb = MT * NT;
-  if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-  const int mt = bid / NT, nt = bid - mt * NT;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int NB = K >> 5, S16 = K >> 4;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  const char* wbase = reinterpret_cast<const char*>(Wp + (int64_t)(n0 >> 7) * S16 * 512);
-  const uint32_t woff = (uint32_t)tid * 16u;                                       // the block image is contiguous: unit tid + 256 q
-  int row = m0 + 32 * wave + l31;
-  row = (row < M ? row : M - 1) - m0;
-  const char* xbase = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
-  const uint32_t xoff = ((uint32_t)row * (uint32_t)K + 16u * lh) * 4u;
-
-  f32x16_t accm[CT], accl[CT];
-#pragma unroll
-  for (int j = 0; j < CT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accm[j][r] = accl[j][r] = 0.f;
-
-  u32x4_t wr[UPL];
-  f32x4 xr[4];
-  f16x8_t ah[1][2], al[1][2];                                                      // [g]: split at the tail of the previous block
-  u32x4_t bq[2][4];                                                                // [column-tile parity][h g0, l g0, h g1, l g1]
-  const int last = NB - 1;
-  auto wload = [&](int c) {
-    const char* src = wbase + (int64_t)(c < last ? c : last) * 16384;
-#pragma unroll
-    for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(src + q * 4096 + woff);
-  };
-  auto xload = [&](int c) {
-    const char* src = xbase + (c < last ? c : last) * 128;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(src + q * 16 + xoff);
-  };
-  const int fb = l31 * 2 + (lh ^ ((l31 >> 3) & 1));                                // + g SUBW + (p BN + 32 j) 2
-  auto bread = [&](const u32x4_t* img, int j, u32x4_t (&d)[4]) {
-    d[0] = img[fb + 64 * j];
-    d[1] = img[fb + 2 * BN + 64 * j];
-    d[2] = img[SUBW + fb + 64 * j];
-    d[3] = img[SUBW + fb + 2 * BN + 64 * j];
-  };
-
-  wload(0);
-  xload(0);
-#pragma unroll
-  for (int q = 0; q < UPL; ++q) lds[tid + 256 * q] = wr[q];
-  split_h3(xr[0], xr[1], ah[0][0], al[0][0]);
-  split_h3(xr[2], xr[3], ah[0][1], al[0][1]);
-  wload(1);
-  xload(1);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  bread(lds, 0, bq[0]);
-  if (TIMING) tm[1] = wall_clock64();
-
-#define RBA_MFMA6(J, Q, P)                                                                                              \
-  {                                                                                                                     \
-    const f16x8_t bh0 = __builtin_bit_cast(f16x8_t, bq[Q][0]), bl0 = __builtin_bit_cast(f16x8_t, bq[Q][1]);             \
-    const f16x8_t bh1 = __builtin_bit_cast(f16x8_t, bq[Q][2]), bl1 = __builtin_bit_cast(f16x8_t, bq[Q][3]);             \
-    accm[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][0], bh0, accm[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][0], bl0, accl[J], 0, 0, 0);                                  \
-    accm[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][1], bh1, accm[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[P][0], bh0, accl[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][1], bl1, accl[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[P][1], bh1, accl[J], 0, 0, 0);                                  \
-  }
-  // one 32-wide block with activation operands of parity P; cur / nxt = the LDS buffers of this / the next block
-#define RBA_BLOCK(B, P, CUR, NXT)                                                                                       \
-  {                                                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < UPL; ++q)(NXT)[tid + 256 * q] = wr[q];                                        \
-    wload((B) + 2);                                                                                                     \
-    bread(CUR, 1, bq[1]);                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    RBA_MFMA6(0, 0, P)                                                                                                  \
-    bread(CUR, 2, bq[0]);                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    RBA_MFMA6(1, 1, P)                                                                                                  \
-    bread(CUR, 3, bq[1]);                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    RBA_MFMA6(2, 0, P)                                                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                   \
-    bread(NXT, 0, bq[0]);                                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    RBA_MFMA6(3, 1, P)                                                                                                  \
-    split_h3(xr[0], xr[1], ah[0][0], al[0][0]);     /* operands of the next block, under the MFMAs just issued */      \
-    split_h3(xr[2], xr[3], ah[0][1], al[0][1]);                                                                         \
-    xload((B) + 2);                                                                                                     \
-  }
-  int b = 0;
-  if (NB & 1) {
-    RBA_BLOCK(0, 0, lds, lds + BLK)
-    for (b = 1; b < NB; b += 2) {
-      RBA_BLOCK(b, 0, lds + BLK, lds)
-      RBA_BLOCK(b + 1, 0, lds, lds + BLK)
-    }
-  } else {
-    for (; b < NB; b += 2) {
-      RBA_BLOCK(b, 0, lds, lds + BLK)
-      RBA_BLOCK(b + 1, 0, lds + BLK, lds)
-    }
-  }
-#undef RBA_BLOCK
-#undef RBA_MFMA6
-
-  if (TIMING) tm[2] = wall_clock64();
-  const bool interior = m0 + BM <= M && n0 + BN <= N;
-#pragma unroll
-  for (int j = 0; j < CT; ++j) {
-    const int col = n0 + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-    f32x16_t v;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]} + bv;
-      if (ACT == 1) y = gelu_erf2(y);
-      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
-      v[r] = y.x;
-      v[r + 1] = y.y;
-    }
-    const int rbase = m0 + 32 * wave + 4 * lh;
-    float* dst = C + (int64_t)rbase * N + col;
-    if (PROBE & 4) {
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += v[r];
-      if (sum == 1234.5f) dst[0] = sum;
-    } else if (interior) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
-    } else if (col < N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = 8 * (r >> 2) + (r & 3);
-        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
-      }
-    }
-  }
-  if (TIMING && tid == 0) {
-    tm[3] = wall_clock64();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dbg[6 * blockIdx.x + i] = tm[i];
-    dbg[6 * blockIdx.x + 4] = dbg[6 * blockIdx.x + 5] = 0;
-  }
-}
-
-template <int ACT, int PROBE = 0>
-int launch_h3p(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t stream) {
-  const int64_t MT = (M + 127) / 128;
-  const int NT = (N + 127) / 128;
-  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, PROBE>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N, K,
-                     (int)MT, NT, nullptr);
-  return 0;
-}
-
-inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t st) {
-  if (act == 1) return launch_h3p<1>(x, wp, bias, out, M, N, K, st);
-  if (act == 2) return launch_h3p<2>(x, wp, bias, out, M, N, K, st);
-  return launch_h3p<0>(x, wp, bias, out, M, N, K, st);
-}
-
 }  // namespace
