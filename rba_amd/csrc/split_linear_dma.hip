@@ -51,10 +51,10 @@ extern "C" int rba_split_linear_f16x3_f32(const float* x, const void* weight_pac
   hipStream_t st = (hipStream_t)stream;
   // K <= 256 (Swin stages 1-2: many short tiles) runs the LDS-staged form, longer K the straight-to-register forms (software-
   // pipelined with 128-column tiles, plain with 64-column tiles); 128 x 64 tiles
-  // when there are fewer than 256 tiles of 128 x 128.  Chosen in the whole model (bench.py, one stream: 89.1 images/s; with the
+  // when there are fewer than 160 tiles of 128 x 128.  Chosen in the whole model (bench.py, one stream: 89.1 images/s; with the
   // LDS-staged form up to K = 1024, which the isolated sweep of profiles/r02_k6_f16x3.txt prefers by 2-4 %, 85.8).
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-  const bool wide = tiles128 >= 256 || N <= 64;
+  const bool wide = tiles128 >= 160 || N <= 64;      // 128-column tiles from 160 tiles up (sweeps: 116-128 tiles prefer 64, 168-192 prefer 128)
   int rc;
   if (K <= 256) rc = wide ? launch_h3l_act<4>(act, x, wp, bias, out, M, N, K, st) : launch_h3l_act<2>(act, x, wp, bias, out, M, N, K, st);
   else rc = wide ? launch_h3p_act(act, x, wp, bias, out, M, N, K, st) : launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st);

@@ -54,7 +54,7 @@ for name, M, N, K, act in shapes(which):
     b = torch.randn(N, device="cuda")
     p6 = ops.split_weight(w, mode="bf16x6")
     p3 = ops.split_weight(w, mode="f16x3")
-    runs = {"bf16x6": lambda: ops.split_linear(x, p6, b, gelu=bool(act)), "product": lambda: ops.split_linear(x, p3, b, gelu=bool(act)),
+    runs = {"bf16x6": lambda: ops.split_linear(x, p6, b, gelu=bool(act), out_features=N), "product": lambda: ops.split_linear(x, p3, b, gelu=bool(act), out_features=N),
             "blas": lambda: (torch.nn.functional.gelu(torch.nn.functional.linear(x, w, b)) if act else torch.nn.functional.linear(x, w, b))}
     for c in cfgs:
         runs[f"h3:{c}"] = (lambda c=c: h3(x, p3, b, act, c, N))
