@@ -24,6 +24,14 @@ __device__ __forceinline__ float rba_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// The same sigmoid on two values with the multiply and the add packed (v_pk_mul_f32 / v_pk_add_f32): identical operations per
+// element (x * -log2(e), v_exp_f32, + 1, v_rcp_f32), two VALU issues fewer per pair.
+__device__ __forceinline__ f32x2 rba_sigmoid2(f32x2 x) {
+  const f32x2 t = x * -1.44269504088896340736f;
+  const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+  return (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+
 // tanh(x) = sign(x) * (1 - 2 / (e^{2|x|} + 1)); e^{2|x|} -> inf gives exactly 1.
 __device__ __forceinline__ float rba_tanh(float x) {
   float ax = fabsf(x);

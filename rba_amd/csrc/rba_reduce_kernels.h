@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256, WPS) void rba_reduce_pk_kernel(const float* __
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int q = q0 + u;
-        const f32x2 s01 = {rba_sigmoid(buf[u].x), rba_sigmoid(buf[u].y)};
-        const f32x2 s23 = {rba_sigmoid(buf[u].z), rba_sigmoid(buf[u].w)};
+        const f32x2 s01 = rba_sigmoid2((f32x2){buf[u].x, buf[u].y});
+        const f32x2 s23 = rba_sigmoid2((f32x2){buf[u].z, buf[u].w});
         const int qn = q + U < Q ? q + U : Q - 1;
         buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
         const float* pq = prob + q * K;

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
 #define RBA_BLOCK(B, P, CUR, NXT)                                                                                       \
   {                                                                                                                     \
     _Pragma("unroll") for (int q = 0; q < UPL; ++q)(NXT)[tid + 256 * q] = wr[q];                                        \
-    wload((B) + 2);                                                                                                     \
+    if (!(PROBE & 1)) wload((B) + 2);                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     RBA_MFMA6(0, 0, P)                                                                                                  \
     bread(CUR, 2, bq[0]);                                                                                               \
@@ -576,9 +576,9 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
     split_h3(xr[2], xr[3], ah[(P) ^ 1][1], al[(P) ^ 1][1]);                                                             \
     RBA_PIPE_MFMA_DSR_VALU                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    xload((B) + 2);                                                                                                     \
+    if (!(PROBE & 2)) xload((B) + 2);                                                                                   \
     RBA_MFMA6(2, 0, P)                                                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                   \
+    if (!(PROBE & 64)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     RBA_MFMA6(3, 1, P)                                                                                                  \
     bread(NXT, 0, bq[0]);                                                                                               \

@@ -137,6 +137,11 @@ extern "C" int rba_split_linear_h3_tune(const float* x, const void* weight_packe
     case 2284: rc = launch_h3l<1, 4, 128>(x, wp, bias, out, M, N, K, st); break;
     case 4004: rc = launch_h3p_act(act, x, wp, bias, out, M, N, K, st); break;
     case 4044: rc = launch_h3p<1, 4>(x, wp, bias, out, M, N, K, st); break;
+    case 4014: rc = launch_h3p<1, 1>(x, wp, bias, out, M, N, K, st); break;
+    case 4024: rc = launch_h3p<1, 2>(x, wp, bias, out, M, N, K, st); break;
+    case 4034: rc = launch_h3p<1, 3>(x, wp, bias, out, M, N, K, st); break;
+    case 4644: rc = launch_h3p<1, 64>(x, wp, bias, out, M, N, K, st); break;
+    case 4674: rc = launch_h3p<1, 67>(x, wp, bias, out, M, N, K, st); break;
     case 2: rc = launch_h3_act<2>(act, x, wp, bias, out, M, N, K, st); break;
     case 1: rc = launch_h3_act<1>(act, x, wp, bias, out, M, N, K, st); break;
     case 14: rc = launch_h3<1, 4, 1>(x, wp, bias, out, M, N, K, st); break;
@@ -169,6 +174,12 @@ extern "C" int rba_split_linear_h3_timing(const float* x, const void* weight_pac
   if (probe == 0)
     hipLaunchKernelGGL((split_linear_h3_kernel<1, 4, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
                        (int)M, N, K, (int)MT, NT, dbg);
+  else if (probe == 1000)
+    hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
+                       (int)M, N, K, (int)MT, NT, dbg);
+  else if (probe == 1001)
+    hipLaunchKernelGGL((split_linear_h3l_kernel<1, 4, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
+                       (int)M, N, K, (int)MT, NT, dbg, ConvShape{0, 0, 0});
   else
     hipLaunchKernelGGL((split_linear_h3_kernel<1, 4, 127, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias,
                        out, (int)M, N, K, (int)MT, NT, dbg);
