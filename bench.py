@@ -243,8 +243,6 @@ def main():
 
     # ---- the step: everything after the image is resident, up to the RbA map
     S = max(1, args.streams)
-    if S > 1 and args.graph:
-        raise SystemExit("--graph and --streams > 1 are mutually exclusive")
     static_ins = [images[i % len(images)].clone() for i in range(S)]
     static_in = static_ins[0]
     side_streams = [torch.cuda.Stream() for _ in range(S - 1)]
@@ -286,7 +284,7 @@ def main():
     with torch.no_grad():
         out = forward_once()                       # eager once: lazy inits (bias gathers, caches, rocBLAS/MIOpen plans)
         torch.cuda.synchronize()
-        if args.graph:
+        if args.graph and S == 1:
             try:
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
@@ -304,7 +302,49 @@ def main():
                 graph = None
                 torch.cuda.synchronize()
 
+    # --graph with several streams: one captured graph of predict_part per stream (the K1 part stays eager on the main stream so that
+    # its HIP events keep bracketing exactly the K1 launch)
+    part_graphs = None
+    if args.graph and S > 1:
+        graph = None
+        try:
+            part_graphs = []
+            with torch.no_grad():
+                for j in range(S):
+                    st = torch.cuda.Stream() if j == 0 else side_streams[j - 1]
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        predict_part(static_ins[j])                      # warm the stream's allocator pool
+                    torch.cuda.current_stream().wait_stream(st)
+                    torch.cuda.synchronize()
+                    gj = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gj, stream=st):
+                        outs = predict_part(static_ins[j])
+                    torch.cuda.synchronize()
+                    part_graphs.append((gj, st, outs))
+        except Exception as e:
+            if rank == 0:
+                print(f"[bench] per-stream hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            part_graphs = None
+            torch.cuda.synchronize()
+
     def step(i):
+        if part_graphs is not None:
+            main = torch.cuda.current_stream()
+            for j, (gj, st, outs) in enumerate(part_graphs):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    static_ins[j].copy_(images[(i + j) % len(images)], non_blocking=True)
+                    gj.replay()
+            r = None
+            with torch.no_grad():
+                for gj, st, outs in part_graphs:
+                    main.wait_stream(st)
+                for gj, st, outs in part_graphs:
+                    rr = post_part(*outs)
+                    k1_events.append(k1_probe["ev"])
+                    r = rr if r is None else r
+            return r
         static_in.copy_(images[i % len(images)], non_blocking=True)     # device-to-device, input stays in HBM
         if graph is not None:
             graph.replay()
@@ -443,7 +483,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per stream per step "
                                    f"(BASELINE.json configs[1]); random-init seeded weights",
-                       "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None,
+                       "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

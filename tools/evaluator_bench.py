@@ -54,8 +54,11 @@ def main():
     a = A.complete(A.ARCHS["swin_b_1dl"])
     torch.save({"model": A.seeded_weights(a, 0)}, os.path.join(mdir, "model_final.pth"))
     res = {"n_images": n, "image": "1024x2048 PNG", "dataset_write_s": round(t_data, 1)}
-    for tag, extra in (("pipelined_2streams", ["--num_workers", "8", "--streams", "2"]),
-                       ("pipelined_1stream", ["--num_workers", "8", "--streams", "1"]),
+    for tag, extra in (("pipelined_24workers_3streams", ["--num_workers", "24", "--streams", "3"]),
+                       ("pipelined_16workers_3streams", ["--num_workers", "16", "--streams", "3"]),
+                       ("pipelined_8workers_3streams", ["--num_workers", "8", "--streams", "3"]),
+                       ("pipelined_8workers_2streams", ["--num_workers", "8", "--streams", "2"]),
+                       ("pipelined_default", []),
                        ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1"])):
         out = os.path.join(work, "results_" + tag)
         timing = {}
@@ -68,7 +71,7 @@ def main():
         E.run_evaluations(model, torch.utils.data.Subset(ds, [0, 1]), "warm", "fishyscapes_laf", args)       # warm-up: plans, weight planes
         m = E.run_evaluations(model, ds, "swin_b_1dl", "fishyscapes_laf", args, timing=timing)
         res[tag] = {"images_per_s": round(timing["images_per_s"], 2), "seconds": round(timing["seconds"], 3), "metrics": m,
-                    "num_workers": timing["num_workers"], "streams": timing["streams"]}
+                    "num_workers": timing["num_workers"], "streams": timing["streams"], "host_thread": timing.get("host_thread")}
         del model
         torch.cuda.empty_cache()
     print(json.dumps(res))
