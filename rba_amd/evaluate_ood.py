@@ -3,6 +3,7 @@ outputs: ``get_model`` (:108-124), ``get_logits`` (:127-140), ``get_RbA`` (:143-
 command line (``python -m rba_amd.evaluate_ood --models_folder ckpts/ --datasets_folder ... --score_func rba``, same flags,
 same ``results/<model>/results.pkl``), extended with image sharding when launched through torchrun."""
 import argparse
+import sys
 import os
 import pickle
 from pathlib import Path
@@ -94,7 +95,7 @@ SCORE_FUNCS = {"rba": get_RbA, "pebal": get_energy, "energy": get_energy, "neg_l
 def build_parser():
     p = argparse.ArgumentParser(description="OOD Evaluation (rba_amd)")
     p.add_argument("--batch_size", type=int, default=1)
-    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--num_workers", type=int, default=8, help="image-decoding threads (the reference: DataLoader workers)")
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--out_path", type=str, default="results")
     p.add_argument("--verbose", type=lambda v: str(v).lower() not in ("0", "false", "no", ""), default=True)
@@ -109,7 +110,49 @@ def build_parser():
     p.add_argument("--score_func", type=str, default="rba", choices=sorted(SCORE_FUNCS))
     p.add_argument("--upper_limit", type=int, default=1300)
     p.add_argument("--streams", type=int, default=3, help="HIP streams the batch-1 forwards alternate on (1 = the reference's serial loop)")
+    p.add_argument("--graph", type=int, default=1,
+                   help="1: replay the forward of each (stream, image shape) from a captured hipGraph -- the scoring thread then issues one "
+                        "launch per image instead of ~370 (it is the bottleneck beside the decode threads); falls back to eager launches "
+                        "if the capture fails")
     return p
+
+
+class GraphedScore:
+    """score_func(model, x[None]) replayed from one captured hipGraph per image shape, for ONE stream.  The first call of a shape
+    runs eagerly (lazy per-shape state of the model), the second captures, later calls copy the image into the static input and
+    replay.  The returned map is a fresh tensor (the static output is overwritten by the next replay)."""
+
+    MAX_SHAPES = 4
+
+    def __init__(self, model, score_func, stream):
+        self.model, self.score_func, self.stream = model, score_func, stream
+        self.graphs = {}             # shape -> None (seen once) | (graph, static_in, static_out) | False (capture failed: eager)
+
+    def __call__(self, x):
+        key = tuple(x.shape)
+        entry = self.graphs.get(key, "new")
+        if entry == "new":
+            # every graph keeps its own activation pool alive: at most MAX_SHAPES image shapes are captured per stream
+            self.graphs[key] = None if sum(1 for e in self.graphs.values() if e is not False) < self.MAX_SHAPES else False
+            return self.score_func(self.model, x[None])
+        if entry is None:
+            try:
+                static_in = x.clone()
+                g = torch.cuda.CUDAGraph()
+                # captured on torch's capture stream, replayed on self.stream; thread_local: the decode threads pin memory meanwhile
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    static_out = self.score_func(self.model, static_in[None])
+                entry = self.graphs[key] = (g, static_in, static_out)
+            except Exception as e:                                   # noqa: BLE001 -- an optimisation only
+                print(f"[rba_amd] hipGraph capture failed for shape {key} ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                torch.cuda.synchronize()
+                entry = self.graphs[key] = False
+        if entry is False:
+            return self.score_func(self.model, x[None])
+        g, static_in, static_out = entry
+        static_in.copy_(x, non_blocking=True)
+        g.replay()
+        return static_out.clone()
 
 
 def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, world=1, timing=None):
@@ -119,8 +162,8 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     Pipeline (the reference feeds its loop from DataLoader(batch_size, num_workers), :210-211): images are decoded ahead of the GPU
     by `--num_workers` threads (datasets.prefetch), copied to the GPU and scored batch-1 on alternating HIP streams (`--streams`,
     default 3) so that the host-side launch work and the under-occupied kernels of one image overlap the other image; score maps and
-    labels never leave the GPU (the metric is a GPU sort).  (Replaying the forward from a captured hipGraph was measured too: no gain,
-    the loop is GPU bound -- profiles/r02_evaluator.json -- so it is not offered.)"""
+    labels never leave the GPU (the metric is a GPU sort).  `--graph 1` replays each stream's forward from a captured hipGraph: the
+    scoring thread, which shares the interpreter lock with the decode threads, is otherwise the bottleneck (tools/host_overhead.py)."""
     import time
     from . import distributed as D
     from .datasets import prefetch
@@ -135,6 +178,8 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     n_streams = max(1, int(getattr(args, "streams", 3))) if on_gpu else 1
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
+    graphed = ({id(st_): GraphedScore(model, score_func, st_) for st_ in streams}
+               if on_gpu and int(getattr(args, "graph", 0)) and not args.store_anomaly_scores else None)
     scores, labels = [], []
     pending = []
     FLUSH = 32
@@ -183,7 +228,9 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
                 t_a = time.perf_counter()
                 x = xb[j].to(dev, non_blocking=True)
                 y = yb[j].to(dev, non_blocking=True)
-                s = score_func(model, x[None])
+                # a graph belongs to the stream it was captured on; the first image of a shape runs on the main stream (above) and
+                # is scored eagerly there
+                s = graphed[id(st)](x) if graphed is not None and not first_of_shape else score_func(model, x[None])
                 t_b = time.perf_counter()
                 if args.store_anomaly_scores:
                     vis = os.path.join("anomaly_scores", model_name, dataset_name)
@@ -213,6 +260,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     dt = time.perf_counter() - t0
     if timing is not None:
         timing.update(images=k, seconds=dt, images_per_s=(k / dt if dt > 0 else 0.0), num_workers=nw, streams=len(streams),
+                      hip_graphs=(sum(1 for gs in graphed.values() for e in gs.graphs.values() if isinstance(e, tuple)) if graphed else 0),
                       host_thread={n: round(v, 3) for n, v in host.items()})
     s_all = torch.cat(scores) if scores else torch.empty(0, device=dev)
     y_all = torch.cat(labels) if labels else torch.empty(0, dtype=torch.bool, device=dev)

@@ -230,8 +230,9 @@ def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
     E.main(argv)
     assert (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns == mtime
     # every pipelining mode of the scoring loop gives the same pooled metrics: decode threads x HIP streams
-    for k, extra in enumerate((["--num_workers", "0", "--streams", "1"], ["--num_workers", "3", "--streams", "2"],
-                               ["--num_workers", "2", "--streams", "1"])):
+    for k, extra in enumerate((["--num_workers", "0", "--streams", "1", "--graph", "0"], ["--num_workers", "3", "--streams", "2", "--graph", "0"],
+                               ["--num_workers", "2", "--streams", "1", "--graph", "0"], ["--num_workers", "3", "--streams", "3", "--graph", "1"],
+                               ["--num_workers", "0", "--streams", "1", "--graph", "1"])):
         out = tmp_path / f"results_{k}"
         E.main(argv[:4] + ["--out_path", str(out), "--verbose", "false"] + extra)
         with open(out / "tiny" / "results.pkl", "rb") as f:

@@ -54,12 +54,14 @@ def main():
     a = A.complete(A.ARCHS["swin_b_1dl"])
     torch.save({"model": A.seeded_weights(a, 0)}, os.path.join(mdir, "model_final.pth"))
     res = {"n_images": n, "image": "1024x2048 PNG", "dataset_write_s": round(t_data, 1)}
-    for tag, extra in (("pipelined_24workers_3streams", ["--num_workers", "24", "--streams", "3"]),
-                       ("pipelined_16workers_3streams", ["--num_workers", "16", "--streams", "3"]),
-                       ("pipelined_8workers_3streams", ["--num_workers", "8", "--streams", "3"]),
-                       ("pipelined_8workers_2streams", ["--num_workers", "8", "--streams", "2"]),
-                       ("pipelined_default", []),
-                       ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1"])):
+    for tag, extra in (("default_graph_8workers_3streams", []),
+                       ("graph_16workers_3streams", ["--num_workers", "16"]),
+                       ("graph_12workers_2streams", ["--num_workers", "12", "--streams", "2"]),
+                       ("graph_4workers_3streams", ["--num_workers", "4"]),
+                       ("eager_8workers_3streams", ["--graph", "0"]),
+                       ("eager_4workers_3streams", ["--graph", "0", "--num_workers", "4"]),
+                       ("eager_16workers_3streams", ["--graph", "0", "--num_workers", "16"]),
+                       ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1", "--graph", "0"])):
         out = os.path.join(work, "results_" + tag)
         timing = {}
         args = E.build_parser().parse_args(["--models_folder", os.path.join(work, "ckpts"), "--datasets_folder", os.path.join(work, "data"),
@@ -71,7 +73,7 @@ def main():
         E.run_evaluations(model, torch.utils.data.Subset(ds, [0, 1]), "warm", "fishyscapes_laf", args)       # warm-up: plans, weight planes
         m = E.run_evaluations(model, ds, "swin_b_1dl", "fishyscapes_laf", args, timing=timing)
         res[tag] = {"images_per_s": round(timing["images_per_s"], 2), "seconds": round(timing["seconds"], 3), "metrics": m,
-                    "num_workers": timing["num_workers"], "streams": timing["streams"], "host_thread": timing.get("host_thread")}
+                    "num_workers": timing["num_workers"], "streams": timing["streams"], "host_thread": timing.get("host_thread"), "hip_graphs": timing.get("hip_graphs")}
         del model
         torch.cuda.empty_cache()
     print(json.dumps(res))
