@@ -225,6 +225,163 @@ int launch_reduce_mx(const float* mask, const float* prob, float* rba, int Q, in
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// K1 on the f16 matrix pipe, register-light ("h3"): the mx idea (no transposition: the 32x32x16 B fragment of a lane IS 8 query
+// planes of one pixel) with what made mx lose removed --
+//   * THREE f16 MFMAs per product instead of six bf16 ones, and a two-piece split (sigma = h + l, h = f16(sigma), l = f16(sigma - h):
+//     sigma and the class probabilities live in (0, 1), so the unscaled residual's f16 underflow is an ABSOLUTE error <= 2^-25 per
+//     term, 3e-6 on a 100-query sum at the very worst, far inside the 1e-4 score tolerance): 4 VALU per pair instead of ~10;
+//   * 64 pixels per wave step (two pixels per lane, 8-byte loads) instead of 128: 32 accumulator registers instead of 64, ~100
+//     registers in all -> four waves per SIMD like the VALU kernel, each with 16-32 plane loads in flight (the VALU kernel: 2).
+// Step (tile, g): lane (l31, lh) loads planes q = 16 g + 8 lh + i, i < 8, at pixels 2 l31, 2 l31 + 1 of the tile (256 contiguous bytes
+// per plane and half-wave); sigmoid; pack (q = 2 j, 2 j + 1) pairs per pixel -> the f16x8 B operands of the two 32-pixel MFMA tiles;
+// A = the split class-probability fragment of query group g from LDS (built once per workgroup).
+typedef _Float16 h3k_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h3k_f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void h3k_split2(float a, float b, uint32_t& h, uint32_t& l) {          // (a, b) -> packed f16 h, l = f16(x - h)
+  const h3k_f16x2 hv = {(_Float16)a, (_Float16)b};
+  h = __builtin_bit_cast(uint32_t, hv);
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(-1.0f), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(-1.0f), "v"(b));
+  l = r;
+}
+
+// PROBE: 1 = loads only, 2 = arithmetic only (every step re-uses the first tile's planes)
+template <int WPS, int PROBE = 0>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_h3_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                               float* __restrict__ rba, int Q, int K, int64_t HW, int ntiles,
+                                                               unsigned int* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) mx_u32x4 h3k_pfrag[];         // [G][2 planes][64 lanes]: A fragments of P^T
+  const int G = (Q + 15) >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  for (int idx = tid; idx < G * 64; idx += 256) {
+    const int g = idx >> 6, l = idx & 63, m = l & 31, hh = l >> 5;
+    mx_u32x4 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q0 = 16 * g + 8 * hh + 2 * j;
+      const float a = (q0 < Q && m < K) ? prob[q0 * K + m] : 0.f;
+      const float b = (q0 + 1 < Q && m < K) ? prob[(q0 + 1) * K + m] : 0.f;
+      uint32_t h, lo;
+      h3k_split2(a, b, h, lo);
+      ph[j] = h;
+      pl[j] = lo;
+    }
+    h3k_pfrag[(g * 2 + 0) * 64 + l] = ph;
+    h3k_pfrag[(g * 2 + 1) * 64 + l] = pl;
+  }
+  __syncthreads();
+
+  // a wave works on 64-pixel tiles; the four waves of a workgroup take consecutive tiles of a 256-pixel chunk
+  const int wave = tid >> 6;
+  const int nchunks = (ntiles + 3) >> 2;
+  auto load = [&](f32x2 (&buf)[8], int64_t tile, int g) {
+    if (PROBE == 2) { tile = wave; g = 0; }
+    int64_t pix = tile * 64 + 2 * l31;
+    pix = pix < HW ? pix : HW - 2;
+    const float* base = mask + pix;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int q = 16 * g + 8 * lh + i;
+      q = q < Q ? q : Q - 1;
+      buf[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(base + (int64_t)q * HW));
+    }
+  };
+  mx_f32x16 acc[2];
+  auto compute = [&](const f32x2 (&buf)[8], int g) {
+    if (g == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+    if (PROBE == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { acc[0][i] += buf[i].x; acc[1][i] += buf[i].y; }
+      return;
+    }
+    const h3k_f16x8 ah = __builtin_bit_cast(h3k_f16x8, h3k_pfrag[(g * 2 + 0) * 64 + lane]);
+    const h3k_f16x8 al = __builtin_bit_cast(h3k_f16x8, h3k_pfrag[(g * 2 + 1) * 64 + lane]);
+    f32x2 sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sg[i] = rba_sigmoid2(buf[i]);
+    mx_u32x4 bh[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t h0, l0, h1, l1;
+      h3k_split2(sg[2 * j].x, sg[2 * j + 1].x, h0, l0);
+      h3k_split2(sg[2 * j].y, sg[2 * j + 1].y, h1, l1);
+      bh[0][j] = h0; bl[0][j] = l0; bh[1][j] = h1; bl[1][j] = l1;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(h3k_f16x8, bh[t]), acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(h3k_f16x8, bl[t]), acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(h3k_f16x8, bh[t]), acc[t], 0, 0, 0);
+  };
+  auto finish = [&](int64_t tile) {
+    // lane holds sem[class = 8 (r / 4) + 4 lh + r % 4][pixel 2 l31 + t of the tile]
+    float out[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc += (8 * (r >> 2) + 4 * lh + (r & 3) < K) ? rba_tanh(acc[t][r]) : 0.f;
+      sacc += __shfl_xor(sacc, 32, RBA_WAVE);
+      out[t] = -sacc;
+    }
+    const int64_t pix = tile * 64 + 2 * l31;
+    if (lh == 0 && pix + 1 < HW) *reinterpret_cast<f32x2*>(rba + pix) = (f32x2){out[0], out[1]};
+    else if (lh == 0 && pix < HW) rba[pix] = out[0];
+  };
+
+  auto dequeue = [&]() -> int {
+    __syncthreads();
+    __shared__ unsigned int sh_chunk;
+    if (tid == 0) sh_chunk = atomicAdd(counters, 1u);
+    __syncthreads();
+    return (int)sh_chunk;
+  };
+  f32x2 bufA[8], bufB[8];
+  for (int chunk = dequeue(); chunk < nchunks; chunk = dequeue()) {
+    const int64_t tile = (int64_t)chunk * 4 + wave;
+    if (tile >= ntiles) continue;
+    load(bufA, tile, 0);
+    for (int g = 0; g < G; g += 2) {                                   // two query groups per trip: the buffers alternate statically
+      if (g + 1 < G) load(bufB, tile, g + 1);
+      compute(bufA, g);
+      if (g + 2 < G) load(bufA, tile, g + 2);
+      if (g + 1 < G) compute(bufB, g + 1);
+    }
+    finish(tile);
+  }
+  if (tid == 0) {
+    const unsigned int done = atomicAdd(counters + 1, 1u);
+    if (done == gridDim.x - 1) {
+      atomicExch(counters, 0u);
+      atomicExch(counters + 1, 0u);
+    }
+  }
+}
+
+template <int WPS, int PROBE = 0>
+int launch_reduce_h3(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, unsigned int* counters, hipStream_t st) {
+  const int64_t tiles = (HW + 63) / 64;
+  if (tiles > 0x7fffffffLL || Q > 1024 || K > 32) return (int)hipErrorInvalidValue;
+  const int G = (Q + 15) / 16;
+  const size_t dyn = (size_t)G * 2 * 64 * 16;
+  const int64_t chunks = (tiles + 3) / 4;
+  int64_t grid = 256 * WPS;
+  grid = chunks < grid ? chunks : grid;
+  grid = grid < 1 ? 1 : grid;
+  hipLaunchKernelGGL((rba_reduce_h3_kernel<WPS, PROBE>), dim3((unsigned)grid), dim3(256), dyn, st, mask, prob, rba, Q, K, HW, (int)tiles, counters);
+  return rba_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // K1 with the class contraction on the EXACT-fp32 matrix pipe ("mf"): v_mfma_f32_32x32x2_f32, D[class][pixel] += P[q][class] *
 // sigma[q][pixel] for TWO queries per instruction, bitwise a k-ordered fmaf chain -- the same ascending-q order as the VALU kernels,
 // no operand splitting.  Loads keep the VALU kernels' pattern (lane l = pixels 4 l .. 4 l + 3 of ONE plane, 1 KiB contiguous per

@@ -754,6 +754,17 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       if (variant == 211) return launch_reduce_mf<2, 1>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
       return launch_reduce_mf<2, 2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
     }
+    case 300: case 301: case 302: case 303: case 304: {   // f16x3 register-light kernel: 4 / 3 / 5 workgroups per CU, loads only, arithmetic only
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      static bool zeroed3 = false;
+      if (!zeroed3) { (void)hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st); zeroed3 = true; }
+      if (variant == 300) return launch_reduce_h3<4>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      if (variant == 301) return launch_reduce_h3<3>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      if (variant == 302) return launch_reduce_h3<5>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      if (variant == 303) return launch_reduce_h3<4, 1>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      return launch_reduce_h3<4, 2>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+    }
     case 202: case 203: {   // ablations of the mx kernel: loads only / arithmetic only
       unsigned int* ctr = nullptr;
       if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
