@@ -438,3 +438,23 @@ def test_bench_self_launch_two_ranks_share_device():
     # in this process)
     for k in want:
         assert abs(res["pooled_metrics"][k] - want[k]) < 1e-5, (k, res["pooled_metrics"], want)
+
+
+def test_split_mode_switch_bf16x6_matches_f16x3(monkeypatch):
+    """ops.SPLIT_MODE selects the arithmetic of the token Linears: the full-range bf16x6 form and the default f16x3 form are both
+    fp32-accurate, so the whole-path score maps agree far inside the 1e-4 tolerance (and the weight planes are re-split on the switch)."""
+    from rba_amd import ops
+    model, a, _ = build("swin_b_1dl", 0)
+    g = torch.Generator().manual_seed(21)
+    image = torch.randint(0, 256, (3, 512, 1024), generator=g, dtype=torch.uint8).cuda()
+    assert ops.SPLIT_MODE == "f16x3"
+    r3 = model.rba_scores([{"image": image}])[0].clone()
+    fc1 = model.backbone.layers[2].blocks[0].mlp.fc1
+    assert fc1._rba_planes[1].dtype == torch.float16
+    monkeypatch.setattr(ops, "SPLIT_MODE", "bf16x6")
+    r6 = model.rba_scores([{"image": image}])[0]
+    assert fc1._rba_planes[1].dtype == torch.bfloat16
+    assert (r3 - r6).abs().max().item() < 5e-5
+    monkeypatch.setattr(ops, "SPLIT_MODE", "f16x3")
+    assert torch.equal(model.rba_scores([{"image": image}])[0], r3)
+
