@@ -235,6 +235,18 @@ int launch_reduce_mx(const float* mask, const float* prob, float* rba, int Q, in
 // Step (tile, g): lane (l31, lh) loads planes q = 16 g + 8 lh + i, i < 8, at pixels 2 l31, 2 l31 + 1 of the tile (256 contiguous bytes
 // per plane and half-wave); sigmoid; pack (q = 2 j, 2 j + 1) pairs per pixel -> the f16x8 B operands of the two 32-pixel MFMA tiles;
 // A = the split class-probability fragment of query group g from LDS (built once per workgroup).
+template <typename KernelT>
+static inline int ensure_dynamic_lds_k1(KernelT kernel, size_t bytes, unsigned char (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+  if (!done[dev]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = 1;
+  }
+  return 0;
+}
+
 typedef _Float16 h3k_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h3k_f16x2 __attribute__((ext_vector_type(2)));
 
@@ -377,6 +389,170 @@ int launch_reduce_h3(const float* mask, const float* prob, float* rba, int Q, in
   grid = chunks < grid ? chunks : grid;
   grid = grid < 1 ? 1 : grid;
   hipLaunchKernelGGL((rba_reduce_h3_kernel<WPS, PROBE>), dim3((unsigned)grid), dim3(256), dyn, st, mask, prob, rba, Q, K, HW, (int)tiles, counters);
+  return rba_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K1 on the f16 matrix pipe with the VALU kernel's LOAD PATTERN ("tr"): every wave instruction reads 1 KiB of ONE plane (lane = 4
+// consecutive pixels), sigma is computed and split (h, l) where it was loaded, written to LDS as f16 rows [query][pixel], and the MFMA
+// B operand (8 consecutive queries of one pixel per lane) is fetched with the TRANSPOSING LDS read ds_read_b64_tr_b16: a 16-lane group
+// reads a [4 queries][16 pixels] block and every lane receives its pixel's column (probe: tools/micro/tr_probe).
+//   workgroup tile 256 pixels; super-step = 32 queries: wave w loads planes 32 g + 8 w + i (i < 8) for all 256 pixels, then computes
+//   its own 64 pixels (4 pixel tiles x 2 class tiles x 3 products = 24 v_mfma_f32_16x16x32_f16) over all 32 queries.
+//   LDS sigma image: [h | l][16 pixel tiles] x 1056 B, a tile = [half 2][kg 4][4 queries][16 pixels] f16 (+32 B pad: the 8-byte
+//   writes of 16 consecutive lanes hit 4 tiles x 32 B -> distinct banks); the two tr reads of a lane: tile + half 512 + lane 8.
+typedef __fp16 trk_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float trk_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int WPS, int PROBE = 0>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_tr_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                               float* __restrict__ rba, int Q, int K, int64_t HW, int ntiles,
+                                                               unsigned int* __restrict__ counters) {
+  constexpr int TS = 1056, PS = 16 * TS;                                       // bytes per pixel tile / per plane part (h or l)
+  extern __shared__ __attribute__((aligned(16))) unsigned char trk_lds[];
+  const int G = (Q + 31) >> 5;
+  unsigned char* sig = trk_lds;                                                // 2 PS bytes
+  mx_u32x4* pfrag = reinterpret_cast<mx_u32x4*>(trk_lds + 2 * PS);             // [G][mt 2][part 2][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int idx = tid; idx < G * 2 * 64; idx += 256) {
+    const int l = idx & 63, mt = (idx >> 6) & 1, g = idx >> 7;
+    const int m = (l & 15) + 16 * mt, kg = l >> 4;
+    mx_u32x4 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q0 = 32 * g + 8 * kg + 2 * j;
+      const float a = (q0 < Q && m < K) ? prob[q0 * K + m] : 0.f;
+      const float b = (q0 + 1 < Q && m < K) ? prob[(q0 + 1) * K + m] : 0.f;
+      uint32_t h, lo;
+      h3k_split2(a, b, h, lo);
+      ph[j] = h;
+      pl[j] = lo;
+    }
+    pfrag[((g * 2 + mt) * 2 + 0) * 64 + l] = ph;
+    pfrag[((g * 2 + mt) * 2 + 1) * 64 + l] = pl;
+  }
+
+  // this thread's slot in the sigma image: pixel tile lane / 4, column group lane % 4, kg = wave; + half 512 + row 32 per plane
+  const int wslot = (lane >> 2) * TS + wave * 128 + (lane & 3) * 8;
+  const int rslot = lane * 8;                                                  // + (4 wave + t) TS + half 512 + part PS
+  auto load = [&](f32x4 (&buf)[8], int64_t tile, int g) {
+    if (PROBE == 2) { tile = 0; g = 0; }
+    int64_t pix = tile * 256 + 4 * lane;
+    pix = pix < HW ? pix : HW - 4;
+    const float* base = mask + pix;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int q = 32 * g + 8 * wave + i;
+      q = q < Q ? q : Q - 1;
+      buf[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (int64_t)q * HW));
+    }
+  };
+  trk_f32x4 acc[4][2];
+  auto stage = [&](const f32x4 (&buf)[8]) {                                    // sigmoid + split + LDS write of this thread's 8 planes
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x2 s01 = rba_sigmoid2((f32x2){buf[i].x, buf[i].y}), s23 = rba_sigmoid2((f32x2){buf[i].z, buf[i].w});
+      uint32_t h0, l0, h1, l1;
+      h3k_split2(s01.x, s01.y, h0, l0);
+      h3k_split2(s23.x, s23.y, h1, l1);
+      const int off = wslot + (i >> 2) * 512 + (i & 3) * 32;
+      *reinterpret_cast<uint2*>(sig + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(sig + PS + off) = make_uint2(l0, l1);
+    }
+  };
+  auto compute = [&](int g) {
+    typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+    f16x8v ah[2], al[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      ah[mt] = __builtin_bit_cast(f16x8v, pfrag[((g * 2 + mt) * 2 + 0) * 64 + lane]);
+      al[mt] = __builtin_bit_cast(f16x8v, pfrag[((g * 2 + mt) * 2 + 1) * 64 + lane]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned char* tb = sig + (4 * wave + t) * TS + rslot;
+      trk_h4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trk_h4*)(tb));
+      trk_h4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trk_h4*)(tb + 512));
+      trk_h4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trk_h4*)(tb + PS));
+      trk_h4 r3 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trk_h4*)(tb + PS + 512));
+      const uint2 u0 = __builtin_bit_cast(uint2, r0), u1 = __builtin_bit_cast(uint2, r1);
+      const uint2 u2 = __builtin_bit_cast(uint2, r2), u3 = __builtin_bit_cast(uint2, r3);
+      const f16x8v bh = __builtin_bit_cast(f16x8v, (mx_u32x4){u0.x, u0.y, u1.x, u1.y});
+      const f16x8v bl = __builtin_bit_cast(f16x8v, (mx_u32x4){u2.x, u2.y, u3.x, u3.y});
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[t][mt], 0, 0, 0);
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, acc[t][mt], 0, 0, 0);
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, acc[t][mt], 0, 0, 0);
+      }
+    }
+  };
+  auto finish = [&](int64_t tile) {
+    // lane holds sem[class = 16 mt + 4 (lane >> 4) + r][pixel 64 wave + 16 t + (lane & 15)]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc += (16 * mt + 4 * (lane >> 4) + r < K) ? rba_tanh(acc[t][mt][r]) : 0.f;
+      sacc += __shfl_xor(sacc, 16, RBA_WAVE);
+      sacc += __shfl_xor(sacc, 32, RBA_WAVE);
+      const int64_t pix = tile * 256 + 64 * wave + 16 * t + (lane & 15);
+      if (lane < 16 && pix < HW) rba[pix] = -sacc;
+    }
+  };
+
+  __shared__ unsigned int sh_tile;
+  auto dequeue = [&]() -> int {
+    __syncthreads();
+    if (tid == 0) sh_tile = atomicAdd(counters, 1u);
+    __syncthreads();
+    return (int)sh_tile;
+  };
+  f32x4 buf[8];
+  for (int tile = dequeue(); tile < ntiles; tile = dequeue()) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[t][mt] = (trk_f32x4){0.f, 0.f, 0.f, 0.f};
+    load(buf, tile, 0);
+    for (int g = 0; g < G; ++g) {
+      if (PROBE != 1) stage(buf);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i & 3][i >> 2] += (trk_f32x4){buf[i].x, buf[i].y, buf[i].z, buf[i].w};
+      }
+      if (g + 1 < G) load(buf, tile, g + 1);
+      __syncthreads();
+      if (PROBE != 1) compute(g);
+      __syncthreads();
+    }
+    finish(tile);
+  }
+  if (tid == 0) {
+    const unsigned int done = atomicAdd(counters + 1, 1u);
+    if (done == gridDim.x - 1) {
+      atomicExch(counters, 0u);
+      atomicExch(counters + 1, 0u);
+    }
+  }
+}
+
+template <int WPS, int PROBE = 0>
+int launch_reduce_tr(const float* mask, const float* prob, float* rba, int Q, int K, int64_t HW, unsigned int* counters, hipStream_t st) {
+  const int64_t tiles = (HW + 255) / 256;
+  if (tiles > 0x7fffffffLL || Q > 256 || K > 32 || (HW & 3)) return (int)hipErrorInvalidValue;
+  const int G = (Q + 31) / 32;
+  const size_t dyn = (size_t)2 * 16 * 1056 + (size_t)G * 4 * 64 * 16;
+  static unsigned char done_attr[64] = {0};
+  int rc = ensure_dynamic_lds_k1(rba_reduce_tr_kernel<WPS, PROBE>, dyn, done_attr);
+  if (rc) return rc;
+  int64_t grid = 256 * WPS;
+  grid = tiles < grid ? tiles : grid;
+  grid = grid < 1 ? 1 : grid;
+  hipLaunchKernelGGL((rba_reduce_tr_kernel<WPS, PROBE>), dim3((unsigned)grid), dim3(256), dyn, st, mask, prob, rba, Q, K, HW, (int)tiles, counters);
   return rba_launch_status();
 }
 

@@ -754,6 +754,17 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       if (variant == 211) return launch_reduce_mf<2, 1>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
       return launch_reduce_mf<2, 2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
     }
+    case 310: case 311: case 312: case 313: case 314: {   // f16x3 + transposing LDS reads: 3 / 2 / 4 workgroups per CU, loads only, arithmetic only
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      static bool zeroed4 = false;
+      if (!zeroed4) { (void)hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st); zeroed4 = true; }
+      if (variant == 310) return launch_reduce_tr<3>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      if (variant == 311) return launch_reduce_tr<2>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      if (variant == 312) return launch_reduce_tr<4>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      if (variant == 313) return launch_reduce_tr<3, 1>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+      return launch_reduce_tr<3, 2>(mask, cls_prob, rba, Q, 19, HW, ctr, st);
+    }
     case 300: case 301: case 302: case 303: case 304: {   // f16x3 register-light kernel: 4 / 3 / 5 workgroups per CU, loads only, arithmetic only
       unsigned int* ctr = nullptr;
       if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
