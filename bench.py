@@ -454,6 +454,9 @@ def main():
                         "achieved": prods * flops32 / (g_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS,
                         "unit": f"TFLOP/s ({'f16' if prods == 3.0 else 'bf16'} MFMA, {int(prods)} products per fp32 product; dense f16 = bf16 peak)",
                         "frac": prods * flops32 / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, "fp32_equivalent_tflops": flops32 / (g_ms * 1e-3) / 1e12,
+                        # the rate a SIX-product (bf16x6) kernel would need for the same launch time, as a fraction of the same peak: the
+                        # round-1 / VERDICT yardstick (0.38 then), comparable across the two arithmetic forms
+                        "six_product_equivalent_frac": 6.0 * flops32 / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
                         "avg_launch_ms": g_ms, "launches_timed": len(evs)}
         except Exception as e:                                           # informational only
             print(f"[bench] K6 roofline probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
