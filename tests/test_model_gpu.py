@@ -458,3 +458,37 @@ def test_split_mode_switch_bf16x6_matches_f16x3(monkeypatch):
     monkeypatch.setattr(ops, "SPLIT_MODE", "f16x3")
     assert torch.equal(model.rba_scores([{"image": image}])[0], r3)
 
+
+@pytest.mark.parametrize("arch_name,score_funcs", [("tiny1", ("energy", "neg_logit_sum")), ("tiny1_dh", ("dense_hybrid",))])
+def test_evaluate_ood_graph_replay_equals_eager(tmp_path, arch_name, score_funcs):
+    """`--graph 1` (the default: each stream's forward replayed from a captured hipGraph) gives the metrics of `--graph 0` for every
+    score function, the DenseHybrid head included."""
+    import pickle
+    import yaml
+    from rba_amd import evaluate_ood as E
+    from tests.test_datasets_cpu import make_fs_laf, make_road_anomaly
+    a = A.complete(A.ARCHS[arch_name])
+    mdir = tmp_path / "ckpts" / "m"
+    mdir.mkdir(parents=True)
+    cfg = {"MODEL": {"SWIN": {"EMBED_DIM": 32, "DEPTHS": [2, 2, 2, 2], "NUM_HEADS": [1, 2, 4, 8], "WINDOW_SIZE": 6},
+                     "SEM_SEG_HEAD": {"CONVS_DIM": 64, "MASK_DIM": 64, "TRANSFORMER_ENC_LAYERS": 2,
+                                      "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res5"]},
+                     "MASK_FORMER": {"HIDDEN_DIM": 64, "NHEADS": 2, "NUM_OBJECT_QUERIES": 16, "DIM_FEEDFORWARD": 128, "DEC_LAYERS": 2,
+                                     "DENSE_HYBRID_LOSS": arch_name == "tiny1_dh"}}}
+    (mdir / "config.yaml").write_text(yaml.safe_dump(cfg))
+    torch.save({"model": A.seeded_weights(a, 0)}, mdir / "model_final.pth")
+    data = tmp_path / "data"
+    make_road_anomaly(str(data), n=7, h=48, w=80)
+    make_fs_laf(str(data), n=7, h=40, w=72)
+    for sf in score_funcs:
+        res = {}
+        for g in ("0", "1"):
+            out = tmp_path / f"res_{sf}_{g}"
+            E.main(["--models_folder", str(tmp_path / "ckpts"), "--datasets_folder", str(data), "--out_path", str(out), "--verbose", "0",
+                    "--score_func", sf, "--graph", g, "--num_workers", "2", "--streams", "2"])
+            with open(out / "m" / "results.pkl", "rb") as f:
+                res[g] = pickle.load(f)
+        for d in res["0"]:
+            for k in res["0"][d]:
+                assert abs(res["0"][d][k] - res["1"][d][k]) < 1e-12, (sf, d, k, res["0"][d][k], res["1"][d][k])
+
