@@ -333,7 +333,9 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
                                                  (4096, 384, 512, False, False), (130, 256, 1024, True, True), (1, 128, 64, False, True),
                                                  (2048, 512, 2048, False, True), (3600, 1024, 96, True, False),
                                                  (500, 192, 192, False, True), (900, 576, 192, True, True), (300, 100, 64, False, False),
-                                                 (257, 1, 32, False, True)])
+                                                 (257, 1, 32, False, True),
+                                                 # the software-pipelined form (K > 256, >= 160 tiles): even / odd block counts, ragged M and N
+                                                 (8192, 1536, 512, False, True), (3000, 1100, 544, True, True), (2600, 1280, 288, False, False)])
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
 def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias, mode):
     """Six bf16 MFMAs (three f16 MFMAs) per product reproduce the fp32 Linear: error against fp64 at the level of an fp32 GEMM's own
