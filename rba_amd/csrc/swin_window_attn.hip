@@ -341,6 +341,8 @@ __global__ void swin_bias_fragments_kernel(const float* __restrict__ bias, float
 
 }  // namespace
 
+#include "swin_window_attn_h3.h"
+
 extern "C" int64_t rba_swin_bias_fragments_elems(int nH, int ws) {
   if (nH <= 0 || ws <= 0 || ws * ws > 256) return 0;
   const int64_t NT = (ws * ws + 15) / 16;
@@ -374,7 +376,7 @@ extern "C" int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias,
   if (hd == 32) {                                   // matrix-pipe path for the window sizes in use
     const int NT = (N + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
-    if (NT == 9) return launch_mfma<9, 9>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
+    if (NT == 9) return launch_h3<9, 9>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
     if (NT == 4) return launch_mfma<4, 4>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
     if (NT == 3) return launch_mfma<3, 3>(qkv, qkv_bias, bias, bias_frag, out, B, H, W, Hp, Wp, nH, ws, shift, scale, st);
   }

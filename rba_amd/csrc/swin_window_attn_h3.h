@@ -1,0 +1,245 @@
+// K5, f16x3 form (head_dim 32): the same workgroup-per-(window, head) kernel as swin_window_attn_mfma_kernel with both contractions
+// on v_mfma_f32_16x16x32_f16 -- three f16 MFMAs per fp32 product (split_linear_h3.h) instead of exact-fp32 MFMAs at 1/16 of the rate:
+//   S^T = K . Q^T   one 32-deep step per key tile: A = K fragment (8 contiguous d of one key: ONE ds_read_b128 per piece),
+//                   B = Q^T (registers, split once per strip); 3 MFMAs of 16 cycles instead of 8 of 32
+//   O   = P . V     32 keys per step (two key tiles): A = P, which the lane already holds (the S^T accumulator layout IS the A layout,
+//                   as in the fp32 kernel), B = V fetched from its row-major [key][d] LDS image with the TRANSPOSING read
+//                   ds_read_b64_tr_b16 (a 16-lane group reads 4 keys x 16 d and every lane receives its d column)
+// Pieces: K, Q and P's first factor use the unscaled residual l = f16(x - h) into ONE accumulator (a softmax only sees absolute
+// errors of the scores: <= 32 |q| 2^-25 from f16's subnormal floor); the P . V product uses scaled residuals (x 2^11) and a second
+// accumulator like the Linear kernel, so the output keeps 22 bits whatever V's magnitude.  |q|, |k|, |v| < 65504.
+// Measured (tools/k5_sweep.py): matrix work is ~40 % of the fp32-MFMA kernel (ablation builds in DESIGN.md section 7).
+// LDS: four f16 planes [NP keys][32 d] with 64-byte rows: K (h, l) with the 16-byte chunk c of key k at c ^ P[(k >> 2) & 3],
+// P = {0, 2, 3, 1} (conflict-free ds_read_b128 for the row-per-lane fragment); V (h, l) with the 32-byte half d / 16 at
+// (d / 16) ^ ((k >> 2) & 1) (conflict-free transposing reads).
+#pragma once
+
+namespace {
+
+typedef _Float16 k5h_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 k5h_f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 k5h_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef uint32_t k5h_u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed f16 h and the packed f16 residual l = f16((x - h) * SC), SC = 1 (unscaled) or 2048
+template <bool SCALED>
+__device__ __forceinline__ void k5h_split2(float a, float b, uint32_t& h, uint32_t& l) {
+  const k5h_f16x2 hv = {(_Float16)a, (_Float16)b};
+  h = __builtin_bit_cast(uint32_t, hv);
+  const float m = SCALED ? -2048.0f : -1.0f;
+  const float a2 = SCALED ? a * 2048.0f : a, b2 = SCALED ? b * 2048.0f : b;
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(m), "v"(a2));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(m), "v"(b2));
+  l = r;
+}
+
+template <int NT, int WAVES, bool FRAG>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8))) void swin_window_attn_h3_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias, float* __restrict__ out,
+    int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale) {
+  constexpr int HD = 32, NP = NT * 16, PL = NP * 64;                         // bytes per f16 plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char k5h_lds[];
+  unsigned char* Kh = k5h_lds;                                                  // + PL: Kl; + 2 PL: Vh; + 3 PL: Vl
+  int* tok = reinterpret_cast<int*>(k5h_lds + 4 * PL);
+  int* rid = tok + NP;
+  const int N = ws * ws;
+  const int wx = blockIdx.x, wy = blockIdx.y;
+  const int h = blockIdx.z % nH, b = blockIdx.z / nH;
+  const int C = nH * HD;
+  const int64_t tok_stride = 3 * (int64_t)C;
+  const float* qkv_b = qkv + (int64_t)b * H * W * tok_stride;
+  const float* qb = qkv_bias + h * HD;
+
+  for (int i = threadIdx.x; i < NP * (HD / 4); i += 64 * WAVES) {
+    const int t = i >> 3, d4 = i & 7;
+    float4 kk4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kk4;
+    int tk = -2, rg = -1;
+    if (t < N) {
+      const int r = wy * ws + t / ws, c = wx * ws + t % ws;
+      int rr = r + shift, cc = c + shift;
+      rr = rr >= Hp ? rr - Hp : rr;
+      cc = cc >= Wp ? cc - Wp : cc;
+      if (rr < H && cc < W) {
+        tk = rr * W + cc;
+        const float* p = qkv_b + (int64_t)tk * tok_stride + h * HD + d4 * 4;
+        kk4 = *reinterpret_cast<const float4*>(p + C);
+        vv4 = *reinterpret_cast<const float4*>(p + 2 * C);
+      } else {
+        tk = -1;
+        kk4 = *reinterpret_cast<const float4*>(qb + C + d4 * 4);
+        vv4 = *reinterpret_cast<const float4*>(qb + 2 * C + d4 * 4);
+      }
+      const int hid = r < Hp - ws ? 0 : (r < Hp - shift ? 1 : 2);
+      const int wid = c < Wp - ws ? 0 : (c < Wp - shift ? 1 : 2);
+      rg = hid * 3 + wid;
+    }
+    uint32_t h0, l0, h1, l1;
+    const int tq = (t >> 2) & 3;
+    const int perm = (0x1320 >> (4 * tq)) & 3;                                  // P = {0, 2, 3, 1}
+    k5h_split2<false>(kk4.x, kk4.y, h0, l0);
+    k5h_split2<false>(kk4.z, kk4.w, h1, l1);
+    const int ko = t * 64 + (((d4 >> 1) ^ perm) * 16) + (d4 & 1) * 8;
+    *reinterpret_cast<uint2*>(Kh + ko) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(Kh + PL + ko) = make_uint2(l0, l1);
+    k5h_split2<true>(vv4.x, vv4.y, h0, l0);
+    k5h_split2<true>(vv4.z, vv4.w, h1, l1);
+    const int vo = t * 64 + (((d4 >> 2) ^ (tq & 1)) * 32) + (d4 & 3) * 8;
+    *reinterpret_cast<uint2*>(Kh + 2 * PL + vo) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(Kh + 3 * PL + vo) = make_uint2(l0, l1);
+    if (d4 == 0) { tok[t] = tk; rid[t] = rg; }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kk = lane >> 4;
+  const bool vec_bias = (N & 3) == 0;
+  // K fragment of key tile c: key c * 16 + l15, chunk kk -> byte offset (+ c * 1024)
+  const int kfrag = l15 * 64 + ((kk ^ ((0x1320 >> (4 * ((l15 >> 2) & 3))) & 3)) * 16);
+  // V transposing read of key tile c, d tile dt: rows c * 16 + 4 kk + (l15 >> 2) -> (+ c * 1024 + (dt ^ (kk & 1)) * 32)
+  const int vfrag = (4 * kk + (l15 >> 2)) * 64 + (l15 & 3) * 8;
+
+  for (int strip = wave; strip < NT; strip += WAVES) {
+    const int qt = strip * 16 + l15;
+    const int qtok = tok[qt];
+    k5h_f16x8 qh, ql;
+    {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c4 = a;
+      if (qtok >= 0) {
+        const float4* p = reinterpret_cast<const float4*>(qkv_b + (int64_t)qtok * tok_stride + h * HD + kk * 8);
+        a = p[0]; c4 = p[1];
+      } else if (qtok == -1) {
+        const float4* p = reinterpret_cast<const float4*>(qb + kk * 8);
+        a = p[0]; c4 = p[1];
+      }
+      k5h_u32x4 hq, lq;
+      uint32_t x0, x1;
+      k5h_split2<false>(a.x * scale, a.y * scale, x0, x1); hq[0] = x0; lq[0] = x1;
+      k5h_split2<false>(a.z * scale, a.w * scale, x0, x1); hq[1] = x0; lq[1] = x1;
+      k5h_split2<false>(c4.x * scale, c4.y * scale, x0, x1); hq[2] = x0; lq[2] = x1;
+      k5h_split2<false>(c4.z * scale, c4.w * scale, x0, x1); hq[3] = x0; lq[3] = x1;
+      qh = __builtin_bit_cast(k5h_f16x8, hq);
+      ql = __builtin_bit_cast(k5h_f16x8, lq);
+    }
+    // ---- S^T tiles: lane holds S[key = c*16 + 4*kk + r][query = qt]
+    f32x4_t S[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const k5h_f16x8 kh = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + c * 1024 + kfrag));
+      const k5h_f16x8 kl = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + PL + c * 1024 + kfrag));
+      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f};
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, a0, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, a0, 0, 0, 0);
+      S[c] = a0;
+    }
+    // ---- + relative-position bias, shift mask, padding keys; row max  (as in the fp32-MFMA kernel)
+    const int myrid = rid[qt];
+    const float* brow = bias + ((int64_t)h * N + (qt < N ? qt : 0)) * N;
+    const float4* bfrag = reinterpret_cast<const float4*>(bias) + (((int64_t)h * NT + strip) * NT) * 64 + lane;
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int k0i = c * 16 + kk * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (FRAG) {
+        const float4 t4 = bfrag[c * 64];
+        bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+      } else if (qt < N) {
+        if (vec_bias && k0i + 3 < N) {
+          const float4 t4 = *reinterpret_cast<const float4*>(brow + k0i);
+          bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (k0i + r < N) bv[r] = brow[k0i + r];
+        }
+      }
+      const int4 kr4 = *reinterpret_cast<const int4*>(rid + k0i);
+      const int krid[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = S[c][r] + bv[r];
+        if (shift > 0 && krid[r] != myrid) v += -100.0f;
+        if (k0i + r >= N) v = -INFINITY;
+        S[c][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, RBA_WAVE));
+    m = fmaxf(m, __shfl_xor(m, 32, RBA_WAVE));
+    float lsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(S[c][r] - m);
+        S[c][r] = p;
+        lsum += p;
+      }
+    lsum += __shfl_xor(lsum, 16, RBA_WAVE);
+    lsum += __shfl_xor(lsum, 32, RBA_WAVE);
+    // ---- O = P . V: 32 keys (two key tiles) per step, two 16-wide d tiles, main + low accumulators
+    f32x4_t Om[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, Ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c0 = 0; c0 < NT; c0 += 2) {
+      const bool two = c0 + 1 < NT;
+      const int c1 = two ? c0 + 1 : c0;                                       // odd NT: the missing tile's P is zero, its V rows are c0's
+      k5h_u32x4 ph, pl;
+      uint32_t x0, x1;
+      k5h_split2<true>(S[c0][0], S[c0][1], x0, x1); ph[0] = x0; pl[0] = x1;
+      k5h_split2<true>(S[c0][2], S[c0][3], x0, x1); ph[1] = x0; pl[1] = x1;
+      if (two) {
+        k5h_split2<true>(S[c1][0], S[c1][1], x0, x1); ph[2] = x0; pl[2] = x1;
+        k5h_split2<true>(S[c1][2], S[c1][3], x0, x1); ph[3] = x0; pl[3] = x1;
+      } else {
+        ph[2] = ph[3] = pl[2] = pl[3] = 0u;
+      }
+      const k5h_f16x8 pa = __builtin_bit_cast(k5h_f16x8, ph), pb = __builtin_bit_cast(k5h_f16x8, pl);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int half = (dt ^ (kk & 1)) * 32;
+        const unsigned char* v0 = Kh + 2 * PL + c0 * 1024 + vfrag + half;
+        const unsigned char* v1 = Kh + 2 * PL + c1 * 1024 + vfrag + half;
+        const k5h_h4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) k5h_h4*)(v0));
+        const k5h_h4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) k5h_h4*)(v1));
+        const k5h_h4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) k5h_h4*)(v0 + PL));
+        const k5h_h4 r3 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) k5h_h4*)(v1 + PL));
+        const uint2 u0 = __builtin_bit_cast(uint2, r0), u1 = __builtin_bit_cast(uint2, r1);
+        const uint2 u2 = __builtin_bit_cast(uint2, r2), u3 = __builtin_bit_cast(uint2, r3);
+        const k5h_f16x8 vh = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u0.x, u0.y, u1.x, u1.y});
+        const k5h_f16x8 vl = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u2.x, u2.y, u3.x, u3.y});
+        Om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vh, Om[dt], 0, 0, 0);
+        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vl, Ol[dt], 0, 0, 0);
+        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, vh, Ol[dt], 0, 0, 0);
+      }
+    }
+    // ---- scatter: lane holds O[query = strip*16 + 4*kk + r][d = l15 (+16)]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qi = kk * 4 + r;
+      const float inv = 1.0f / __shfl(lsum, qi, RBA_WAVE);
+      const int t = tok[strip * 16 + qi];
+      if (t >= 0) {
+        float* o = out + ((int64_t)b * H * W + t) * C + h * HD + l15;
+        o[0] = fmaf(Ol[0][r], 0.00048828125f, Om[0][r]) * inv;
+        o[16] = fmaf(Ol[1][r], 0.00048828125f, Om[1][r]) * inv;
+      }
+    }
+  }
+}
+
+template <int NT, int WAVES>
+int launch_h3(const float* qkv, const float* qkv_bias, const float* bias, const float* bias_frag, float* out, int B, int H, int W,
+              int Hp, int Wp, int nH, int ws, int shift, float scale, hipStream_t st) {
+  const size_t shm = (size_t)(4 * NT * 16 * 64) + (size_t)(2 * NT * 16) * sizeof(int);
+  const dim3 grid(Wp / ws, Hp / ws, B * nH), block(64 * WAVES);
+  if (bias_frag)
+    hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, true>), grid, block, shm, st, qkv, qkv_bias, bias_frag, out, H, W, Hp, Wp,
+                       nH, ws, shift, scale);
+  else
+    hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, false>), grid, block, shm, st, qkv, qkv_bias, bias, out, H, W, Hp, Wp, nH,
+                       ws, shift, scale);
+  return rba_launch_status();
+}
+
+}  // namespace
