@@ -121,44 +121,51 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       qh = __builtin_bit_cast(k5h_f16x8, hq);
       ql = __builtin_bit_cast(k5h_f16x8, lq);
     }
-    // ---- S^T tiles: lane holds S[key = c*16 + 4*kk + r][query = qt]
+    // ---- S^T tiles: lane holds S[key = c*16 + 4*kk + r][query = qt].  The relative-position bias is the INITIAL value of the
+    // accumulator: its loads are issued ahead of the MFMAs that consume them instead of in front of the softmax that waits for them.
+    const float* brow = bias + ((int64_t)h * N + (qt < N ? qt : 0)) * N;
+    // FRAG: bias pre-permuted to [nH][strip][c][lane][4] (rba_swin_bias_fragments_f32): 1 KiB coalesced per load
+    const float4* bfrag = reinterpret_cast<const float4*>(bias) + (((int64_t)h * NT + strip) * NT) * 64 + lane;
     f32x4_t S[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const int k0i = c * 16 + kk * 4;
+      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f};
+      if (FRAG) {
+        const float4 t4 = bfrag[c * 64];
+        a0 = (f32x4_t){t4.x, t4.y, t4.z, t4.w};
+      } else if (qt < N) {
+        if (vec_bias && k0i + 3 < N) {
+          const float4 t4 = *reinterpret_cast<const float4*>(brow + k0i);
+          a0 = (f32x4_t){t4.x, t4.y, t4.z, t4.w};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (k0i + r < N) a0[r] = brow[k0i + r];
+        }
+      }
+      S[c] = a0;
+    }
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
       const k5h_f16x8 kh = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + c * 1024 + kfrag));
       const k5h_f16x8 kl = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + PL + c * 1024 + kfrag));
-      f32x4_t a0 = {0.f, 0.f, 0.f, 0.f};
+      f32x4_t a0 = S[c];
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, a0, 0, 0, 0);
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, a0, 0, 0, 0);
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, a0, 0, 0, 0);
       S[c] = a0;
     }
-    // ---- + relative-position bias, shift mask, padding keys; row max  (as in the fp32-MFMA kernel)
+    // ---- shift mask, padding keys; row max
     const int myrid = rid[qt];
-    const float* brow = bias + ((int64_t)h * N + (qt < N ? qt : 0)) * N;
-    const float4* bfrag = reinterpret_cast<const float4*>(bias) + (((int64_t)h * NT + strip) * NT) * 64 + lane;
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
       const int k0i = c * 16 + kk * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (FRAG) {
-        const float4 t4 = bfrag[c * 64];
-        bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
-      } else if (qt < N) {
-        if (vec_bias && k0i + 3 < N) {
-          const float4 t4 = *reinterpret_cast<const float4*>(brow + k0i);
-          bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (k0i + r < N) bv[r] = brow[k0i + r];
-        }
-      }
       const int4 kr4 = *reinterpret_cast<const int4*>(rid + k0i);
       const int krid[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = S[c][r] + bv[r];
+        float v = S[c][r];
         if (shift > 0 && krid[r] != myrid) v += -100.0f;
         if (k0i + r >= N) v = -INFINITY;
         S[c][r] = v;
