@@ -178,6 +178,13 @@ int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float*
 int rba_conv3x3_nhwc_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W, int C,
                                int N, void* stream);
 
+/* Front end of the Swin path in one pass: (image - mean) / std, ImageList zero padding to Hp x Wp, and the im2col of PatchEmbed's
+ * 4x4 / stride-4 convolution (maskformer_model.py:255-257, backbone/swin.py:479-495): image [3,h,w] (device; uint8 or fp32) ->
+ * out [(Hp/4)*(Wp/4), 64] fp32 with out[token][c*16 + ky*4 + kx] and columns 48..63 zero; mean / std: 3 host floats each.
+ * Followed by rba_split_linear_f16x3_f32 with the [E, 64] zero-padded projection weight and by rba_add_layer_norm_f32. */
+int rba_patch_im2col_u8(const uint8_t* image, float* out, int h, int w, int Hp, int Wp, const float* mean, const float* std, void* stream);
+int rba_patch_im2col_f32(const float* image, float* out, int h, int w, int Hp, int Wp, const float* mean, const float* std, void* stream);
+
 /* Gaussian smoothing of the score map (the evaluator's optional transforms.GaussianBlur(7, sigma=1), support.py:366-383):
  * out[H,W] = correlation of in[H,W] (reflect-padded by kernel_size/2) with the normalised outer-product kernel of
  * exp(-0.5 (x/sigma)^2), x = -(k-1)/2 .. (k-1)/2.  kernel_size odd, <= 15; in != out. */

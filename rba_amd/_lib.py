@@ -36,6 +36,8 @@ SIGNATURES = {
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f16x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_patch_im2col_u8": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "rba_patch_im2col_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "rba_group_norm_nhwc_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
     "rba_resample_bilinear_nhwc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -50,7 +52,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 171        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 172        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -29,6 +29,9 @@ class MaskFormer(nn.Module):
         self.size_divisibility = a["size_divisibility"] if a["size_divisibility"] > 0 else self.backbone.size_divisibility
         self.register_buffer("pixel_mean", torch.tensor(a["pixel_mean"], dtype=torch.float32).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(a["pixel_std"], dtype=torch.float32).view(-1, 1, 1), False)
+        self._mean3 = tuple(float(torch.tensor(v, dtype=torch.float32)) for v in a["pixel_mean"])      # fp32-rounded, as the buffers hold them
+        self._std3 = tuple(float(torch.tensor(v, dtype=torch.float32)) for v in a["pixel_std"])
+        self.fused_front_end = True
         self.fused_upsample = True      # K1 reads the low-res logits and up-samples on the fly (rba_reduce_up4)
         # panoptic inference (maskformer_model.py:202-220): off unless TEST.PANOPTIC_ON
         self.panoptic_on, self.open_panoptic = bool(a["panoptic_on"]), bool(a["open_panoptic"])
@@ -56,6 +59,18 @@ class MaskFormer(nn.Module):
     # ------------------------------------------------------------------ network
     @torch.no_grad()
     def _predict_outputs(self, batched_inputs):
+        pe = getattr(self.backbone, "patch_embed", None)
+        if (self.fused_front_end and pe is not None and hasattr(self.backbone, "forward_images") and pe.fused_ok()
+                and all(x["image"].dim() == 3 and x["image"].shape[0] == 3 and x["image"].dtype in (torch.uint8, torch.float32)
+                        for x in batched_inputs)):
+            # normalisation + ImageList padding + patch im2col in one kernel, the projection on K6 (backbone/swin.py PatchEmbed.forward_images)
+            images = [x["image"].to(self.device).contiguous() for x in batched_inputs]
+            sizes = [tuple(int(v) for v in im.shape[-2:]) for im in images]
+            d = self.size_divisibility
+            H = (max(s[0] for s in sizes) + d - 1) // d * d
+            W = (max(s[1] for s in sizes) + d - 1) // d * d
+            features = self.backbone.forward_images(images, self._mean3, self._std3, H, W)
+            return self.sem_seg_head(features), sizes, (H, W)
         batch, sizes = self.preprocess(batched_inputs)
         features = self.backbone(batch)
         return self.sem_seg_head(features), sizes, tuple(batch.shape[-2:])

@@ -124,6 +124,27 @@ class PatchEmbed(nn.Module):
         x = x.flatten(2).transpose(1, 2).contiguous()
         return ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)[1], Wh, Ww
 
+    def fused_ok(self):
+        w = self.proj.weight
+        return self.patch_size == 4 and w.shape[1] == 3 and w.is_cuda and w.dtype == torch.float32 and ops.SPLIT_MODE == "f16x3"
+
+    def forward_images(self, images, mean, std, Hp, Wp):
+        """Raw images [3,h_i,w_i] (uint8 / fp32) -> tokens [B, (Hp/4)*(Wp/4), C]: normalisation, ImageList zero padding and the im2col of the
+        4x4 convolution in ONE kernel (ops.patch_im2col), the projection as an f16x3 GEMM over K = 48 (+16 zero columns), then the
+        LayerNorm -- instead of five elementwise passes, a library convolution and a 67 MB NCHW -> token-major copy."""
+        w = self.proj.weight
+        key = (w.data_ptr(), w._version, w.device)
+        cache = getattr(self, "_rba_planes", None)
+        if cache is None or cache[0] != key:
+            w64 = torch.zeros((w.shape[0], 64), dtype=torch.float32, device=w.device)
+            w64[:, :48] = w.detach().reshape(w.shape[0], 48)
+            cache = (key, ops.split_weight(w64, mode="f16x3"))
+            self._rba_planes = cache
+        cols = torch.stack([ops.patch_im2col(im, mean, std, Hp, Wp) for im in images]) if len(images) > 1 \
+            else ops.patch_im2col(images[0], mean, std, Hp, Wp)[None]
+        x = ops.split_linear(cols, cache[1], self.proj.bias, out_features=w.shape[0])
+        return ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)[1], Hp // 4, Wp // 4
+
 
 @BACKBONE_REGISTRY.register()
 class D2SwinTransformer(nn.Module):
@@ -144,10 +165,16 @@ class D2SwinTransformer(nn.Module):
     def size_divisibility(self):
         return 32
 
+    def forward_images(self, images, mean, std, Hp, Wp):
+        """The same network from raw images (see PatchEmbed.forward_images); Hp, Wp = the padded size (multiples of 32)."""
+        return self._stages(*self.patch_embed.forward_images(images, mean, std, Hp, Wp))
+
     def forward(self, x):
         if x.dim() != 4:
             raise ValueError(f"SwinTransformer takes an input of shape (N, C, H, W). Got {tuple(x.shape)} instead!")
-        x, Wh, Ww = self.patch_embed(x)
+        return self._stages(*self.patch_embed(x))
+
+    def _stages(self, x, Wh, Ww):
         outs = {}
         for i, layer in enumerate(self.layers):
             pending = None

@@ -503,6 +503,27 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
 
 
 @_hip_op
+def patch_im2col(image, mean, std, Hp, Wp):
+    """image [3,h,w] (uint8 or fp32) -> [(Hp/4)*(Wp/4), 64] fp32: (image - mean) / std, zero padding to Hp x Wp (ImageList semantics:
+    the padding is zero AFTER normalisation) and the im2col of the 4x4 / stride-4 patch convolution in one pass; column
+    c*16 + ky*4 + kx, columns 48..63 zero.  `mean`, `std`: three python floats each."""
+    import ctypes
+    lib = _lib.load()
+    if image.dtype not in (torch.uint8, torch.float32):
+        raise RbaHipError("image must be uint8 or float32")
+    _chk(image, "image", dtype=image.dtype, dim=3)
+    if image.shape[0] != 3 or Hp % 4 or Wp % 4 or Hp < image.shape[1] or Wp < image.shape[2] or len(mean) != 3 or len(std) != 3:
+        raise RbaHipError("patch_im2col needs a [3,h,w] image and Hp >= h, Wp >= w multiples of 4")
+    h, w = int(image.shape[1]), int(image.shape[2])
+    out = torch.empty(((Hp // 4) * (Wp // 4), 64), dtype=torch.float32, device=image.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    fn, name = ((lib.rba_patch_im2col_u8, "rba_patch_im2col_u8") if image.dtype == torch.uint8 else (lib.rba_patch_im2col_f32, "rba_patch_im2col_f32"))
+    _lib.check(fn(_p(image), _p(out), h, w, int(Hp), int(Wp), ctypes.addressof(m), ctypes.addressof(sd), _stream()), name)
+    return out
+
+
+@_hip_op
 def group_norm_nhwc(x, num_groups, weight, bias, eps=1e-5, relu=False):
     """GroupNorm (+ReLU) of channels-last x [B, P, C] (or [B, H, W, C]): the same operator as group_norm on the token layout."""
     lib = _lib.load()

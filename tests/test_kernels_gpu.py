@@ -655,3 +655,24 @@ def test_resample_bilinear_align_corners(ops, C, h, w, H, W):
     ref = F.interpolate(x[None].double(), size=(H, W), mode="bilinear", align_corners=True)[0]
     out = ops.resample_bilinear_ac(dev(x), (H, W))
     assert out.shape == (C, H, W) and maxerr(out, ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------------- fused front end (normalise + pad + patch im2col)
+@pytest.mark.parametrize("h,w,Hp,Wp,dtype", [(37, 50, 64, 64, torch.uint8), (64, 96, 64, 96, torch.uint8), (5, 9, 32, 32, torch.float32),
+                                             (1024, 2048, 1024, 2048, torch.uint8)])
+def test_patch_im2col(ops, h, w, Hp, Wp, dtype):
+    """(image - mean) / std, zero padding AFTER normalisation (ImageList) and the im2col of the 4x4 / stride-4 convolution, against
+    torch's elementwise ops + F.pad + F.unfold: bit-identical."""
+    g = torch.Generator().manual_seed(h * w)
+    img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    if dtype == torch.float32:
+        img = img.float() + torch.rand(3, h, w, generator=g)
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    m32 = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
+    s32 = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+    ref = F.pad((img.float() - m32) / s32, (0, Wp - w, 0, Hp - h))
+    ref = F.unfold(ref[None], kernel_size=4, stride=4)[0].t()                  # [tokens, 48], column c*16 + ky*4 + kx
+    out = ops.patch_im2col(dev(img), [float(v) for v in m32.flatten()], [float(v) for v in s32.flatten()], Hp, Wp)
+    assert out.shape == ((Hp // 4) * (Wp // 4), 64)
+    assert torch.equal(out[:, :48].cpu(), ref) and not out[:, 48:].any()
+

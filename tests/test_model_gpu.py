@@ -492,3 +492,20 @@ def test_evaluate_ood_graph_replay_equals_eager(tmp_path, arch_name, score_funcs
             for k in res["0"][d]:
                 assert abs(res["0"][d][k] - res["1"][d][k]) < 1e-12, (sf, d, k, res["0"][d][k], res["1"][d][k])
 
+
+@pytest.mark.parametrize("name,h,w", [("tiny1", 60, 90), ("swin_b_1dl", 250, 510)])
+def test_fused_front_end_matches_library_path(name, h, w):
+    """MaskFormer.fused_front_end (normalise + pad + im2col kernel, patch projection on K6) against the elementwise / F.conv2d path:
+    same tokens to fp32 rounding, same scores well inside the tolerance; uint8 and fp32 images, ragged sizes."""
+    model, a, _ = build(name, 0)
+    g = torch.Generator().manual_seed(h + w)
+    for image in (torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8), torch.rand(3, h, w, generator=g) * 255):
+        image = image.cuda()
+        assert model.fused_front_end
+        r1 = model.rba_scores([{"image": image}])[0].clone()
+        model.fused_front_end = False
+        r0 = model.rba_scores([{"image": image}])[0]
+        model.fused_front_end = True
+        assert r1.shape == r0.shape == (h, w)
+        assert (r1 - r0).abs().max().item() < 2e-5
+
