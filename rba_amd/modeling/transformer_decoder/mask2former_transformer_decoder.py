@@ -41,8 +41,10 @@ class _MHAParams(nn.Module):
         S = key.shape[1]
         w, b = self.in_proj_weight, self.in_proj_bias
         q = _qlinear(query, w[:E], b[:E]).view(B, Q, nH, E // nH)
-        k = F.linear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
-        v = F.linear(value, w[2 * E:], b[2 * E:]).view(B, S, nH, E // nH)
+        # self-attention: key / value are the (<= 128) queries themselves -> the skinny kernel too (hipBLASLt takes 33 us for
+        # 100 x 256 x 256); cross-attention: thousands of memory tokens -> library GEMM
+        k = _qlinear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
+        v = _qlinear(value, w[2 * E:], b[2 * E:]).view(B, S, nH, E // nH)
         o = ops.masked_xattn(q, k, v, mask_logits)
         return _qlinear(o, self.out_proj.weight)            # out_proj.bias is added inside the caller's fused add+LN
 
