@@ -51,43 +51,73 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
   const float* qkv_b = qkv + (int64_t)b * H * W * tok_stride;
   const float* qb = qkv_bias + h * HD;
 
-  for (int i = threadIdx.x; i < NP * (HD / 4); i += 64 * WAVES) {
+  // ---- gather K, V of the window's N tokens into the f16 planes.  All global loads of a thread are issued before the first is
+  // consumed (a rolled loop pays the memory latency once per trip), and the Q fragment of the wave's first strip is requested
+  // here too, so that it arrives under the gather instead of in front of the first MFMA.
+  constexpr int NIT = (NP * (HD / 4) + 64 * WAVES - 1) / (64 * WAVES);
+  float4 kk4[NIT], vv4[NIT];
+  int tkv[NIT], rgv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = threadIdx.x + it * 64 * WAVES;
     const int t = i >> 3, d4 = i & 7;
-    float4 kk4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kk4;
-    int tk = -2, rg = -1;
-    if (t < N) {
+    kk4[it] = vv4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    tkv[it] = -2;
+    rgv[it] = -1;
+    if (i < NP * (HD / 4) && t < N) {
       const int r = wy * ws + t / ws, c = wx * ws + t % ws;
       int rr = r + shift, cc = c + shift;
       rr = rr >= Hp ? rr - Hp : rr;
       cc = cc >= Wp ? cc - Wp : cc;
       if (rr < H && cc < W) {
-        tk = rr * W + cc;
-        const float* p = qkv_b + (int64_t)tk * tok_stride + h * HD + d4 * 4;
-        kk4 = *reinterpret_cast<const float4*>(p + C);
-        vv4 = *reinterpret_cast<const float4*>(p + 2 * C);
+        tkv[it] = rr * W + cc;
+        const float* p = qkv_b + (int64_t)tkv[it] * tok_stride + h * HD + d4 * 4;
+        kk4[it] = *reinterpret_cast<const float4*>(p + C);
+        vv4[it] = *reinterpret_cast<const float4*>(p + 2 * C);
       } else {
-        tk = -1;
-        kk4 = *reinterpret_cast<const float4*>(qb + C + d4 * 4);
-        vv4 = *reinterpret_cast<const float4*>(qb + 2 * C + d4 * 4);
+        tkv[it] = -1;
+        kk4[it] = *reinterpret_cast<const float4*>(qb + C + d4 * 4);
+        vv4[it] = *reinterpret_cast<const float4*>(qb + 2 * C + d4 * 4);
       }
       const int hid = r < Hp - ws ? 0 : (r < Hp - shift ? 1 : 2);
       const int wid = c < Wp - ws ? 0 : (c < Wp - shift ? 1 : 2);
-      rg = hid * 3 + wid;
+      rgv[it] = hid * 3 + wid;
     }
+  }
+  // Q rows of this wave's first strip (token index by the same arithmetic as above: tok[] is not written yet)
+  float4 q_a = make_float4(0.f, 0.f, 0.f, 0.f), q_b = q_a;
+  {
+    const int qt0 = (threadIdx.x >> 6) * 16 + (threadIdx.x & 15), kq = (threadIdx.x & 63) >> 4;
+    if ((threadIdx.x >> 6) < NT && qt0 < N) {
+      const int r = wy * ws + qt0 / ws, c = wx * ws + qt0 % ws;
+      int rr = r + shift, cc = c + shift;
+      rr = rr >= Hp ? rr - Hp : rr;
+      cc = cc >= Wp ? cc - Wp : cc;
+      const float4* p = (rr < H && cc < W) ? reinterpret_cast<const float4*>(qkv_b + (int64_t)(rr * W + cc) * tok_stride + h * HD + kq * 8)
+                                           : reinterpret_cast<const float4*>(qb + kq * 8);
+      q_a = p[0];
+      q_b = p[1];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = threadIdx.x + it * 64 * WAVES;
+    if (i >= NP * (HD / 4)) break;
+    const int t = i >> 3, d4 = i & 7;
     uint32_t h0, l0, h1, l1;
     const int tq = (t >> 2) & 3;
     const int perm = (0x1320 >> (4 * tq)) & 3;                                  // P = {0, 2, 3, 1}
-    k5h_split2<false>(kk4.x, kk4.y, h0, l0);
-    k5h_split2<false>(kk4.z, kk4.w, h1, l1);
+    k5h_split2<false>(kk4[it].x, kk4[it].y, h0, l0);
+    k5h_split2<false>(kk4[it].z, kk4[it].w, h1, l1);
     const int ko = t * 64 + (((d4 >> 1) ^ perm) * 16) + (d4 & 1) * 8;
     *reinterpret_cast<uint2*>(Kh + ko) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(Kh + PL + ko) = make_uint2(l0, l1);
-    k5h_split2<true>(vv4.x, vv4.y, h0, l0);
-    k5h_split2<true>(vv4.z, vv4.w, h1, l1);
+    k5h_split2<true>(vv4[it].x, vv4[it].y, h0, l0);
+    k5h_split2<true>(vv4[it].z, vv4[it].w, h1, l1);
     const int vo = t * 64 + (((d4 >> 2) ^ (tq & 1)) * 32) + (d4 & 3) * 8;
     *reinterpret_cast<uint2*>(Kh + 2 * PL + vo) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(Kh + 3 * PL + vo) = make_uint2(l0, l1);
-    if (d4 == 0) { tok[t] = tk; rid[t] = rg; }
+    if (d4 == 0) { tok[t] = tkv[it]; rid[t] = rgv[it]; }
   }
   __syncthreads();
 
@@ -104,13 +134,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
     const int qtok = tok[qt];
     k5h_f16x8 qh, ql;
     {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c4 = a;
-      if (qtok >= 0) {
-        const float4* p = reinterpret_cast<const float4*>(qkv_b + (int64_t)qtok * tok_stride + h * HD + kk * 8);
-        a = p[0]; c4 = p[1];
-      } else if (qtok == -1) {
-        const float4* p = reinterpret_cast<const float4*>(qb + kk * 8);
-        a = p[0]; c4 = p[1];
+      float4 a = q_a, c4 = q_b;                                                  // first strip: requested before the gather
+      if (strip != wave) {
+        a = c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qtok >= 0) {
+          const float4* p = reinterpret_cast<const float4*>(qkv_b + (int64_t)qtok * tok_stride + h * HD + kk * 8);
+          a = p[0]; c4 = p[1];
+        } else if (qtok == -1) {
+          const float4* p = reinterpret_cast<const float4*>(qb + kk * 8);
+          a = p[0]; c4 = p[1];
+        }
       }
       k5h_u32x4 hq, lq;
       uint32_t x0, x1;
