@@ -161,6 +161,11 @@ int rba_split_linear_f32(const float* x, const void* weight_packed, const float*
 int rba_split_weight_f16x2(const float* weight, void* packed, int N, int K, void* stream);
 int rba_split_linear_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
                                int act, void* stream);
+/* out = (residual + x W^T) + bias, no activation: the `x = x + proj(...)` / `x = x + fc2(...)` of a transformer block folded into the
+ * GEMM epilogue (backbone/swin.py:284-293), in the order of operations of rba_add_layer_norm_f32's own add (bit-identical to it).
+ * residual [M,N]; `out` may be `residual` itself. */
+int rba_split_linear_f16x3_res_f32(const float* x, const void* weight_packed, const float* bias, const float* residual, float* out,
+                                   int64_t M, int N, int K, void* stream);
 
 /* The same GEMM with NHWC rows in and NCHW out: out[(b*N + n)*P + p] = sum_k x[b*P + p, k] * weight[n, k] + bias[n],
  * P = rows_per_image, M % P == 0 (the mask-feature 1x1 convolution of pixel_decoder/msdeformattn.py:298-306). */

@@ -79,3 +79,23 @@ extern "C" int rba_conv3x3_nhwc_f16x3_f32(const float* x, const void* weight_pac
   if (rc) return rc;
   return rba_launch_status();
 }
+
+// out = (residual + x W^T) + bias: the residual add of a transformer block (`x = x + proj(attn)`, `x = x + fc2(h)`: backbone/swin.py:284-293)
+// folded into the GEMM epilogue; `out` may alias `residual`.
+extern "C" int rba_split_linear_f16x3_res_f32(const float* x, const void* weight_packed, const float* bias, const float* residual, float* out,
+                                              int64_t M, int N, int K, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && residual && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out | (uintptr_t)residual) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const bool wide = tiles128 >= 160 || N <= 64;
+  int rc;
+  if (K <= 256) rc = wide ? launch_h3l_res<4>(x, wp, bias, residual, out, M, N, K, st) : launch_h3l_res<2>(x, wp, bias, residual, out, M, N, K, st);
+  else rc = wide ? launch_h3p_res(x, wp, bias, residual, out, M, N, K, st) : launch_h3_res<2>(x, wp, bias, residual, out, M, N, K, st);
+  if (rc) return rc;
+  return rba_launch_status();
+}

@@ -92,14 +92,68 @@ __global__ void split_weight_f16x2_kernel(const float* __restrict__ w, u32x4_t* 
   }
 }
 
+// Epilogue shared by the three kernels: lane holds D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] of each 32 x 32 tile of
+// its wave's 32 rows; value = main + 2^-11 low.  RES: out = (residual + value) + bias -- the `x = x + proj(...)` / `x = x + fc2(...)`
+// of a transformer block folded into the GEMM, in the fused add + LayerNorm kernel's own order of operations (bit-identical to it),
+// `out` may be the residual tensor itself (every element is read and written by the same lane).
+template <int ACT, int CT, int PROBE, bool RES>
+__device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f32x16_t (&accl)[CT], const float* __restrict__ bias,
+                                            float* C, const float* R, int M, int N, int m0, int n0, int BM, int BN, int wave, int l31,
+                                            int lh) {
+  const bool interior = m0 + BM <= M && n0 + BN <= N;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = n0 + 32 * j + l31;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+    const int rbase = m0 + 32 * wave + 4 * lh;
+    float* dst = C + (int64_t)rbase * N + col;
+    f32x16_t res;
+    if (RES) {
+      const float* src = R + (int64_t)rbase * N + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = 8 * (r >> 2) + (r & 3);
+        res[r] = (interior || (col < N && rbase + ro < M)) ? src[(int64_t)ro * N] : 0.f;
+      }
+    }
+    f32x16_t v;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]};
+      if (RES) y = (f32x2){res[r], res[r + 1]} + y;
+      y = y + bv;
+      if (ACT == 1) y = gelu_erf2(y);
+      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+      v[r] = y.x;
+      v[r + 1] = y.y;
+    }
+    if (PROBE & 4) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += v[r];
+      if (sum == 1234.5f) dst[0] = sum;
+    } else if (interior) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
+    } else if (col < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = 8 * (r >> 2) + (r & 3);
+        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
+      }
+    }
+  }
+}
+
 // ACT: 0 none, 1 exact GELU, 2 ReLU.  CT: 32-column MFMA tiles per wave = tile width / 32 (BN = 32 CT; 128 must be a multiple).
 // Tile 128 x BN, four waves, wave w owns rows 32 w .. 32 w + 31 x all BN columns; two workgroups per CU (256 registers a wave).
 // PROBE (tune builds only, results wrong): bit 0 no weight loads in the loop, bit 1 no activation loads in the loop, bit 2 no epilogue,
 // bit 3 weight fragments read once, bit 4 no activation split, bit 5 no weight ds_write in the loop, bit 6 no barrier in the loop
-template <int ACT, int CT, int PROBE = 0, bool TIMING = false>
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool RES = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
-                                                                const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                                int K, int MT, int NT, unsigned long long* dbg = nullptr) {
+                                                                const float* __restrict__ bias, float* C, int M, int N,
+                                                                int K, int MT, int NT, unsigned long long* dbg = nullptr,
+                                                                const float* R = nullptr) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int BM = 128, BN = 32 * CT;
@@ -219,38 +273,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __
 
   // ---- epilogue: lane holds D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] of each 32 x 32 tile
   if (TIMING) tm[2] = wall_clock64();
-  const bool interior = m0 + BM <= M && n0 + BN <= N;
-#pragma unroll
-  for (int j = 0; j < CT; ++j) {
-    const int col = n0 + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-    f32x16_t v;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]} + bv;
-      if (ACT == 1) y = gelu_erf2(y);
-      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
-      v[r] = y.x;
-      v[r + 1] = y.y;
-    }
-    const int rbase = m0 + 32 * wave + 4 * lh;
-    float* dst = C + (int64_t)rbase * N + col;
-    if (PROBE & 4) {
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += v[r];
-      if (sum == 1234.5f) dst[0] = sum;
-    } else if (interior) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
-    } else if (col < N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = 8 * (r >> 2) + (r & 3);
-        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
-      }
-    }
-  }
+  h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
     unsigned xcc;
@@ -278,11 +301,11 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __
 struct ConvShape {
   int H, W, Cin;
 };
-template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false>
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
-                                                                 const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                                 const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
-                                                                 ConvShape cs = ConvShape{0, 0, 0}) {
+                                                                 ConvShape cs = ConvShape{0, 0, 0}, const float* R = nullptr) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int BM = 128, BN = 32 * CT;
@@ -413,38 +436,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   }
 
   if (TIMING) tm[2] = wall_clock64();
-  const bool interior = m0 + BM <= M && n0 + BN <= N;
-#pragma unroll
-  for (int j = 0; j < CT; ++j) {
-    const int col = n0 + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-    f32x16_t v;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]} + bv;
-      if (ACT == 1) y = gelu_erf2(y);
-      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
-      v[r] = y.x;
-      v[r + 1] = y.y;
-    }
-    const int rbase = m0 + 32 * wave + 4 * lh;
-    float* dst = C + (int64_t)rbase * N + col;
-    if (PROBE & 4) {
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += v[r];
-      if (sum == 1234.5f) dst[0] = sum;
-    } else if (interior) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
-    } else if (col < N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = 8 * (r >> 2) + (r & 3);
-        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
-      }
-    }
-  }
+  h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
@@ -463,10 +455,11 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 // tile 3 computes.  The interleaving is pinned with __builtin_amdgcn_sched_group_barrier (MFMA, DS read, 4 VALU, ...): left to
 // itself the compiler re-serialises reads and MFMAs (83 us instead of 69 us on Swin stage-3 fc1).  Register budget: 128
 // accumulators + 2 x 16 weight fragments + 2 x 16 activation operands + 16 raw activations + 16 weight staging.
-template <int ACT, int PROBE = 0, bool TIMING = false>
+template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
-                                                                 const float* __restrict__ bias, float* __restrict__ C, int M, int N,
-                                                                 int K, int MT, int NT, unsigned long long* dbg = nullptr) {
+                                                                 const float* __restrict__ bias, float* C, int M, int N,
+                                                                 int K, int MT, int NT, unsigned long long* dbg = nullptr,
+                                                                 const float* R = nullptr) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int CT = 4, BM = 128, BN = 128;
@@ -606,38 +599,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
 #undef RBA_MFMA6
 
   if (TIMING) tm[2] = wall_clock64();
-  const bool interior = m0 + BM <= M && n0 + BN <= N;
-#pragma unroll
-  for (int j = 0; j < CT; ++j) {
-    const int col = n0 + 32 * j + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
-    f32x16_t v;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 y = (f32x2){accl[j][r], accl[j][r + 1]} * 0.00048828125f + (f32x2){accm[j][r], accm[j][r + 1]} + bv;
-      if (ACT == 1) y = gelu_erf2(y);
-      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
-      v[r] = y.x;
-      v[r + 1] = y.y;
-    }
-    const int rbase = m0 + 32 * wave + 4 * lh;
-    float* dst = C + (int64_t)rbase * N + col;
-    if (PROBE & 4) {
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += v[r];
-      if (sum == 1234.5f) dst[0] = sum;
-    } else if (interior) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(int64_t)(8 * (r >> 2) + (r & 3)) * N] = v[r];
-    } else if (col < N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = 8 * (r >> 2) + (r & 3);
-        if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
-      }
-    }
-  }
+  h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
@@ -706,6 +668,35 @@ int launch_h3_act(int act, const float* x, const u32x4_t* wp, const float* bias,
   if (act == 1) return launch_h3<1, CT>(x, wp, bias, out, M, N, K, st);
   if (act == 2) return launch_h3<2, CT>(x, wp, bias, out, M, N, K, st);
   return launch_h3<0, CT>(x, wp, bias, out, M, N, K, st);
+}
+
+// out = (residual + x W^T) + bias  (no activation): the residual forms of the three kernels
+template <int CT>
+int launch_h3_res(const float* x, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K, hipStream_t st) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3_kernel<0, CT, 0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M, N, K,
+                     (int)MT, NT, nullptr, res);
+  return 0;
+}
+template <int CT>
+int launch_h3l_res(const float* x, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K, hipStream_t st) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3l_kernel<0, CT, 0, false, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M,
+                     N, K, (int)MT, NT, nullptr, ConvShape{0, 0, 0}, res);
+  return 0;
+}
+inline int launch_h3p_res(const float* x, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K,
+                          hipStream_t st) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 127) / 128;
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M, N, K,
+                     (int)MT, NT, nullptr, res);
+  return 0;
 }
 
 }  // namespace

@@ -73,6 +73,13 @@ class SwinTransformerBlock(nn.Module):
         bias, bias_frag = a.gathered_bias()
         y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size,
                                  bias_frag=bias_frag)
+        M, C = x.numel() // x.shape[-1], x.shape[-1]
+        if ops.linear_residual_fused(M, C, C):
+            # the residual adds ride in the GEMM epilogues (x is updated in place), the LayerNorms read one tensor and write one
+            x = ops.linear(y, a.proj, residual=x)
+            y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]
+            y = ops.linear(y, self.mlp.fc1, gelu=True)
+            return ops.linear(y, self.mlp.fc2, residual=x), None
         t = ops.linear(y, a.proj, use_bias=False)                        # proj bias rides in the fused add+LN
         x, y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, t, a.proj.bias, inplace_sum=True)
         y = ops.linear(y, self.mlp.fc1, gelu=True)                       # exact GELU in the GEMM epilogue

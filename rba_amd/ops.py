@@ -400,9 +400,10 @@ def split_linear_pays(M, N, K, gelu=False):
 
 
 @_hip_op
-def linear(x, lin, use_bias=True, gelu=False, relu=False):
-    """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the bf16x6
-    kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise."""
+def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None):
+    """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the split
+    kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise.
+    ``residual`` (f16x3 form only, see linear_residual_fused): returns ``(residual + x W^T) + bias`` written IN PLACE over `residual`."""
     _chk(x, "x") if x.is_contiguous() else _chk(x.contiguous(), "x")          # HIP fp32 tensors only: no CPU path here either
     w = lin.weight
     N, K = w.shape
@@ -414,13 +415,20 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False):
         if cache is None or cache[0] != key:
             cache = (key, split_weight(w.detach().contiguous()))
             lin._rba_planes = cache
-        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu, out_features=N, relu=relu)
+        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
+    if residual is not None:
+        raise RbaHipError("linear(residual=...) needs the fused f16x3 path: check linear_residual_fused(M, N, K) first")
     y = torch.nn.functional.linear(x, w, bias)
     return torch.nn.functional.gelu(y) if gelu else (torch.relu(y) if relu else y)
 
 
+def linear_residual_fused(M, N, K):
+    """True when linear(..., residual=r) runs as ONE kernel (the f16x3 GEMM with the residual add in its epilogue)."""
+    return SPLIT_MODE == "f16x3" and split_linear_pays(M, N, K)
+
+
 @_hip_op
-def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False):
+def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False, residual=None):
     """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 / f16 matrix pipe (the planes'
     dtype says which form they were packed for).
     ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
@@ -438,8 +446,15 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False
         _chk(bias, "bias", dim=1)
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
-    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
     act = 1 if gelu else (2 if relu else 0)
+    if residual is not None:                 # out = (residual + x W^T) + bias, in place over `residual` (f16x3 planes, no activation)
+        _chk(residual, "residual")
+        if not f16 or act or tuple(residual.shape) != tuple(x.shape[:-1]) + (N,):
+            raise RbaHipError("residual needs f16x3 planes, no activation and a [..., N] tensor")
+        _lib.check(lib.rba_split_linear_f16x3_res_f32(_p(x), _p(planes), _p(bias), _p(residual), _p(residual), M, N, K, _stream()),
+                   "rba_split_linear_f16x3_res_f32")
+        return residual
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
     if f16:
         _lib.check(lib.rba_split_linear_f16x3_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, act, _stream()), "rba_split_linear_f16x3_f32")
     else:

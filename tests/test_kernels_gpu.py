@@ -239,7 +239,8 @@ def test_k5_swin_block_golden(ops, golden):
         pending = None
         for blk in layer.blocks:
             x, pending = blk(x, H, W, pending)
-        x = x + pending[0] + pending[1]
+        if pending is not None:
+            x = x + pending[0] + pending[1]
         down = layer.downsample(x, H, W)
     assert maxerr(x, T(g["bl_out"])) < 2e-5
     assert maxerr(down, T(g["bl_down"])) < 2e-5
@@ -369,6 +370,22 @@ def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias, mode):
         assert maxerr(out, ref) < 2.0 * maxerr(fp32, ref) + 1e-6, "not worse than the fp32 GEMM it replaces"
     out3 = ops.split_linear(dev(x.view(1, M, K)), planes, dev(b) if has_bias else None, gelu=gelu, out_features=N)
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (3000, 1100, 544), (32768, 256, 256), (1000, 128, 128), (2048, 1024, 4096),
+                                   (130, 200, 96)])
+def test_split_linear_residual_epilogue(ops, M, N, K):
+    """linear(..., residual=r): (r + x W^T) + bias in the GEMM epilogue, in place over r -- bit-identical to the unfused
+    composition in the fused add + LayerNorm kernel's order ((r + t) + bias), on every kernel form (LDS-staged, pipelined, 64-column)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = dev(torch.randn(M, K, generator=g)), dev(torch.randn(N, K, generator=g) * K ** -0.5)
+    b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+    planes = ops.split_weight(w, mode="f16x3")
+    t = ops.split_linear(x, planes, None, out_features=N)
+    want = (r + t) + b
+    r2 = r.clone()
+    out = ops.split_linear(x, planes, b, out_features=N, residual=r2)
+    assert out.data_ptr() == r2.data_ptr() and torch.equal(out, want)
 
 
 def test_split_linear_relu_epilogue(ops):
