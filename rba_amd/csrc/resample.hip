@@ -22,8 +22,10 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) tx[r] = bilinear_tap(x0 + r < W ? x0 + r : W - 1, sw, w);
   const int c0 = blockIdx.z * CCHUNK;
-  const int c1 = c0 + CCHUNK < C ? c0 + CCHUNK : C;
-  for (int c = c0; c < c1; ++c) {
+  // one channel: 16 tap loads -> 4 outputs.  The body is unrolled over the CCHUNK channels of the block so that all their loads are in
+  // flight together (a rolled loop paid the memory latency once per channel); the map is written once and read once by the next
+  // kernel from a 839 MB tensor -> non-temporal stores.
+  auto one = [&](int c) {
     const float* r0 = in + ((int64_t)c * h + ty.i0) * w;
     const float* r1 = in + ((int64_t)c * h + ty.i1) * w;
     float v[4];
@@ -36,13 +38,23 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     const int64_t o = ((int64_t)c * H + y) * W + x0;
     if (VEC4) {
       f32x4 t = {v[0], v[1], v[2], v[3]};
-      if (ADD) t += *reinterpret_cast<const f32x4*>(add + o);
-      *reinterpret_cast<f32x4*>(out + o) = t;
+      if (ADD) {
+        t += *reinterpret_cast<const f32x4*>(add + o);
+        *reinterpret_cast<f32x4*>(out + o) = t;
+      } else {
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(out + o));
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (x0 + r < W) out[o + r] = ADD ? v[r] + add[o + r] : v[r];
     }
+  };
+  if (c0 + CCHUNK <= C) {
+#pragma unroll
+    for (int i = 0; i < CCHUNK; ++i) one(c0 + i);
+  } else {
+    for (int c = c0; c < C; ++c) one(c);
   }
 }
 
