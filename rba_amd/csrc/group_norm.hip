@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const float* __restr
   const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)b * P * C) + j;
   float sum = 0.f, sq = 0.f;
   if (pl < lanes)
+#pragma unroll 8
     for (int p = lo + pl; p < hi; p += lanes) {
       const float4 v = xp[(int64_t)p * C4];
       sum += (v.x + v.y) + (v.z + v.w);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const float* __restr
   const int lo = s * PIX_CHUNK, hi = lo + PIX_CHUNK < P ? lo + PIX_CHUNK : P;
   const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)b * P * C) + j;
   float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * P * C) + j;
+#pragma unroll 8
   for (int p = lo + pl; p < hi; p += lanes) {
     float4 v = xp[(int64_t)p * C4];
     v.x = fmaf(v.x, a0, b0); v.y = fmaf(v.y, a1, b1); v.z = fmaf(v.z, a2, b2); v.w = fmaf(v.w, a3, b3);
