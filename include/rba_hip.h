@@ -135,6 +135,11 @@ int rba_resample_bilinear_nhwc_f32(const float* in, const float* add, float* out
 int rba_add_layer_norm_f32(const float* x, const float* t, const float* t_bias, const float* gamma, const float* beta,
                            float* sum_out, float* y, int64_t rows, int C, float eps, void* stream);
 
+/* PatchMerging's 2x2 gather + LayerNorm in one pass (backbone/swin.py:311-337): x [B, H, W, Cin] token-major ->
+ * y [B * ceil(H/2) * ceil(W/2), 4*Cin] = LN(cat(x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2])), odd maps zero-padded. */
+int rba_merge_layer_norm_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int Cin, float eps,
+                             void* stream);
+
 /* Skinny linear layer: out[m,n] = act(sum_k x[m,k] * weight[n,k] + bias[n]), x [M,K] with M <= 128, weight [N,K]
  * (nn.Linear layout), bias [N] or NULL, relu != 0 applies max(.,0).  K % 32 == 0.  For the decoder's 100-query GEMMs
  * (mask2former_transformer_decoder.py:25-212). */

@@ -49,11 +49,12 @@ SIGNATURES = {
     "rba_morph3x3_u8": [_vp, _vp, _i, _i, _i, _vp],
     "rba_ccl4_roots_i32": [_vp, _vp, _i, _i, _vp],
     "rba_add_layer_norm_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_float, _vp],
+    "rba_merge_layer_norm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp],
     "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 173        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 174        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -13,17 +13,36 @@
 
 namespace {
 
-template <int G, int NV>
+// MERGE: the row is gathered, not contiguous -- PatchMerging's 2 x 2 neighbourhood (swin.py:311-337): output token (b, i, j) of the
+// half-resolution grid = [x(2i, 2j) | x(2i+1, 2j) | x(2i, 2j+1) | x(2i+1, 2j+1)] (C = 4 Cin channels; positions outside an odd-sized map
+// are zero, as the reference pads), read straight from the [B, H, W, Cin] token tensor: the concatenated tensor is never written.
+struct MergeGeom {
+  int H, W, Cin;           // source map; rows = B * ceil(H/2) * ceil(W/2), C = 4 Cin
+};
+
+template <int G, int NV, bool MERGE = false>
 __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, const float* __restrict__ t,
                                                              const float* __restrict__ tb, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* sum_out /* may alias x */,
-                                                             float* __restrict__ y, int64_t rows, int C, float eps) {
+                                                             float* __restrict__ y, int64_t rows, int C, float eps,
+                                                             MergeGeom mg = MergeGeom{0, 0, 0}) {
   constexpr int RPW = 64 / G;                              // rows per wave
   const int lane = threadIdx.x & 63, sub = lane % G, rsel = lane / G;
   const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + rsel;
   const bool rvalid = row < rows;
   const int64_t base = (rvalid ? row : 0) * C;
   const int nv4 = C >> 2;
+  int mi = 0, mj = 0;
+  int64_t mb = 0;                                          // MERGE: this row's (batch offset in tokens, i, j)
+  if (MERGE) {
+    const int H2 = (mg.H + 1) >> 1, W2 = (mg.W + 1) >> 1;
+    const int64_t r = rvalid ? row : 0;
+    const int64_t bimg = r / ((int64_t)H2 * W2);
+    const int rem = (int)(r - bimg * H2 * W2);
+    mi = rem / W2;
+    mj = rem - mi * W2;
+    mb = bimg * mg.H * mg.W;
+  }
   constexpr bool EARLY = NV <= 2;                          // hoisting costs 8 NV registers: measured faster for NV <= 2, slower above
   f32x4 v[NV], g4[EARLY ? NV : 1], b4[EARLY ? NV : 1];
   float sum = 0.f;
@@ -42,7 +61,13 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, con
     const int c4 = sub + j * G;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (c4 < nv4) {
-      a = *reinterpret_cast<const f32x4*>(x + base + 4 * c4);
+      if (MERGE) {
+        const int seg = (4 * c4) / mg.Cin, off = 4 * c4 - seg * mg.Cin;          // segment order (ee, oe, eo, oo): di = seg & 1, dj = seg >> 1
+        const int si = 2 * mi + (seg & 1), sj = 2 * mj + (seg >> 1);
+        if (si < mg.H && sj < mg.W) a = *reinterpret_cast<const f32x4*>(x + (mb + (int64_t)si * mg.W + sj) * mg.Cin + off);
+      } else {
+        a = *reinterpret_cast<const f32x4*>(x + base + 4 * c4);
+      }
       if (t) a += *reinterpret_cast<const f32x4*>(t + base + 4 * c4);
       if (tb) a += *reinterpret_cast<const f32x4*>(tb + 4 * c4);
       sum += (a.x + a.y) + (a.z + a.w);
@@ -88,7 +113,43 @@ int launch(const float* x, const float* t, const float* tb, const float* gamma, 
   return rba_launch_status();
 }
 
+template <int G, int NV>
+int launch_merge(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps, MergeGeom mg,
+                 hipStream_t st) {
+  const int64_t rpb = 4 * (64 / G);
+  const int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((add_layer_norm_kernel<G, NV, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, nullptr,
+                     y, rows, C, eps, mg);
+  return rba_launch_status();
+}
+
 }  // namespace
+
+// PatchMerging's gather + LayerNorm in one pass: x [B, H, W, Cin] (token-major) -> y [B * ceil(H/2) * ceil(W/2), 4 Cin] =
+// LN(cat(x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2])) with zero padding of odd maps (backbone/swin.py:311-337).  Cin % 4 == 0.
+extern "C" int rba_merge_layer_norm_f32(const float* x, const float* gamma, const float* beta, float* y, int B, int H, int W, int Cin,
+                                        float eps, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && Cin >= 4 && Cin % 4 == 0 && 4 * Cin <= 8192);
+  if (B == 0) return 0;
+  RBA_CHECK_ARG(x && gamma && beta && y);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) == 0);
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  const int C = 4 * Cin, nv4 = C / 4;
+  const int64_t rows = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  const MergeGeom mg{H, W, Cin};
+#define RBA_L(G, NV) return launch_merge<G, NV>(x, gamma, beta, y, rows, C, eps, mg, st)
+  if (nv4 <= 16) RBA_L(16, 1);
+  if (nv4 <= 32) RBA_L(32, 1);
+  if (nv4 <= 64) RBA_L(64, 1);
+  if (nv4 <= 128) RBA_L(64, 2);
+  if (nv4 <= 256) RBA_L(64, 4);
+  if (nv4 <= 512) RBA_L(64, 8);
+  if (nv4 <= 1024) RBA_L(64, 16);
+  RBA_L(64, 32);
+#undef RBA_L
+}
 
 extern "C" int rba_add_layer_norm_f32(const float* x, const float* t, const float* t_bias, const float* gamma, const float* beta,
                                       float* sum_out, float* y, int64_t rows, int C, float eps, void* stream) {

@@ -94,13 +94,7 @@ class PatchMerging(nn.Module):
 
     def forward(self, x, H, W):
         """2x2 gather in the order (ee, oe, eo, oo) -> LN -> Linear (swin.py:311-337)."""
-        B, L, C = x.shape
-        x = x.view(B, H, W, C)
-        if H % 2 or W % 2:
-            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
-        x = x.reshape(B, -1, 4 * C)
-        _, x = ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        x = ops.merge_layer_norm(x.contiguous(), H, W, self.norm.weight, self.norm.bias, self.norm.eps)
         return ops.linear(x, self.reduction)
 
 

@@ -319,6 +319,22 @@ def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None,
 
 
 @_hip_op
+def merge_layer_norm(x, H, W, weight, bias, eps=1e-5):
+    """PatchMerging's gather + LayerNorm: x [B, H*W, C] -> [B, ceil(H/2)*ceil(W/2), 4C] = LN over the 2x2 neighbourhoods in the order
+    (ee, oe, eo, oo), odd maps zero-padded -- the concatenated tensor is never materialised."""
+    lib = _lib.load()
+    _chk(x, "x", dim=3)
+    _chk(weight, "weight", dim=1)
+    _chk(bias, "bias", dim=1)
+    B, L, C = x.shape
+    if L != H * W or C % 4 or weight.numel() != 4 * C or bias.numel() != 4 * C:
+        raise RbaHipError("merge_layer_norm needs x [B, H*W, C] (C % 4 == 0) and a LayerNorm over 4C channels")
+    y = torch.empty((B, ((H + 1) // 2) * ((W + 1) // 2), 4 * C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_merge_layer_norm_f32(_p(x), _p(weight), _p(bias), _p(y), B, H, W, C, float(eps), _stream()), "rba_merge_layer_norm_f32")
+    return y
+
+
+@_hip_op
 def skinny_linear(x, weight, bias=None, relu=False):
     """F.linear(x, weight, bias) [+ ReLU] for x with at most 128 rows (the decoder's 100 queries): [..., K] -> [..., N]."""
     lib = _lib.load()

@@ -693,3 +693,20 @@ def test_patch_im2col(ops, h, w, Hp, Wp, dtype):
     assert out.shape == ((Hp // 4) * (Wp // 4), 64)
     assert torch.equal(out[:, :48].cpu(), ref) and not out[:, 48:].any()
 
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 8, 12, 32), (2, 7, 9, 64), (1, 64, 128, 512), (1, 256, 512, 128), (1, 5, 5, 16)])
+def test_merge_layer_norm(ops, B, H, W, C):
+    """PatchMerging's gather + LayerNorm in one kernel against pad + the four strided slices + cat + F.layer_norm (swin.py:311-337)"""
+    g = torch.Generator().manual_seed(B * H * W + C)
+    x = torch.randn(B, H * W, C, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(4 * C, generator=g), 0.1 * torch.randn(4 * C, generator=g)
+    xv = x.view(B, H, W, C)
+    if H % 2 or W % 2:
+        xv = F.pad(xv, (0, 0, 0, W % 2, 0, H % 2))
+    cat = torch.cat([xv[:, 0::2, 0::2], xv[:, 1::2, 0::2], xv[:, 0::2, 1::2], xv[:, 1::2, 1::2]], -1).reshape(B, -1, 4 * C)
+    ref = F.layer_norm(cat.double(), (4 * C,), gamma.double(), beta.double(), 1e-5)
+    out = ops.merge_layer_norm(dev(x), H, W, dev(gamma), dev(beta), 1e-5)
+    assert out.shape == ref.shape and maxerr(out, ref) < 5e-6
+    same = ops.add_layer_norm(dev(cat.contiguous()), dev(gamma), dev(beta), 1e-5)[1]
+    assert torch.equal(out, same), "same arithmetic as the LayerNorm kernel on the materialised concatenation"
+
