@@ -85,6 +85,12 @@ int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes
                                const float* sampling_loc, const float* attn_weight, float* out,
                                int N, int S, int M, int D, int L, int Lq, int P, void* stream);
 
+/* The sampling parameters of MSDeformAttn.forward in one pass (pixel_decoder/ops/modules/ms_deform_attn.py:95-115):
+ * raw [rows, M*L*P*2 | M*L*P] = the sampling_offsets and attention_weights Linears evaluated as one; reference_points [rows, L, 2];
+ * spatial_shapes [L,2] int64 (H, W) -> loc [rows, M, L, P, 2] = reference + offset / (W_l, H_l), attw [rows, M, L, P] = softmax over L*P. */
+int rba_msda_prepare_f32(const float* raw, const float* reference_points, const int64_t* spatial_shapes, float* loc, float* attw,
+                         int64_t rows, int M, int L, int P, void* stream);
+
 /* K3.  Masked multi-head cross attention core (projections are done by the caller):
  * q [B,Q,nH,hd] (already includes the in_proj bias, NOT yet scaled), k,v [B,S,nH,hd];
  * mask_logits [B,Q,S] or NULL: key s is blocked for query q (all heads) iff sigmoid(mask_logits) < 0.5,

@@ -22,6 +22,7 @@ SIGNATURES = {
     "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_msda_prepare_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_masked_xattn_workspace_bytes": [_i, _i, _i, _i],
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_mask_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],
@@ -54,7 +55,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 174        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 175        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

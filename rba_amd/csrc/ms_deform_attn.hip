@@ -74,7 +74,51 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
   else o[0] = acc[0];
 }
 
+// Sampling parameters of MSDeformAttn.forward in one pass (ms_deform_attn.py:95-115): raw = the output of the sampling_offsets and
+// attention_weights Linears evaluated as ONE Linear, [rows, M L P 2 | M L P]; loc = reference_points + offsets / (W_l, H_l);
+// attw = softmax over the L P logits of a head.  One thread per (row, head).  Replaces two GEMM launches, the softmax and six small
+// elementwise / copy kernels per encoder layer.
+__global__ __launch_bounds__(256) void msda_prepare_kernel(const float* __restrict__ raw, const float* __restrict__ ref,
+                                                           const int64_t* __restrict__ shapes, float* __restrict__ loc,
+                                                           float* __restrict__ attw, int64_t rows, int M, int L, int P) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * M) return;
+  const int64_t row = idx / M;
+  const int m = (int)(idx - row * M);
+  const int LP = L * P, stride = 3 * M * LP;
+  const float* off = raw + row * stride + (int64_t)m * LP * 2;
+  const float* lg = raw + row * stride + (int64_t)M * LP * 2 + (int64_t)m * LP;
+  float mx = -INFINITY;
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+  float sum = 0.f;
+  for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
+  float* lo = loc + idx * LP * 2;
+  float* wo = attw + idx * LP;
+  for (int l = 0; l < L; ++l) {
+    const float Wl = (float)shapes[2 * l + 1], Hl = (float)shapes[2 * l];
+    const float rx = ref[(row * L + l) * 2], ry = ref[(row * L + l) * 2 + 1];
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      lo[2 * i] = rx + off[2 * i] / Wl;
+      lo[2 * i + 1] = ry + off[2 * i + 1] / Hl;
+      wo[i] = expf(lg[i] - mx) / sum;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int rba_msda_prepare_f32(const float* raw, const float* reference_points, const int64_t* spatial_shapes, float* loc, float* attw,
+                                    int64_t rows, int M, int L, int P, void* stream) {
+  RBA_CHECK_ARG(rows >= 0 && M >= 1 && L >= 1 && P >= 1);
+  if (rows == 0) return 0;
+  RBA_CHECK_ARG(raw && reference_points && spatial_shapes && loc && attw && rows * M < (int64_t)1 << 40);
+  rba_begin();
+  const int64_t total = rows * M;
+  hipLaunchKernelGGL(msda_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, reference_points,
+                     spatial_shapes, loc, attw, rows, M, L, P);
+  return rba_launch_status();
+}
 
 extern "C" int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                           const float* sampling_loc, const float* attn_weight, float* out,

@@ -32,6 +32,19 @@ class MSDeformAttn(nn.Module):
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
 
+    def _sampling_linear(self):
+        """[sampling_offsets ; attention_weights] stacked along the output dimension, rebuilt when either weight changes."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight.data_ptr(), so.weight._version, aw.weight.data_ptr(), aw.weight._version, so.bias._version, aw.bias._version)
+        cache = getattr(self, "_rba_sampling", None)
+        if cache is None or cache[0] != key:
+            from types import SimpleNamespace
+            lin = SimpleNamespace(weight=torch.cat([so.weight.detach(), aw.weight.detach()], 0).contiguous(),
+                                  bias=torch.cat([so.bias.detach(), aw.bias.detach()], 0).contiguous())
+            cache = (key, lin)
+            self._rba_sampling = cache
+        return cache[1]
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query [N,Lq,C]; reference_points [N,Lq,L,2] in [0,1]; input_flatten [N,S,C] -> [N,Lq,C]."""
@@ -42,12 +55,12 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
-        offsets = ops.linear(query, self.sampling_offsets).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(ops.linear(query, self.attention_weights).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
         if reference_points.shape[-1] != 2:
             raise ValueError(f"Last dim of reference_points must be 2 on this path, got {reference_points.shape[-1]}")
-        normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(offsets.dtype)
-        loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
-        out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                         loc.contiguous(), weights.contiguous(), self.im2col_step)
+        # sampling_offsets and attention_weights as ONE Linear (rows [offsets | logits]), then one kernel for
+        # loc = reference + offset / (W_l, H_l) and the softmax over the L*P logits (reference :95-115)
+        raw = ops.linear(query, self._sampling_linear())
+        loc, weights = ops.msda_prepare(raw, reference_points.contiguous(), input_spatial_shapes, M, L, P)
+        out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index, loc, weights,
+                                         self.im2col_step)
         return ops.linear(out, self.output_proj)

@@ -319,6 +319,24 @@ def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None,
 
 
 @_hip_op
+def msda_prepare(raw, reference_points, spatial_shapes, M, L, P):
+    """raw [N, Lq, M*L*P*3] (offsets | logits of the fused sampling Linear), reference_points [N, Lq, L, 2], spatial_shapes [L,2] int64
+    -> (sampling_locations [N,Lq,M,L,P,2], attention_weights [N,Lq,M,L,P]) as MSDeformAttn.forward computes them."""
+    lib = _lib.load()
+    _chk(raw, "raw", dim=3)
+    _chk(reference_points, "reference_points", dim=4)
+    _chk(spatial_shapes, "spatial_shapes", torch.int64, 2)
+    N, Lq, W3 = raw.shape
+    if W3 != 3 * M * L * P or tuple(reference_points.shape) != (N, Lq, L, 2) or spatial_shapes.shape[0] != L:
+        raise RbaHipError("msda_prepare: shapes do not match")
+    loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=raw.device)
+    attw = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=raw.device)
+    _lib.check(lib.rba_msda_prepare_f32(_p(raw), _p(reference_points), _p(spatial_shapes), _p(loc), _p(attw), N * Lq, M, L, P, _stream()),
+               "rba_msda_prepare_f32")
+    return loc, attw
+
+
+@_hip_op
 def merge_layer_norm(x, H, W, weight, bias, eps=1e-5):
     """PatchMerging's gather + LayerNorm: x [B, H*W, C] -> [B, ceil(H/2)*ceil(W/2), 4C] = LN over the 2x2 neighbourhoods in the order
     (ee, oe, eo, oo), odd maps zero-padded -- the concatenated tensor is never materialised."""

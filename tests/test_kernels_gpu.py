@@ -710,3 +710,20 @@ def test_merge_layer_norm(ops, B, H, W, C):
     same = ops.add_layer_norm(dev(cat.contiguous()), dev(gamma), dev(beta), 1e-5)[1]
     assert torch.equal(out, same), "same arithmetic as the LayerNorm kernel on the materialised concatenation"
 
+
+@pytest.mark.parametrize("N,Lq,M,L,P", [(1, 2048, 8, 1, 4), (2, 300, 8, 3, 4), (1, 7, 2, 2, 3)])
+def test_msda_prepare(ops, N, Lq, M, L, P):
+    """offsets / logits of the fused sampling Linear -> sampling locations and softmaxed weights, against MSDeformAttn.forward's
+    own torch expressions (ms_deform_attn.py:95-115)"""
+    g = torch.Generator().manual_seed(N * Lq + M * L * P)
+    raw = torch.randn(N, Lq, 3 * M * L * P, generator=g)
+    ref_pts = torch.rand(N, Lq, L, 2, generator=g)
+    shapes = torch.tensor([[32 >> l, 64 >> l] for l in range(L)], dtype=torch.int64)
+    offsets = raw[..., : 2 * M * L * P].reshape(N, Lq, M, L, P, 2)
+    weights = F.softmax(raw[..., 2 * M * L * P:].reshape(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).float()
+    loc = ref_pts[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+    loc2, w2 = ops.msda_prepare(dev(raw), dev(ref_pts), dev(shapes), M, L, P)
+    assert torch.equal(loc2.cpu(), loc)
+    assert maxerr(w2, weights) < 2e-7
+
