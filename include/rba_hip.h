@@ -178,6 +178,20 @@ int rba_split_linear_f16x3_f32(const float* x, const void* weight_packed, const 
 int rba_split_linear_f16x3_res_f32(const float* x, const void* weight_packed, const float* bias, const float* residual, float* out,
                                    int64_t M, int N, int K, void* stream);
 
+/* Split activations: a [M, K] fp32 activation matrix held ONLY as the f16x3 GEMM's A operand, written by its producer (one split per
+ * element instead of one per column tile of every consumer; contiguous 1 KiB wave loads and no arithmetic in the GEMM).  Image =
+ * ceil(M / 32) * 32 * K * 4 bytes: per (32-row group rg, 32-wide block b of K) four 1 KiB pieces [h g0 | l g0 | h g1 | l g1], each
+ * [half][row & 31][8 f16] with k = 32 b + 16 half + 8 g + i; h = f16(x) (rne), l = f16((x - h) * 2^11).  Rows M .. are padding and never
+ * written.  K % 32 == 0.
+ *   rba_add_layer_norm_frag_f32     = rba_add_layer_norm_f32 with y written as that image (norm1 -> qkv, norm2 -> fc1 of
+ *                                     backbone/swin.py:235-295)
+ *   rba_split_linear_f16x3_frag_f32 = rba_split_linear_f16x3_f32 / _res_f32 (residual non-NULL, act 0) reading it; bit-identical to the
+ *                                     fp32-input entry points on the same values. */
+int rba_add_layer_norm_frag_f32(const float* x, const float* t, const float* t_bias, const float* gamma, const float* beta,
+                                float* sum_out, void* y_frag, int64_t rows, int C, float eps, void* stream);
+int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* weight_packed, const float* bias, const float* residual, float* out,
+                                    int64_t M, int N, int K, int act, void* stream);
+
 /* The same GEMM with NHWC rows in and NCHW out: out[(b*N + n)*P + p] = sum_k x[b*P + p, k] * weight[n, k] + bias[n],
  * P = rows_per_image, M % P == 0 (the mask-feature 1x1 convolution of pixel_decoder/msdeformattn.py:298-306). */
 int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N,

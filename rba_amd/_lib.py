@@ -35,6 +35,7 @@ SIGNATURES = {
     "rba_split_weight_f16x2": [_vp, _vp, _i, _i, _vp],
     "rba_split_linear_f16x3_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_linear_f16x3_res_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "rba_split_linear_f16x3_frag_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f16x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -50,12 +51,13 @@ SIGNATURES = {
     "rba_morph3x3_u8": [_vp, _vp, _i, _i, _i, _vp],
     "rba_ccl4_roots_i32": [_vp, _vp, _i, _i, _vp],
     "rba_add_layer_norm_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_float, _vp],
+    "rba_add_layer_norm_frag_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, ctypes.c_float, _vp],
     "rba_merge_layer_norm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp],
     "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 175        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 176        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -8,6 +8,7 @@
 // native clang vectors (the nontemporal builtins reject HIP's float4 class)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t rba_u32x4 __attribute__((ext_vector_type(4)));
 
 #define RBA_CHECK_ARG(cond)                      \
   do {                                           \
@@ -66,4 +67,19 @@ __device__ __forceinline__ BilinearTap bilinear_tap(int dst, float scale, int in
   t.l1 = src - (float)i0;
   t.l0 = 1.0f - t.l1;
   return t;
+}
+
+// The f16x3 split of two fp32 values (split_linear_h3.h): h = f16(x) (rne), l = f16((x - h) 2^11) = f16(fma(h, -2^11, 2^11 x)), the
+// fma exact.  Packed pairs: h = {f16(a), f16(b)}, l likewise.  v_cvt_pk_f16_f32, v_pk_mul_f32, v_fma_mixlo/mixhi_f16 reading the f16
+// halves of h in place: four VALU.  |x| >= 65504 gives h = inf and a NaN l (documented domain of the f16x3 mode).
+__device__ __forceinline__ void rba_split_f16x2(float a, float b, uint32_t& h, uint32_t& l) {
+  typedef _Float16 rba_f16x2 __attribute__((ext_vector_type(2)));
+  const rba_f16x2 hh = {(_Float16)a, (_Float16)b};
+  const uint32_t ap = __builtin_bit_cast(uint32_t, hh);
+  const f32x2 t = (f32x2){a, b} * 2048.0f;
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(ap), "v"(-2048.0f), "v"(t.x));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(ap), "v"(-2048.0f), "v"(t.y));
+  h = ap;
+  l = r;
 }

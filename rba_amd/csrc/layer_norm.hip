@@ -20,7 +20,11 @@ struct MergeGeom {
   int H, W, Cin;           // source map; rows = B * ceil(H/2) * ceil(W/2), C = 4 Cin
 };
 
-template <int G, int NV, bool MERGE = false>
+// FRAG: y is not written row-major but as the split, fragment-ordered image the f16x3 GEMM reads as its A operand without any
+// arithmetic (split_linear_h3.h, "PRE"): per (32-row group, 32-wide block of C) four 1 KiB pieces [h g0 | l g0 | h g1 | l g1], each
+// [lh][row & 31][8 f16], k = 32 b + 16 lh + 8 g + i; h = f16(y), l = f16((y - h) 2^11).  A lane holds 4 consecutive channels; the even
+// lane of a pair stores the 16-byte h piece, the odd lane the l piece (one DPP exchange): as many bytes and stores as the fp32 row.
+template <int G, int NV, bool MERGE = false, bool FRAG = false>
 __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, const float* __restrict__ t,
                                                              const float* __restrict__ tb, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* sum_out /* may alias x */,
@@ -97,18 +101,33 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, con
       if (sum_out) *reinterpret_cast<f32x4*>(sum_out + base + 4 * c4) = v[j];
       const f32x4 gj = EARLY ? g4[EARLY ? j : 0] : *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
       const f32x4 bj = EARLY ? b4[EARLY ? j : 0] : *reinterpret_cast<const f32x4*>(beta + 4 * c4);
-      *reinterpret_cast<f32x4*>(y + base + 4 * c4) = (v[j] - mean) * rstd * gj + bj;
+      const f32x4 o = (v[j] - mean) * rstd * gj + bj;
+      if (FRAG) {
+        uint32_t h[2], l[2];
+        rba_split_f16x2(o.x, o.y, h[0], l[0]);
+        rba_split_f16x2(o.z, o.w, h[1], l[1]);
+        const bool odd = c4 & 1;
+        const uint32_t s0 = odd ? h[0] : l[0], s1 = odd ? h[1] : l[1];             // what the partner lane stores
+        const uint32_t r0 = __builtin_amdgcn_mov_dpp(s0, 0xB1, 0xf, 0xf, true), r1 = __builtin_amdgcn_mov_dpp(s1, 0xB1, 0xf, 0xf, true);
+        const rba_u32x4 piece = odd ? (rba_u32x4){r0, r1, l[0], l[1]} : (rba_u32x4){h[0], h[1], r0, r1};
+        const int k8 = c4 >> 1;
+        const int64_t off = ((row >> 5) * (int64_t)(C >> 5) + (k8 >> 2)) * 4096 + ((k8 & 1) * 2 + (odd ? 1 : 0)) * 1024 +
+                            (((k8 >> 1) & 1) * 32 + (int)(row & 31)) * 16;
+        *reinterpret_cast<rba_u32x4*>(reinterpret_cast<char*>(y) + off) = piece;
+      } else {
+        *reinterpret_cast<f32x4*>(y + base + 4 * c4) = o;
+      }
     }
   }
 }
 
-template <int G, int NV>
+template <int G, int NV, bool FRAG = false>
 int launch(const float* x, const float* t, const float* tb, const float* gamma, const float* beta, float* sum_out, float* y,
            int64_t rows, int C, float eps, hipStream_t st) {
   const int64_t rpb = 4 * (64 / G);
   const int64_t blocks = (rows + rpb - 1) / rpb;
   if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((add_layer_norm_kernel<G, NV>), dim3((unsigned)blocks), dim3(256), 0, st, x, t, tb, gamma, beta, sum_out, y,
+  hipLaunchKernelGGL((add_layer_norm_kernel<G, NV, false, FRAG>), dim3((unsigned)blocks), dim3(256), 0, st, x, t, tb, gamma, beta, sum_out, y,
                      rows, C, eps);
   return rba_launch_status();
 }
@@ -162,6 +181,31 @@ extern "C" int rba_add_layer_norm_f32(const float* x, const float* t, const floa
   hipStream_t st = (hipStream_t)stream;
   const int nv4 = C / 4;
 #define RBA_L(G, NV) return launch<G, NV>(x, t, t_bias, gamma, beta, sum_out, y, rows, C, eps, st)
+  if (nv4 <= 16) RBA_L(16, 1);
+  if (nv4 <= 32) RBA_L(32, 1);
+  if (nv4 <= 64) RBA_L(64, 1);
+  if (nv4 <= 128) RBA_L(64, 2);
+  if (nv4 <= 256) RBA_L(64, 4);
+  if (nv4 <= 512) RBA_L(64, 8);
+  if (nv4 <= 1024) RBA_L(64, 16);
+  RBA_L(64, 32);
+#undef RBA_L
+}
+
+// The same, with y written as the split fragment image of the f16x3 GEMM's A operand (see FRAG above; 128 B per row per 32 channels,
+// rows padded to a multiple of 32: y_frag holds ceil(rows / 32) * 32 * C * 4 bytes, the padding rows are never written).  C % 32 == 0.
+extern "C" int rba_add_layer_norm_frag_f32(const float* x, const float* t, const float* t_bias, const float* gamma, const float* beta,
+                                           float* sum_out, void* y_frag, int64_t rows, int C, float eps, void* stream) {
+  RBA_CHECK_ARG(rows >= 0 && C >= 32 && C % 32 == 0 && C <= 8192);
+  if (rows == 0) return 0;
+  RBA_CHECK_ARG(x && gamma && beta && y_frag);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)t | (uintptr_t)t_bias | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)sum_out |
+                  (uintptr_t)y_frag) & 15) == 0);
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  const int nv4 = C / 4;
+  float* y = reinterpret_cast<float*>(y_frag);
+#define RBA_L(G, NV) return launch<G, NV, true>(x, t, t_bias, gamma, beta, sum_out, y, rows, C, eps, st)
   if (nv4 <= 16) RBA_L(16, 1);
   if (nv4 <= 32) RBA_L(32, 1);
   if (nv4 <= 64) RBA_L(64, 1);

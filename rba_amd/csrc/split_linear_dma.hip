@@ -99,3 +99,21 @@ extern "C" int rba_split_linear_f16x3_res_f32(const float* x, const void* weight
   if (rc) return rc;
   return rba_launch_status();
 }
+
+// The same Linear with the A operand supplied as the producer's split fragment image (rba_add_layer_norm_frag_f32, ...): no
+// activation arithmetic and only contiguous 1 KiB wave loads in the GEMM.  x_frag: ceil(M / 32) * 32 * K * 4 bytes, layout in
+// split_linear_h3.h ("PRE").  act 0 / 1 (GELU) / 2 (ReLU); residual (nullable, act must be 0): out = residual + x W^T + bias.
+extern "C" int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* weight_packed, const float* bias, const float* residual,
+                                               float* out, int64_t M, int N, int K, int act, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0 && act >= 0 && act <= 2 && !(residual && act));
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x_frag && weight_packed && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x_frag | (uintptr_t)weight_packed | (uintptr_t)out | (uintptr_t)residual) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = h3p_single_resident(M, N) ? launch_h3p_pre_act<1>(act, x_frag, wp, bias, residual, out, M, N, K, st)
+                                           : launch_h3p_pre_act<2>(act, x_frag, wp, bias, residual, out, M, N, K, st);
+  if (rc) return rc;
+  return rba_launch_status();
+}

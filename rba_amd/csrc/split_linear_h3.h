@@ -32,18 +32,13 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 // 8 fp32 -> the two f16x8 MFMA operands: h = f16(x), l = f16((x - h) * 2^11) = f16(fma(h, -2^11, 2^11 x)) (the fma is exact).
 // Four VALU per pair: v_cvt_pk_f16_f32, v_pk_mul_f32, and v_fma_mixlo/mixhi_f16 reading the f16 halves of h in place.
 __device__ __forceinline__ void split_h3(const f32x4 u, const f32x4 v, f16x8_t& h, f16x8_t& l) {
-  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
   const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
   u32x4_t hp, lp;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const f16x2_t a = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]};
-    const uint32_t ap = __builtin_bit_cast(uint32_t, a);
-    const f32x2 t = (f32x2){x[2 * i], x[2 * i + 1]} * 2048.0f;
-    uint32_t r;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(ap), "v"(-2048.0f), "v"(t.x));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(ap), "v"(-2048.0f), "v"(t.y));
-    hp[i] = ap;
+    uint32_t a, r;
+    rba_split_f16x2(x[2 * i], x[2 * i + 1], a, r);
+    hp[i] = a;
     lp[i] = r;
   }
   h = __builtin_bit_cast(f16x8_t, hp);
@@ -455,8 +450,8 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 // tile 3 computes.  The interleaving is pinned with __builtin_amdgcn_sched_group_barrier (MFMA, DS read, 4 VALU, ...): left to
 // itself the compiler re-serialises reads and MFMAs (83 us instead of 69 us on Swin stage-3 fc1).  Register budget: 128
 // accumulators + 2 x 16 weight fragments + 2 x 16 activation operands + 16 raw activations + 16 weight staging.
-template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false>
-__global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false>
+__global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
                                                                  const float* R = nullptr) {
@@ -490,7 +485,9 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
     for (int r = 0; r < 16; ++r) accm[j][r] = accl[j][r] = 0.f;
 
   u32x4_t wr[UPL];
-  f32x4 xr[4];
+  constexpr bool DEEP = OCC == 1;                                                  // registers to spare: activations two blocks ahead
+  constexpr bool DIRECT = PRE && OCC == 2;                                         // pieces straight into the next block's operand set
+  f32x4 xr[DEEP ? 2 : 1][4];
   f16x8_t ah[2][2], al[2][2];                                                      // [block parity][g]
   u32x4_t bq[2][4];                                                                // [column-tile parity][h g0, l g0, h g1, l g1]
   const int last = NB - 1;
@@ -499,10 +496,26 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(src + q * 4096 + woff);
   };
-  auto xload = [&](int c) {
+  // PRE: A is the producer's fragment-ordered, already split image (frag_layout.h): per (32-row group, 32-wide block) four 1 KiB
+  // pieces [h g0 | l g0 | h g1 | l g1], each [lane][8 f16] -- one contiguous wave load per operand register quad, no arithmetic here
+  const int rgrp = min((m0 >> 5) + wave, ((M + 31) >> 5) - 1);
+  const char* fbase = reinterpret_cast<const char*>(A) + ((int64_t)rgrp * NB) * 4096 + lane * 16;
+  auto xload = [&](int c, f32x4 (&d)[4]) {
+    if (PRE) {
+      const char* src = fbase + (c < last ? c : last) * 4096;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(src + q * 1024);
+      return;
+    }
+    if (PROBE & 2048) {                                                            // ablation: the same bytes as contiguous 1 KiB wave loads
+      const char* src = xbase + (uint32_t)(32 * wave) * (uint32_t)K * 4u + (c < last ? c : last) * 4096 + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(src + q * 1024);
+      return;
+    }
     const char* src = xbase + (c < last ? c : last) * 128;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(src + q * 16 + xoff);
+    for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(src + q * 16 + xoff);
   };
   const int fb = l31 * 2 + (lh ^ ((l31 >> 3) & 1));                                // + g SUBW + (p BN + 32 j) 2
   auto bread = [&](const u32x4_t* img, int j, u32x4_t (&d)[4]) {
@@ -512,18 +525,49 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
     d[3] = img[SUBW + fb + 2 * BN + 64 * j];
   };
 
+  auto xloadset = [&](int c, int p) {
+    const char* src = fbase + (c < last ? c : last) * 4096;
+    ah[p][0] = *reinterpret_cast<const f16x8_t*>(src);
+    al[p][0] = *reinterpret_cast<const f16x8_t*>(src + 1024);
+    ah[p][1] = *reinterpret_cast<const f16x8_t*>(src + 2048);
+    al[p][1] = *reinterpret_cast<const f16x8_t*>(src + 3072);
+  };
+  auto psplit = [&](const f32x4 u, const f32x4 v, f16x8_t& h, f16x8_t& l) {
+    if (PRE || (PROBE & 512)) {                                                    // PRE: the pieces ARE the operands (PROBE 512: ablation)
+      h = __builtin_bit_cast(f16x8_t, u);
+      l = __builtin_bit_cast(f16x8_t, v);
+    } else {
+      split_h3(u, v, h, l);
+    }
+  };
+  auto pbread = [&](const u32x4_t* img, int j, u32x4_t (&d)[4]) {
+    if (!(PROBE & 1024)) bread(img, j, d);
+  };
   wload(0);
-  xload(0);
+  if (DIRECT) xloadset(0, 0);
+  else xload(0, xr[0]);
 #pragma unroll
   for (int q = 0; q < UPL; ++q) lds[tid + 256 * q] = wr[q];
-  split_h3(xr[0], xr[1], ah[0][0], al[0][0]);
-  split_h3(xr[2], xr[3], ah[0][1], al[0][1]);
+  if (!DIRECT) {
+    psplit(xr[0][0], xr[0][1], ah[0][0], al[0][0]);
+    psplit(xr[0][2], xr[0][3], ah[0][1], al[0][1]);
+  }
   wload(1);
-  xload(1);
+  if (DIRECT) {
+  } else if (DEEP) {
+    xload(1, xr[DEEP ? 1 : 0]);
+    xload(2, xr[0]);
+  } else {
+    xload(1, xr[0]);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   bread(lds, 0, bq[0]);
   bread(lds, 1, bq[1]);
-  if (TIMING) tm[1] = wall_clock64();
+  unsigned long long cyc = 0;
+  if (TIMING) {
+    tm[1] = wall_clock64();
+    cyc = __builtin_readcyclecounter();
+  }
 
 #define RBA_MFMA6(J, Q, P)                                                                                              \
   {                                                                                                                     \
@@ -554,30 +598,32 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
   __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                    \
   __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                                    \
   __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#define RBA_XI(P) (DEEP ? (P) ^ 1 : 0)
 #define RBA_BLOCK(B, P, CUR, NXT)                                                                                       \
   {                                                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < UPL; ++q)(NXT)[tid + 256 * q] = wr[q];                                        \
+    if (!(PROBE & 256)) { _Pragma("unroll") for (int q = 0; q < UPL; ++q)(NXT)[tid + 256 * q] = wr[q]; }                \
     if (!(PROBE & 1)) wload((B) + 2);                                                                                   \
+    if (DIRECT) xloadset((B) + 1, (P) ^ 1);                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     RBA_MFMA6(0, 0, P)                                                                                                  \
-    bread(CUR, 2, bq[0]);                                                                                               \
-    split_h3(xr[0], xr[1], ah[(P) ^ 1][0], al[(P) ^ 1][0]);                                                             \
+    pbread(CUR, 2, bq[0]);                                                                                              \
+    if (!DIRECT) psplit(xr[RBA_XI(P)][0], xr[RBA_XI(P)][1], ah[(P) ^ 1][0], al[(P) ^ 1][0]);                                                           \
     RBA_PIPE_MFMA_DSR_VALU                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     RBA_MFMA6(1, 1, P)                                                                                                  \
-    bread(CUR, 3, bq[1]);                                                                                               \
-    split_h3(xr[2], xr[3], ah[(P) ^ 1][1], al[(P) ^ 1][1]);                                                             \
+    pbread(CUR, 3, bq[1]);                                                                                              \
+    if (!DIRECT) psplit(xr[RBA_XI(P)][2], xr[RBA_XI(P)][3], ah[(P) ^ 1][1], al[(P) ^ 1][1]);                                                           \
     RBA_PIPE_MFMA_DSR_VALU                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    if (!(PROBE & 2)) xload((B) + 2);                                                                                   \
+    if (!DIRECT && !(PROBE & 2)) xload((B) + (DEEP ? 3 : 2), xr[RBA_XI(P)]);                                                                                 \
     RBA_MFMA6(2, 0, P)                                                                                                  \
     if (!(PROBE & 64)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                               \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     RBA_MFMA6(3, 1, P)                                                                                                  \
-    bread(NXT, 0, bq[0]);                                                                                               \
+    pbread(NXT, 0, bq[0]);                                                                                              \
     RBA_PIPE_MFMA_DSR                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    bread(NXT, 1, bq[1]);                                                                                               \
+    pbread(NXT, 1, bq[1]);                                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
   }
   int b = 0;
@@ -594,34 +640,68 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3p_kernel(const float* _
     }
   }
 #undef RBA_BLOCK
+#undef RBA_XI
 #undef RBA_PIPE_MFMA_DSR
 #undef RBA_PIPE_MFMA_DSR_VALU
 #undef RBA_MFMA6
 
-  if (TIMING) tm[2] = wall_clock64();
+  if (TIMING) {
+    tm[2] = wall_clock64();
+    cyc = __builtin_readcyclecounter() - cyc;
+  }
   h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
     for (int i = 0; i < 4; ++i) dbg[6 * blockIdx.x + i] = tm[i];
-    dbg[6 * blockIdx.x + 4] = dbg[6 * blockIdx.x + 5] = 0;
+    dbg[6 * blockIdx.x + 4] = cyc;                                                 // shader clocks spent in the k loop
+    dbg[6 * blockIdx.x + 5] = 0;
   }
 }
 
-template <int ACT, int PROBE = 0>
+template <int ACT, int PROBE = 0, int OCC = 2>
 int launch_h3p(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t stream) {
   const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, PROBE>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N, K,
+  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, PROBE, false, false, OCC>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N, K,
                      (int)MT, NT, nullptr);
   return 0;
 }
 
+// At most one workgroup per CU (<= 256 tiles): the OCC = 1 build (no second workgroup to share the register file with, so the
+// activations are prefetched two blocks ahead): -4 ... -9 % on Swin stage-3/4 proj and fc2 (profiles/r02_k6_h3p_ablation.txt).
+inline bool h3p_single_resident(int64_t M, int N) { return ((M + 127) / 128) * ((N + 127) / 128) <= 256; }
+
 inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t st) {
+  if (h3p_single_resident(M, N)) {
+    if (act == 1) return launch_h3p<1, 0, 1>(x, wp, bias, out, M, N, K, st);
+    if (act == 2) return launch_h3p<2, 0, 1>(x, wp, bias, out, M, N, K, st);
+    return launch_h3p<0, 0, 1>(x, wp, bias, out, M, N, K, st);
+  }
   if (act == 1) return launch_h3p<1>(x, wp, bias, out, M, N, K, st);
   if (act == 2) return launch_h3p<2>(x, wp, bias, out, M, N, K, st);
   return launch_h3p<0>(x, wp, bias, out, M, N, K, st);
+}
+
+// A operand = the producer's split fragment image (PRE); residual may be null
+template <int ACT, bool RES, int OCC>
+int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K,
+                   hipStream_t st) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 127) / 128;
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, OCC, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
+                     reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr, res);
+  return 0;
+}
+template <int OCC>
+int launch_h3p_pre_act(int act, const void* xf, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N,
+                       int K, hipStream_t st) {
+  if (res) return launch_h3p_pre<0, true, OCC>(xf, wp, bias, res, out, M, N, K, st);
+  if (act == 1) return launch_h3p_pre<1, false, OCC>(xf, wp, bias, nullptr, out, M, N, K, st);
+  if (act == 2) return launch_h3p_pre<2, false, OCC>(xf, wp, bias, nullptr, out, M, N, K, st);
+  return launch_h3p_pre<0, false, OCC>(xf, wp, bias, nullptr, out, M, N, K, st);
 }
 
 template <int ACT, int CT, int PROBE = 0>
@@ -694,8 +774,12 @@ inline int launch_h3p_res(const float* x, const u32x4_t* wp, const float* bias, 
   const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M, N, K,
-                     (int)MT, NT, nullptr, res);
+  if (MT * NT <= 256)
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, true, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M,
+                       N, K, (int)MT, NT, nullptr, res);
+  else
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M, N,
+                       K, (int)MT, NT, nullptr, res);
   return 0;
 }
 

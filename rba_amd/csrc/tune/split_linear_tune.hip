@@ -136,6 +136,10 @@ extern "C" int rba_split_linear_h3_tune(const float* x, const void* weight_packe
     case 1644: rc = launch_h3l<1, 4, 64>(x, wp, bias, out, M, N, K, st); break;
     case 2284: rc = launch_h3l<1, 4, 128>(x, wp, bias, out, M, N, K, st); break;
     case 4004: rc = launch_h3p_act(act, x, wp, bias, out, M, N, K, st); break;
+    case 5004:
+      rc = act == 1 ? launch_h3p<1, 0, 1>(x, wp, bias, out, M, N, K, st) : act == 2 ? launch_h3p<2, 0, 1>(x, wp, bias, out, M, N, K, st)
+                                                                                      : launch_h3p<0, 0, 1>(x, wp, bias, out, M, N, K, st);
+      break;
     case 4044: rc = launch_h3p<1, 4>(x, wp, bias, out, M, N, K, st); break;
     case 4014: rc = launch_h3p<1, 1>(x, wp, bias, out, M, N, K, st); break;
     case 4024: rc = launch_h3p<1, 2>(x, wp, bias, out, M, N, K, st); break;
@@ -177,6 +181,16 @@ extern "C" int rba_split_linear_h3_timing(const float* x, const void* weight_pac
   else if (probe == 1000)
     hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
                        (int)M, N, K, (int)MT, NT, dbg);
+#define RBA_H3P_T(P)                                                                                                                  \
+  else if (probe == 1100 + P) hipLaunchKernelGGL((split_linear_h3p_kernel<0, P, true>), dim3((unsigned)(MT * NT)), dim3(256), 0,       \
+                                                 (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT, dbg);
+  RBA_H3P_T(0) RBA_H3P_T(1) RBA_H3P_T(2) RBA_H3P_T(3) RBA_H3P_T(64) RBA_H3P_T(67) RBA_H3P_T(2048) RBA_H3P_T(2560)
+#undef RBA_H3P_T
+#define RBA_H3P_T(P)                                                                                                                  \
+  else if (probe == 1200 + P) hipLaunchKernelGGL((split_linear_h3p_kernel<0, P, true, false, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, \
+                                                 (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT, dbg);
+  RBA_H3P_T(0) RBA_H3P_T(3) RBA_H3P_T(67) RBA_H3P_T(323) RBA_H3P_T(579) RBA_H3P_T(1091) RBA_H3P_T(1859) RBA_H3P_T(2048) RBA_H3P_T(2560) RBA_H3P_T(1) RBA_H3P_T(2) RBA_H3P_T(64) RBA_H3P_T(1795) RBA_H3P_T(768) RBA_H3P_T(512) RBA_H3P_T(256)
+#undef RBA_H3P_T
   else if (probe == 1001)
     hipLaunchKernelGGL((split_linear_h3l_kernel<1, 4, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
                        (int)M, N, K, (int)MT, NT, dbg, ConvShape{0, 0, 0});

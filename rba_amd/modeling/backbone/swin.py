@@ -68,16 +68,20 @@ class SwinTransformerBlock(nn.Module):
         adds and projection biases are folded into the fused add+LayerNorm kernel."""
         a = self.attn
         t, tb = pending if pending is not None else (None, None)
-        x, y = ops.add_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, t, tb, inplace_sum=True)
+        M, C = x.numel() // x.shape[-1], x.shape[-1]
+        # where the consumer is the pipelined f16x3 GEMM, the LayerNorm hands its output over already split and in MFMA fragment
+        # order (ops.SplitActivations): one split per element instead of one per column tile, contiguous operand loads
+        x, y = ops.add_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, t, tb, inplace_sum=True,
+                                  frag=ops.linear_takes_split(M, 3 * C, C))
         qkv = ops.linear(y, a.qkv)
         bias, bias_frag = a.gathered_bias()
         y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size,
                                  bias_frag=bias_frag)
-        M, C = x.numel() // x.shape[-1], x.shape[-1]
         if ops.linear_residual_fused(M, C, C):
             # the residual adds ride in the GEMM epilogues (x is updated in place), the LayerNorms read one tensor and write one
             x = ops.linear(y, a.proj, residual=x)
-            y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]
+            y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps,
+                                   frag=ops.linear_takes_split(M, self.mlp.fc1.out_features, C))[1]
             y = ops.linear(y, self.mlp.fc1, gelu=True)
             return ops.linear(y, self.mlp.fc2, residual=x), None
         t = ops.linear(y, a.proj, use_bias=False)                        # proj bias rides in the fused add+LN

@@ -6,6 +6,7 @@ AT_ASSERTM on contiguity and device -> RuntimeError): a bad argument raises Runt
 no fallback path.
 """
 import functools
+import os
 
 import torch
 
@@ -26,6 +27,9 @@ def _cuda_tensors(args):
                 yield a
         elif isinstance(a, (list, tuple)):
             yield from _cuda_tensors(a)
+        elif isinstance(a, SplitActivations):
+            if a.data.is_cuda:
+                yield a.data
         elif isinstance(a, torch.nn.Module):
             yield from (p_ for p_ in a.parameters(recurse=False) if p_.is_cuda)
 
@@ -290,9 +294,10 @@ def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
 
 
 @_hip_op
-def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None, inplace_sum=False):
+def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None, inplace_sum=False, frag=False):
     """y = LayerNorm(x + residual + residual_bias) over the last dim.  Returns (s, y) where s = the summed tensor
-    (x itself when there is nothing to add; written in place over x when inplace_sum, else a new tensor)."""
+    (x itself when there is nothing to add; written in place over x when inplace_sum, else a new tensor).
+    ``frag``: y is returned as SplitActivations (the f16x3 GEMM's A operand, already split and fragment-ordered) for linear()."""
     lib = _lib.load()
     _chk(x, "x")
     _chk(weight, "weight", dim=1)
@@ -311,6 +316,14 @@ def add_layer_norm(x, weight, bias, eps=1e-5, residual=None, residual_bias=None,
             raise RbaHipError("residual_bias must have C elements")
     has_sum = residual is not None or residual_bias is not None
     s = x if (not has_sum or inplace_sum) else torch.empty_like(x)
+    if frag:
+        if C % 32:
+            raise RbaHipError("add_layer_norm(frag=True) needs C % 32 == 0")
+        y = SplitActivations.empty(tuple(x.shape), x.device)
+        _lib.check(lib.rba_add_layer_norm_frag_f32(_p(x), _p(residual), _p(residual_bias), _p(weight), _p(bias),
+                                                   _p(s) if has_sum else 0, _p(y.data), rows, C, float(eps), _stream()),
+                   "rba_add_layer_norm_frag_f32")
+        return s, y
     y = torch.empty_like(x)
     _lib.check(lib.rba_add_layer_norm_f32(_p(x), _p(residual), _p(residual_bias), _p(weight), _p(bias),
                                           _p(s) if has_sum else 0, _p(y), rows, C, float(eps), _stream()),
@@ -371,6 +384,59 @@ def skinny_linear(x, weight, bias=None, relu=False):
     _lib.check(lib.rba_skinny_linear_f32(_p(x), _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), _stream()),
                "rba_skinny_linear_f32")
     return out
+
+
+class SplitActivations:
+    """A [..., K] fp32 activation tensor held ONLY as the f16x3 GEMM's A operand: h = f16(x), l = f16((x - h) 2^11), stored per
+    (32-row group, 32-wide block of K) as four 1 KiB pieces [h g0 | l g0 | h g1 | l g1], each [k-half][row & 31][8 f16] with
+    k = 32 b + 16 half + 8 g + i (csrc/split_linear_h3.h, "PRE").  Same bytes as the fp32 tensor (rows padded to a multiple of 32,
+    padding never written); produced by add_layer_norm(frag=True), consumed by linear().  ``shape`` = the logical fp32 shape."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    @staticmethod
+    def empty(shape, device):
+        K = shape[-1]
+        M = 1
+        for d in shape[:-1]:
+            M *= d
+        return SplitActivations(torch.empty((((M + 31) // 32) * 32 * K,), dtype=torch.int32, device=device), shape)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def numel(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    @staticmethod
+    def pack(x):
+        """Reference packer (torch ops; tests and tools): the image the kernels write for x."""
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).float()
+        M = x2.shape[0]
+        Mp = (M + 31) // 32 * 32
+        xp = torch.zeros((Mp, K), dtype=torch.float32, device=x.device)
+        xp[:M] = x2
+        h = xp.half()
+        l = ((xp - h.float()) * 2048.0).half()
+        hl = torch.stack([h, l], 0).reshape(2, Mp // 32, 32, K // 32, 2, 2, 8)          # [hl, rg, l31, b, half, g, i]
+        img = hl.permute(1, 3, 5, 0, 4, 2, 6).contiguous()                              # [rg, b, g, hl, half, l31, i]
+        return SplitActivations(img.reshape(-1).view(torch.int32), x.shape)
+
+    def unpack(self):
+        """fp32 values h + l 2^-11 of the image (rows beyond M dropped)."""
+        K = self.shape[-1]
+        M = self.numel() // K
+        Mp = (M + 31) // 32 * 32
+        img = self.data.view(torch.float16).reshape(Mp // 32, K // 32, 2, 2, 2, 32, 8)  # [rg, b, g, hl, half, l31, i]
+        hl = img.permute(3, 0, 5, 1, 4, 2, 6).reshape(2, Mp, K).float()
+        return (hl[0] + hl[1] / 2048.0)[:M].reshape(self.shape)
 
 
 SPLIT_MODE = "f16x3"
@@ -438,22 +504,39 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None):
     """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the split
     kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise.
     ``residual`` (f16x3 form only, see linear_residual_fused): returns ``(residual + x W^T) + bias`` written IN PLACE over `residual`."""
-    _chk(x, "x") if x.is_contiguous() else _chk(x.contiguous(), "x")          # HIP fp32 tensors only: no CPU path here either
     w = lin.weight
     N, K = w.shape
     M = x.numel() // K if K else 0
     bias = lin.bias if use_bias else None
+    if isinstance(x, SplitActivations):
+        if SPLIT_MODE != "f16x3" or x.shape[-1] != K:
+            raise RbaHipError("SplitActivations feed the f16x3 Linear only (check linear_takes_split(M, N, K) before producing them)")
+        return split_linear(x, _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
+    _chk(x, "x") if x.is_contiguous() else _chk(x.contiguous(), "x")          # HIP fp32 tensors only: no CPU path here either
     if split_linear_pays(M, N, K, gelu):
-        key = (w.data_ptr(), w._version, w.device, SPLIT_MODE)
-        cache = getattr(lin, "_rba_planes", None)
-        if cache is None or cache[0] != key:
-            cache = (key, split_weight(w.detach().contiguous()))
-            lin._rba_planes = cache
-        return split_linear(x.contiguous(), cache[1], bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
+        return split_linear(x.contiguous(), _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
     if residual is not None:
         raise RbaHipError("linear(residual=...) needs the fused f16x3 path: check linear_residual_fused(M, N, K) first")
     y = torch.nn.functional.linear(x, w, bias)
     return torch.nn.functional.gelu(y) if gelu else (torch.relu(y) if relu else y)
+
+
+def _cached_planes(lin, w):
+    key = (w.data_ptr(), w._version, w.device, SPLIT_MODE)
+    cache = getattr(lin, "_rba_planes", None)
+    if cache is None or cache[0] != key:
+        cache = (key, split_weight(w.detach().contiguous()))
+        lin._rba_planes = cache
+    return cache[1]
+
+
+SPLIT_ACTIVATIONS = os.environ.get("RBA_SPLIT_ACTIVATIONS", "1") != "0"      # A/B switch (tools): producers keep writing fp32 rows
+
+
+def linear_takes_split(M, N, K):
+    """True when linear() on this shape runs the pipelined 128-column f16x3 kernel, whose A operand a producer can hand over as
+    SplitActivations (the same dispatch as csrc/split_linear_dma.hip: K > 256 and at least 160 tiles of 128 x 128)."""
+    return (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K > 256 and K % 32 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 160)
 
 
 def linear_residual_fused(M, N, K):
@@ -467,7 +550,11 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False
     dtype says which form they were packed for).
     ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
     lib = _lib.load()
-    _chk(x, "x")
+    pre = isinstance(x, SplitActivations)
+    if pre:
+        _chk(x.data, "x.data", dtype=torch.int32, dim=1)
+    else:
+        _chk(x, "x")
     f16 = planes.dtype == torch.float16
     _chk(planes, "planes", dtype=torch.float16 if f16 else torch.bfloat16, dim=6)
     K = x.shape[-1]
@@ -485,10 +572,20 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False
         _chk(residual, "residual")
         if not f16 or act or tuple(residual.shape) != tuple(x.shape[:-1]) + (N,):
             raise RbaHipError("residual needs f16x3 planes, no activation and a [..., N] tensor")
+        if pre:
+            _lib.check(lib.rba_split_linear_f16x3_frag_f32(_p(x.data), _p(planes), _p(bias), _p(residual), _p(residual), M, N, K, 0, _stream()),
+                       "rba_split_linear_f16x3_frag_f32")
+            return residual
         _lib.check(lib.rba_split_linear_f16x3_res_f32(_p(x), _p(planes), _p(bias), _p(residual), _p(residual), M, N, K, _stream()),
                    "rba_split_linear_f16x3_res_f32")
         return residual
     out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    if pre:
+        if not f16:
+            raise RbaHipError("SplitActivations need f16x3 planes")
+        _lib.check(lib.rba_split_linear_f16x3_frag_f32(_p(x.data), _p(planes), _p(bias), 0, _p(out), M, N, K, act, _stream()),
+                   "rba_split_linear_f16x3_frag_f32")
+        return out
     if f16:
         _lib.check(lib.rba_split_linear_f16x3_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, act, _stream()), "rba_split_linear_f16x3_f32")
     else:

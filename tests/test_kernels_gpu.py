@@ -388,6 +388,45 @@ def test_split_linear_residual_epilogue(ops, M, N, K):
     assert out.data_ptr() == r2.data_ptr() and torch.equal(out, want)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (8192, 2048, 512), (3000, 1100, 544), (2048, 3072, 1024), (130, 200, 96), (31, 128, 32),
+                                   (8192, 512, 2048)])
+def test_split_linear_from_split_activations(ops, M, N, K):
+    """The f16x3 GEMM reading its A operand as the producer's split fragment image (SplitActivations): bit-identical to the
+    fp32-input kernel, with every epilogue (bias, GELU, ReLU, residual), one and two workgroups per CU, ragged M and N."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = dev(torch.randn(M, K, generator=g) * 3), dev(torch.randn(N, K, generator=g) * K ** -0.5)
+    b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+    planes = ops.split_weight(w, mode="f16x3")
+    xs = ops.SplitActivations.pack(x)
+    assert torch.equal(xs.unpack(), (x.half().float() + ((x - x.half().float()) * 2048).half().float() / 2048))
+    for kw in ({}, {"gelu": True}, {"relu": True}):
+        assert torch.equal(ops.split_linear(xs, planes, b, out_features=N, **kw), ops.split_linear(x, planes, b, out_features=N, **kw))
+    want = ops.split_linear(x, planes, b, out_features=N, residual=r.clone())
+    got = ops.split_linear(xs, planes, b, out_features=N, residual=r.clone())
+    assert torch.equal(got, want)
+    assert torch.equal(ops.split_linear(xs, planes, None, out_features=N), ops.split_linear(x, planes, None, out_features=N))
+
+
+@pytest.mark.parametrize("rows,C", [(8192, 512), (2048, 1024), (1000, 96), (33, 32), (4100, 1536), (70, 2048)])
+def test_add_layer_norm_split_output(ops, rows, C):
+    """add_layer_norm(frag=True): the LayerNorm output written directly as SplitActivations == pack(fp32 output), bit for bit, with and
+    without the fused residual add; the summed tensor is unchanged."""
+    g = torch.Generator().manual_seed(rows + C)
+    x, t = dev(torch.randn(rows, C, generator=g) * 2), dev(torch.randn(rows, C, generator=g))
+    tb, w, b = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    for res, rb in ((None, None), (t, tb)):
+        s0, y0 = ops.add_layer_norm(x, w, b, 1e-5, res, rb)
+        s1, y1 = ops.add_layer_norm(x, w, b, 1e-5, res, rb, frag=True)
+        assert isinstance(y1, ops.SplitActivations) and y1.shape == tuple(x.shape)
+        ref = ops.SplitActivations.pack(y0)
+        K = C
+        nfull = rows // 32 * 32 * K                                            # the padding rows of the last group are never written
+        assert torch.equal(y1.data[:nfull], ref.data[:nfull])
+        assert torch.equal(y1.unpack(), ref.unpack()) and torch.equal(s0, s1)
+    with pytest.raises(ops.RbaHipError):
+        ops.add_layer_norm(dev(torch.randn(8, 48)), dev(torch.randn(48)), dev(torch.randn(48)), frag=True)
+
+
 def test_split_linear_relu_epilogue(ops):
     g = torch.Generator().manual_seed(3)
     for M, N, K in ((1000, 1024, 256), (300, 256, 1024)):

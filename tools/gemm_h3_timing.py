@@ -36,6 +36,9 @@ t -= t0
 print(f"{nwg} workgroups; kernel span {t[:, 3].max():.1f} us")
 print(f"prologue {np.median(t[:, 1] - t[:, 0]):.2f} us  loop {np.median(t[:, 2] - t[:, 1]):.2f} us  epilogue {np.median(t[:, 3] - t[:, 2]):.2f} us (medians);"
       f" loop p10/p90 {np.percentile(t[:, 2] - t[:, 1], 10):.2f}/{np.percentile(t[:, 2] - t[:, 1], 90):.2f}")
+if probe >= 1000 and probe != 1001:
+    lp = np.median(t[:, 2] - t[:, 1])
+    print(f"shader clock in the loop: {np.median(d[:, 4]) / lp / 1e3:.2f} GHz; {np.median(d[:, 4]) / (K // 32):.0f} clk per 32-wide block (MFMA alone: 768)")
 # residency: number of workgroups alive at sample times
 for ts in np.linspace(1, t[:, 3].max() - 1, 12):
     alive = int(((t[:, 0] <= ts) & (t[:, 3] > ts)).sum())
