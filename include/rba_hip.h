@@ -191,6 +191,12 @@ int rba_add_layer_norm_frag_f32(const float* x, const float* t, const float* t_b
                                 float* sum_out, void* y_frag, int64_t rows, int C, float eps, void* stream);
 int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* weight_packed, const float* bias, const float* residual, float* out,
                                     int64_t M, int N, int K, int act, void* stream);
+/*   rba_split_linear_f16x3_gelu_split_out = GELU(x W^T + bias) written as the split image of the NEXT Linear (Mlp.fc1 -> fc2,
+ *                                     backbone/swin.py:35-41): the GEMM runs with its MFMA operands swapped (D^T = W x^T), so a lane ends
+ *                                     up with consecutive output channels of one row and stores 16-byte pieces.  x: fp32 rows
+ *                                     (x_is_split 0) or a split image (1).  N % 32 == 0; out_frag ceil(M / 32) * 32 * N * 4 bytes. */
+int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_split, const void* weight_packed, const float* bias, void* out_frag,
+                                          int64_t M, int N, int K, void* stream);
 
 /* The same GEMM with NHWC rows in and NCHW out: out[(b*N + n)*P + p] = sum_k x[b*P + p, k] * weight[n, k] + bias[n],
  * P = rows_per_image, M % P == 0 (the mask-feature 1x1 convolution of pixel_decoder/msdeformattn.py:298-306). */

@@ -117,3 +117,23 @@ extern "C" int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* w
   if (rc) return rc;
   return rba_launch_status();
 }
+
+// Linear + GELU whose OUTPUT is the next Linear's split fragment image (Mlp.fc1 -> fc2 of backbone/swin.py:35-41): the operand-swapped
+// pipelined kernel.  x: fp32 rows (x_is_split 0) or a split image (1).  out_frag: ceil(M / 32) * 32 * N * 4 bytes.  N % 32 == 0.
+extern "C" int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_split, const void* weight_packed, const float* bias,
+                                                     void* out_frag, int64_t M, int N, int K, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 32 && (N % 32) == 0 && K >= 32 && (K % 32) == 0);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out_frag && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out_frag | (uintptr_t)bias) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (h3p_single_resident(M, N))
+    rc = x_is_split ? launch_h3p_fout<1, true, 1>(x, wp, bias, out_frag, M, N, K, st) : launch_h3p_fout<1, false, 1>(x, wp, bias, out_frag, M, N, K, st);
+  else
+    rc = x_is_split ? launch_h3p_fout<1, true, 2>(x, wp, bias, out_frag, M, N, K, st) : launch_h3p_fout<1, false, 2>(x, wp, bias, out_frag, M, N, K, st);
+  if (rc) return rc;
+  return rba_launch_status();
+}

@@ -440,6 +440,50 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   }
 }
 
+// Epilogue of the operand-swapped form (FOUT): the MFMAs ran with the weight fragment as A and the activation fragment as B, so a lane
+// holds D^T: row = lane % 32 of its wave's 32 rows, columns n = 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32-wide tile -- four
+// consecutive output channels per register quad.  The output is not an fp32 tensor but the NEXT Linear's split A operand (see "PRE"
+// in the pipelined kernel): value -> bias -> activation -> (h, l) split, one exchange with the lane that holds the other four
+// channels of the 8-channel piece (lane ^ 32), one 16-byte store per piece, 512 contiguous bytes per 32 lanes.  N % 32 == 0.
+template <int ACT, int CT>
+__device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], const f32x16_t (&accl)[CT], const float* __restrict__ bias,
+                                                  void* out_frag, int M, int N, int m0, int n0, int wave, int l31, int lh) {
+  const int row = m0 + 32 * wave + l31;
+  const bool full = m0 + 128 <= M;                                                 // uniform
+  const int NBo = N >> 5;
+  char* base = reinterpret_cast<char*>(out_frag) + ((int64_t)((m0 >> 5) + wave) * NBo) * 4096 + l31 * 16 + lh * 1024;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int nj = n0 + 32 * j;
+    if (nj >= N) break;                                                            // uniform: whole 32-wide blocks only
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nj + 8 * q + 4 * lh;
+      const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x2 y0 = (f32x2){accl[j][4 * q], accl[j][4 * q + 1]} * 0.00048828125f + (f32x2){accm[j][4 * q], accm[j][4 * q + 1]};
+      f32x2 y1 = (f32x2){accl[j][4 * q + 2], accl[j][4 * q + 3]} * 0.00048828125f + (f32x2){accm[j][4 * q + 2], accm[j][4 * q + 3]};
+      y0 = y0 + (f32x2){bv.x, bv.y};
+      y1 = y1 + (f32x2){bv.z, bv.w};
+      if (ACT == 1) {
+        y0 = gelu_erf2(y0);
+        y1 = gelu_erf2(y1);
+      }
+      if (ACT == 2) {
+        y0 = (f32x2){fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f)};
+        y1 = (f32x2){fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f)};
+      }
+      uint32_t h0, l0, h1, l1;
+      rba_split_f16x2(y0.x, y0.y, h0, l0);
+      rba_split_f16x2(y1.x, y1.y, h1, l1);
+      // v_permlane32_swap(h, l): lanes 32-63 of h <-> lanes 0-31 of l.  Afterwards a low lane holds (its h, the partner's h) and a high
+      // lane (the partner's l, its l): exactly the piece each of them stores, in channel order
+      const auto p0 = __builtin_amdgcn_permlane32_swap(h0, l0, false, false), p1 = __builtin_amdgcn_permlane32_swap(h1, l1, false, false);
+      const u32x4_t piece = {p0[0], p1[0], p0[1], p1[1]};
+      if (full || row < M) *reinterpret_cast<u32x4_t*>(base + (int64_t)((nj >> 5)) * 4096 + (q & 1) * 2048 + (q >> 1) * 512) = piece;
+    }
+  }
+}
+
 // ---- f16x3, straight-to-register activations, SOFTWARE-PIPELINED fragment reads (the form used for K > 256 with 128-column
 // tiles).  In the kernels above a wave issues its weight fragment reads, waits for LDS, issues 12 MFMAs, reads again, waits again:
 // per 32-wide block ~2800 cycles for 768 cycles of MFMA (tools/gemm_h3_timing.py; the second workgroup of the CU fills some of
@@ -450,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 // tile 3 computes.  The interleaving is pinned with __builtin_amdgcn_sched_group_barrier (MFMA, DS read, 4 VALU, ...): left to
 // itself the compiler re-serialises reads and MFMAs (83 us instead of 69 us on Swin stage-3 fc1).  Register budget: 128
 // accumulators + 2 x 16 weight fragments + 2 x 16 activation operands + 16 raw activations + 16 weight staging.
-template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false>
+template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false>
 __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
@@ -569,16 +613,20 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
     cyc = __builtin_readcyclecounter();
   }
 
+  // FOUT: operands swapped (D^T = W x^T): same products, same order, the accumulators transposed for h3_epilogue_split
+  auto mm = [](const f16x8_t a, const f16x8_t b, const f32x16_t c) {
+    return FOUT ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  };
 #define RBA_MFMA6(J, Q, P)                                                                                              \
   {                                                                                                                     \
     const f16x8_t bh0 = __builtin_bit_cast(f16x8_t, bq[Q][0]), bl0 = __builtin_bit_cast(f16x8_t, bq[Q][1]);             \
     const f16x8_t bh1 = __builtin_bit_cast(f16x8_t, bq[Q][2]), bl1 = __builtin_bit_cast(f16x8_t, bq[Q][3]);             \
-    accm[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][0], bh0, accm[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][0], bl0, accl[J], 0, 0, 0);                                  \
-    accm[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][1], bh1, accm[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[P][0], bh0, accl[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[P][1], bl1, accl[J], 0, 0, 0);                                  \
-    accl[J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[P][1], bh1, accl[J], 0, 0, 0);                                  \
+    accm[J] = mm(ah[P][0], bh0, accm[J]);                                                                               \
+    accl[J] = mm(ah[P][0], bl0, accl[J]);                                                                               \
+    accm[J] = mm(ah[P][1], bh1, accm[J]);                                                                               \
+    accl[J] = mm(al[P][0], bh0, accl[J]);                                                                               \
+    accl[J] = mm(ah[P][1], bl1, accl[J]);                                                                               \
+    accl[J] = mm(al[P][1], bh1, accl[J]);                                                                               \
   }
   // one 32-wide block with activation operands of parity P; cur / nxt = the LDS buffers of this / the next block
 // scheduling patterns of one column-tile step: the four fragment reads of the next tile (and, in two of the steps, the split of half
@@ -649,7 +697,8 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
     tm[2] = wall_clock64();
     cyc = __builtin_readcyclecounter() - cyc;
   }
-  h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
+  if (FOUT) h3_epilogue_split<ACT, CT>(accm, accl, bias, C, M, N, m0, n0, wave, l31, lh);
+  else h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
@@ -693,6 +742,17 @@ int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const f
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, OCC, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr, res);
+  return 0;
+}
+// out = the split fragment image of act(x W^T + bias) (FOUT); x either fp32 rows or a split image (PRE)
+template <int ACT, bool PRE, int OCC>
+int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* out_frag, int64_t M, int N, int K, hipStream_t st) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 127) / 128;
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, false, OCC, PRE, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
+                     reinterpret_cast<const float*>(x), wp, bias, reinterpret_cast<float*>(out_frag), (int)M, N, K, (int)MT, NT, nullptr,
+                     nullptr);
   return 0;
 }
 template <int OCC>

@@ -191,6 +191,12 @@ extern "C" int rba_split_linear_h3_timing(const float* x, const void* weight_pac
                                                  (hipStream_t)stream, x, wp, bias, out, (int)M, N, K, (int)MT, NT, dbg);
   RBA_H3P_T(0) RBA_H3P_T(3) RBA_H3P_T(67) RBA_H3P_T(323) RBA_H3P_T(579) RBA_H3P_T(1091) RBA_H3P_T(1859) RBA_H3P_T(2048) RBA_H3P_T(2560) RBA_H3P_T(1) RBA_H3P_T(2) RBA_H3P_T(64) RBA_H3P_T(1795) RBA_H3P_T(768) RBA_H3P_T(512) RBA_H3P_T(256)
 #undef RBA_H3P_T
+  else if (probe == 1300)
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, true, false, 2, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias,
+                       out, (int)M, N, K, (int)MT, NT, dbg);
+  else if (probe == 1400)
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, true, false, 1, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias,
+                       out, (int)M, N, K, (int)MT, NT, dbg);
   else if (probe == 1001)
     hipLaunchKernelGGL((split_linear_h3l_kernel<1, 4, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
                        (int)M, N, K, (int)MT, NT, dbg, ConvShape{0, 0, 0});

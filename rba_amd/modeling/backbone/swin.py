@@ -80,9 +80,11 @@ class SwinTransformerBlock(nn.Module):
         if ops.linear_residual_fused(M, C, C):
             # the residual adds ride in the GEMM epilogues (x is updated in place), the LayerNorms read one tensor and write one
             x = ops.linear(y, a.proj, residual=x)
-            y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps,
-                                   frag=ops.linear_takes_split(M, self.mlp.fc1.out_features, C))[1]
-            y = ops.linear(y, self.mlp.fc1, gelu=True)
+            hidden = self.mlp.fc1.out_features
+            # fc2 reads fc1's output as its split operand wherever it runs the pipelined kernel; fc1's own input comes split from
+            # the LayerNorm only where K > 256 (below, the scattered 16-byte stores cost the LayerNorm more than the GEMM gains)
+            y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, frag=ops.linear_takes_split(M, hidden, C))[1]
+            y = ops.linear(y, self.mlp.fc1, gelu=True, split_out=ops.linear_takes_split(M, C, hidden))
             return ops.linear(y, self.mlp.fc2, residual=x), None
         t = ops.linear(y, a.proj, use_bias=False)                        # proj bias rides in the fused add+LN
         x, y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, t, a.proj.bias, inplace_sum=True)

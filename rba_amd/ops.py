@@ -500,10 +500,11 @@ def split_linear_pays(M, N, K, gelu=False):
 
 
 @_hip_op
-def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None):
+def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None, split_out=False):
     """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the split
     kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise.
-    ``residual`` (f16x3 form only, see linear_residual_fused): returns ``(residual + x W^T) + bias`` written IN PLACE over `residual`."""
+    ``residual`` (f16x3 form only, see linear_residual_fused): returns ``(residual + x W^T) + bias`` written IN PLACE over `residual`.
+    ``split_out`` (f16x3, with gelu): the result is returned as SplitActivations for the next linear() (fc1 -> fc2)."""
     w = lin.weight
     N, K = w.shape
     M = x.numel() // K if K else 0
@@ -511,8 +512,12 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None):
     if isinstance(x, SplitActivations):
         if SPLIT_MODE != "f16x3" or x.shape[-1] != K:
             raise RbaHipError("SplitActivations feed the f16x3 Linear only (check linear_takes_split(M, N, K) before producing them)")
-        return split_linear(x, _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
+        return split_linear(x, _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual, split_out=split_out)
     _chk(x, "x") if x.is_contiguous() else _chk(x.contiguous(), "x")          # HIP fp32 tensors only: no CPU path here either
+    if split_out:
+        if SPLIT_MODE != "f16x3" or not split_linear_supported(N, K):
+            raise RbaHipError("linear(split_out=True) needs the f16x3 mode and K % 32 == 0")
+        return split_linear(x.contiguous(), _cached_planes(lin, w), bias, gelu=gelu, out_features=N, split_out=True)
     if split_linear_pays(M, N, K, gelu):
         return split_linear(x.contiguous(), _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
     if residual is not None:
@@ -545,7 +550,7 @@ def linear_residual_fused(M, N, K):
 
 
 @_hip_op
-def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False, residual=None):
+def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False, residual=None, split_out=False):
     """F.linear(x, W, bias) [+ exact GELU] with W given as split_weight(W): fp32-accurate on the bf16 / f16 matrix pipe (the planes'
     dtype says which form they were packed for).
     ``out_features`` = N when it is not a multiple of 128 (the packed planes are padded)."""
@@ -568,6 +573,13 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
     act = 1 if gelu else (2 if relu else 0)
+    if split_out:                            # GELU(x W^T + bias) handed to the next Linear as its split A operand
+        if not f16 or act != 1 or residual is not None or N % 32:
+            raise RbaHipError("split_out needs f16x3 planes, gelu=True, no residual and N % 32 == 0")
+        out = SplitActivations.empty(tuple(x.shape[:-1]) + (N,), x.device)
+        _lib.check(lib.rba_split_linear_f16x3_gelu_split_out(_p(x.data) if pre else _p(x), 1 if pre else 0, _p(planes), _p(bias), _p(out.data),
+                                                             M, N, K, _stream()), "rba_split_linear_f16x3_gelu_split_out")
+        return out
     if residual is not None:                 # out = (residual + x W^T) + bias, in place over `residual` (f16x3 planes, no activation)
         _chk(residual, "residual")
         if not f16 or act or tuple(residual.shape) != tuple(x.shape[:-1]) + (N,):

@@ -407,6 +407,22 @@ def test_split_linear_from_split_activations(ops, M, N, K):
     assert torch.equal(ops.split_linear(xs, planes, None, out_features=N), ops.split_linear(x, planes, None, out_features=N))
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (131072, 512, 128), (3000, 1120, 544), (2048, 4096, 1024), (130, 96, 96), (8192, 256, 512)])
+def test_split_linear_gelu_split_output(ops, M, N, K):
+    """fc1 -> fc2 hand-over: GELU(x W^T + b) written by the operand-swapped GEMM as SplitActivations == pack(fp32 result), bit for bit,
+    from fp32 rows and from a split image, ragged M / N % 128, one and two workgroups per CU."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = dev(torch.randn(M, K, generator=g)), dev(torch.randn(N, K, generator=g) * K ** -0.5), dev(torch.randn(N, generator=g))
+    planes = ops.split_weight(w, mode="f16x3")
+    ref = ops.SplitActivations.pack(ops.split_linear(x, planes, b, gelu=True, out_features=N))
+    nfull = M // 32 * 32 * N
+    for xin in (x, ops.SplitActivations.pack(x)):
+        got = ops.split_linear(xin, planes, b, gelu=True, out_features=N, split_out=True)
+        assert got.shape == (M, N) and torch.equal(got.data[:nfull], ref.data[:nfull]) and torch.equal(got.unpack(), ref.unpack())
+    with pytest.raises(ops.RbaHipError):
+        ops.split_linear(x, planes, b, out_features=N, split_out=True)
+
+
 @pytest.mark.parametrize("rows,C", [(8192, 512), (2048, 1024), (1000, 96), (33, 32), (4100, 1536), (70, 2048)])
 def test_add_layer_norm_split_output(ops, rows, C):
     """add_layer_norm(frag=True): the LayerNorm output written directly as SplitActivations == pack(fp32 output), bit for bit, with and
