@@ -191,6 +191,10 @@ int rba_add_layer_norm_frag_f32(const float* x, const float* t, const float* t_b
                                 float* sum_out, void* y_frag, int64_t rows, int C, float eps, void* stream);
 int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* weight_packed, const float* bias, const float* residual, float* out,
                                     int64_t M, int N, int K, int act, void* stream);
+/*   rba_swin_window_attn_split_out_f32 = rba_swin_window_attn_f32 with the attention output written as the proj Linear's split image
+ *                                     (backbone/swin.py:165-168 -> :169); head_dim 32, 12 x 12 windows, bias_frag required. */
+int rba_swin_window_attn_split_out_f32(const float* qkv, const float* qkv_bias, const float* bias_frag, void* out_frag, int B, int H, int W,
+                                       int nH, int hd, int ws, int shift, void* stream);
 /*   rba_split_linear_f16x3_gelu_split_out = GELU(x W^T + bias) written as the split image of the NEXT Linear (Mlp.fc1 -> fc2,
  *                                     backbone/swin.py:35-41): the GEMM runs with its MFMA operands swapped (D^T = W x^T), so a lane ends
  *                                     up with consecutive output channels of one row and stores 16-byte pieces.  x: fp32 rows

@@ -27,6 +27,7 @@ SIGNATURES = {
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_mask_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],
     "rba_swin_window_attn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_swin_window_attn_split_out_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_bias_fragments_elems": [_i, _i],
     "rba_swin_bias_fragments_f32": [_vp, _vp, _i, _i, _vp],
     "rba_skinny_linear_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -58,7 +59,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 177        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 178        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -388,3 +388,20 @@ extern "C" int rba_swin_window_attn_f32(const float* qkv, const float* qkv_bias,
 #undef RBA_L
   return rba_launch_status();
 }
+
+// The same attention with the output written as the proj Linear's split A operand (rba_split_linear_f16x3_frag_f32): image of
+// [B * H * W, nH * 32] rows (ceil(rows / 32) * 32 * C * 4 bytes).  Only the f16x3 matrix-pipe form has this epilogue: head_dim 32,
+// 12 x 12 windows, bias_frag required (hipErrorInvalidValue otherwise: the caller keeps the fp32 entry point for other geometries).
+extern "C" int rba_swin_window_attn_split_out_f32(const float* qkv, const float* qkv_bias, const float* bias_frag, void* out_frag, int B,
+                                                  int H, int W, int nH, int hd, int ws, int shift, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && nH >= 1 && hd == 32 && ws == 12 && shift >= 0 && shift < ws);
+  if (B == 0) return 0;
+  RBA_CHECK_ARG(qkv && qkv_bias && bias_frag && out_frag);
+  RBA_CHECK_ARG((((uintptr_t)qkv | (uintptr_t)qkv_bias | (uintptr_t)out_frag) & 15) == 0);
+  const int Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;
+  RBA_CHECK_ARG((int64_t)B * nH <= 65535 && Hp / ws <= 65535);
+  rba_begin();
+  const float scale = (float)(1.0 / sqrt((double)hd));
+  return launch_h3<9, 9>(qkv, qkv_bias, nullptr, bias_frag, reinterpret_cast<float*>(out_frag), B, H, W, Hp, Wp, nH, ws, shift, scale,
+                         (hipStream_t)stream, true);
+}

@@ -34,7 +34,7 @@ __device__ __forceinline__ void k5h_split2(float a, float b, uint32_t& h, uint32
   l = r;
 }
 
-template <int NT, int WAVES, bool FRAG>
+template <int NT, int WAVES, bool FRAG, bool SOUT = false>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8))) void swin_window_attn_h3_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias, float* __restrict__ out,
     int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale) {
@@ -248,21 +248,38 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
         const uint2 u2 = __builtin_bit_cast(uint2, r2), u3 = __builtin_bit_cast(uint2, r3);
         const k5h_f16x8 vh = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u0.x, u0.y, u1.x, u1.y});
         const k5h_f16x8 vl = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u2.x, u2.y, u3.x, u3.y});
-        Om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vh, Om[dt], 0, 0, 0);
-        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vl, Ol[dt], 0, 0, 0);
-        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, vh, Ol[dt], 0, 0, 0);
+        // O^T = V^T P^T (V as the A operand, P as B: the same register contents, swapped): the lane ends up with four consecutive
+        // head-dim channels of ONE query instead of one channel of four queries -- 16-byte stores, and the pairing the split output needs
+        Om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pa, Om[dt], 0, 0, 0);
+        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, pa, Ol[dt], 0, 0, 0);
+        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pb, Ol[dt], 0, 0, 0);
       }
     }
-    // ---- scatter: lane holds O[query = strip*16 + 4*kk + r][d = l15 (+16)]
+    // ---- scatter: lane holds O[query = strip*16 + l15][d = 16 dt + 4 kk + r]
+    const float inv = 1.0f / lsum;
+    const int t = tok[strip * 16 + l15];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qi = kk * 4 + r;
-      const float inv = 1.0f / __shfl(lsum, qi, RBA_WAVE);
-      const int t = tok[strip * 16 + qi];
-      if (t >= 0) {
-        float* o = out + ((int64_t)b * H * W + t) * C + h * HD + l15;
-        o[0] = fmaf(Ol[0][r], 0.00048828125f, Om[0][r]) * inv;
-        o[16] = fmaf(Ol[1][r], 0.00048828125f, Om[1][r]) * inv;
+    for (int dt = 0; dt < 2; ++dt) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = fmaf(Ol[dt][r], 0.00048828125f, Om[dt][r]) * inv;
+      if (SOUT) {
+        // the proj Linear's split A operand (split_linear_h3.h, "PRE"): channel c = 32 h + 16 dt + 4 kk + r -> block h, piece
+        // (g = kk / 2, h|l), k-half dt; the 8-channel piece is completed by the lane of the neighbouring kk (lane ^ 16):
+        // v_permlane16_swap(h, l) leaves an even-kk lane with (its h, the partner's h) and an odd-kk lane with (the partner's l, its l)
+        uint32_t h0, l0, h1, l1;
+        rba_split_f16x2(o.x, o.y, h0, l0);
+        rba_split_f16x2(o.z, o.w, h1, l1);
+        const auto p0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false), p1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
+        const rba_u32x4 piece = {p0[0], p1[0], p0[1], p1[1]};
+        if (t >= 0) {
+          const int64_t row = (int64_t)b * H * W + t;
+          char* dst = reinterpret_cast<char*>(out) + ((row >> 5) * nH + h) * 4096 + ((kk >> 1) * 2 + (kk & 1)) * 1024 +
+                      (dt * 32 + (int)(row & 31)) * 16;
+          *reinterpret_cast<rba_u32x4*>(dst) = piece;
+        }
+      } else if (t >= 0) {
+        *reinterpret_cast<f32x4*>(out + ((int64_t)b * H * W + t) * C + h * HD + 16 * dt + 4 * kk) = o;
       }
     }
   }
@@ -270,9 +287,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
 
 template <int NT, int WAVES>
 int launch_h3(const float* qkv, const float* qkv_bias, const float* bias, const float* bias_frag, float* out, int B, int H, int W,
-              int Hp, int Wp, int nH, int ws, int shift, float scale, hipStream_t st) {
+              int Hp, int Wp, int nH, int ws, int shift, float scale, hipStream_t st, bool split_out = false) {
   const size_t shm = (size_t)(4 * NT * 16 * 64) + (size_t)(2 * NT * 16) * sizeof(int);
   const dim3 grid(Wp / ws, Hp / ws, B * nH), block(64 * WAVES);
+  if (split_out) {
+    if (!bias_frag) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, true, true>), grid, block, shm, st, qkv, qkv_bias, bias_frag, out, H, W, Hp,
+                       Wp, nH, ws, shift, scale);
+    return rba_launch_status();
+  }
   if (bias_frag)
     hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, true>), grid, block, shm, st, qkv, qkv_bias, bias_frag, out, H, W, Hp, Wp,
                        nH, ws, shift, scale);

@@ -75,9 +75,11 @@ class SwinTransformerBlock(nn.Module):
                                   frag=ops.linear_takes_split(M, 3 * C, C))
         qkv = ops.linear(y, a.qkv)
         bias, bias_frag = a.gathered_bias()
-        y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size,
-                                 bias_frag=bias_frag)
-        if ops.linear_residual_fused(M, C, C):
+        fused = ops.linear_residual_fused(M, C, C)
+        y = ops.swin_window_attn(qkv, a.qkv.bias, bias, H, W, self.num_heads, self.window_size, self.shift_size, bias_frag=bias_frag,
+                                 split_out=fused and bias_frag is not None and ops.linear_takes_split(M, C, C) and
+                                 ops.swin_window_attn_split_ok(C // self.num_heads, self.window_size))
+        if fused:
             # the residual adds ride in the GEMM epilogues (x is updated in place), the LayerNorms read one tensor and write one
             x = ops.linear(y, a.proj, residual=x)
             hidden = self.mlp.fc1.out_features

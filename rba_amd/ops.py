@@ -248,8 +248,13 @@ def swin_bias_fragments(rel_bias, window_size):
     return frag
 
 
+def swin_window_attn_split_ok(head_dim, window_size):
+    """Geometries whose window-attention kernel can write SplitActivations (the f16x3 matrix-pipe form)."""
+    return head_dim == 32 and window_size == 12
+
+
 @_hip_op
-def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shift, bias_frag=None):
+def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shift, bias_frag=None, split_out=False):
     """K5.  qkv [B,H*W,3*C] = Linear(norm1(x)) on un-padded tokens, qkv_bias [3*C], rel_bias [nH,N,N] ->
     attention output [B,H*W,C] (before proj).  swin.py:131-171 + :251-284 + :413-440."""
     lib = _lib.load()
@@ -268,6 +273,13 @@ def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shif
         _chk(bias_frag, "bias_frag", dim=1)
         if bias_frag.numel() != lib.rba_swin_bias_fragments_elems(num_heads, window_size):
             raise RbaHipError("bias_frag has the wrong size")
+    if split_out:                                   # the proj Linear's split A operand (see swin_window_attn_split_ok)
+        if not swin_window_attn_split_ok(hd, window_size) or bias_frag is None:
+            raise RbaHipError("split_out needs head_dim 32, 12 x 12 windows and bias_frag")
+        out = SplitActivations.empty((B, L, C), qkv.device)
+        _lib.check(lib.rba_swin_window_attn_split_out_f32(_p(qkv), _p(qkv_bias), _p(bias_frag), _p(out.data), B, H, W, num_heads, hd,
+                                                          window_size, shift, _stream()), "rba_swin_window_attn_split_out_f32")
+        return out
     out = torch.empty((B, L, C), dtype=torch.float32, device=qkv.device)
     _lib.check(lib.rba_swin_window_attn_f32(_p(qkv), _p(qkv_bias), _p(rel_bias), _p(bias_frag), _p(out), B, H, W,
                                             num_heads, hd, window_size, shift, _stream()), "rba_swin_window_attn_f32")

@@ -275,6 +275,14 @@ def test_k5_window_attn_core(ops, H, W, ws, nH, shift):
     frag = ops.swin_bias_fragments(dev(bias), ws)            # coalesced fragment-ordered bias: same result
     out2 = ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag)
     assert torch.equal(out2, out)
+    if ops.swin_window_attn_split_ok(32, ws):               # the proj Linear's split operand written by the attention kernel itself
+        so = ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag, split_out=True)
+        want = ops.SplitActivations.pack(out)
+        nfull = (B * H * W) // 32 * 32 * C
+        assert so.shape == (B, H * W, C) and torch.equal(so.data[:nfull], want.data[:nfull]) and torch.equal(so.unpack(), want.unpack())
+    else:
+        with pytest.raises(ops.RbaHipError):
+            ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag, split_out=True)
 
 
 # ----------------------------------------------------------------------------------- GroupNorm
