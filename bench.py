@@ -437,19 +437,26 @@ def main():
             lin = model.backbone.layers[2].blocks[0].mlp.fc1
             if ops.split_linear_pays(M3, lin.weight.shape[0], lin.weight.shape[1], True):
                 xg = torch.randn(M3, C3, device=dev)
+                # the launch form the step uses: where the pipelined kernel runs, its A operand arrives as the LayerNorm's split image
+                # and its output leaves as fc2's split image (ops.SplitActivations)
+                N3, K3 = lin.weight.shape
+                s_in, s_out = ops.linear_takes_split(M3, N3, K3), ops.linear_takes_split(M3, K3, N3)
+                if s_in:
+                    xg = ops.SplitActivations.pack(xg)
                 with torch.no_grad():
                     for _ in range(3):
-                        ops.linear(xg, lin, gelu=True)
+                        ops.linear(xg, lin, gelu=True, split_out=s_out)
                     evs = []
                     for _ in range(10):
                         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                        e0.record(); ops.linear(xg, lin, gelu=True); e1.record()
+                        e0.record(); ops.linear(xg, lin, gelu=True, split_out=s_out); e1.record()
                         evs.append((e0, e1))
                 torch.cuda.synchronize()
                 g_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
                 flops32 = 2.0 * M3 * lin.weight.shape[0] * lin.weight.shape[1]
                 prods = 3.0 if ops.SPLIT_MODE == "f16x3" else 6.0
-                gemm = {"bound": "mfma", "kernel": ("split_linear_h3_kernel<GELU>" if prods == 3.0 else "split_linear_v4_kernel<GELU>") + " (fc1 of Swin stage 3)",
+                gemm = {"bound": "mfma", "kernel": ("split_linear_h3p_kernel<GELU>" if prods == 3.0 else "split_linear_v4_kernel<GELU>") + " (fc1 of Swin stage 3)",
+                        "operands": {"activations_in": "split image" if s_in else "fp32 rows", "out": "split image" if s_out else "fp32 rows"},
                         "shape_MNK": [M3, lin.weight.shape[0], lin.weight.shape[1]], "split_mode": ops.SPLIT_MODE,
                         "achieved": prods * flops32 / (g_ms * 1e-3) / 1e12, "peak": BF16_PEAK_TFLOPS,
                         "unit": f"TFLOP/s ({'f16' if prods == 3.0 else 'bf16'} MFMA, {int(prods)} products per fp32 product; dense f16 = bf16 peak)",

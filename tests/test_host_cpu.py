@@ -263,3 +263,33 @@ def test_reference_resnet_and_densehybrid_configs_parse():
     assert a["resnet"]["depth"] == 101 and a["dec_layers"] == 1
     a = A.arch_from_cfg(load_cfg(base + "densehybrid/maskformer2_swin_base_IN21k_384_bs16_90k_1dl_densehybrid_cocomix_finetune.yaml"))
     assert a["dense_hybrid"] is True and a["embed_dim"] == 128 and a["dec_layers"] == 1
+
+
+def test_split_activations_layout_and_predicate():
+    """ops.SplitActivations.pack is the layout contract of include/rba_hip.h ("Split activations"): checked element by element against
+    the index formula, and unpack() inverts it; linear_takes_split mirrors the C dispatch (K > 256, >= 160 tiles, f16x3 mode)."""
+    import numpy as np
+    from rba_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, K = 70, 96
+    x = torch.randn(M, K, generator=g) * 5
+    sa = ops.SplitActivations.pack(x)
+    assert sa.shape == (M, K) and sa.data.dtype == torch.int32 and sa.data.numel() == 96 * K      # rows padded to 96
+    img = sa.data.view(torch.float16).numpy()
+    h = x.half()
+    l = ((x - h.float()) * 2048.0).half()
+    NB = K // 32
+    for row, k in ((0, 0), (1, 7), (31, 8), (32, 16), (33, 31), (69, 95), (45, 40), (64, 63)):
+        rg, l31, b, half, gsel, i = row >> 5, row & 31, k >> 5, (k >> 4) & 1, (k >> 3) & 1, k & 7
+        base = ((rg * NB + b) * 4096 + (2 * gsel) * 1024 + (half * 32 + l31) * 16) // 2 + i            # f16 units
+        assert img[base] == h[row, k].numpy() and img[base + 512] == l[row, k].numpy()
+    un = sa.unpack()
+    assert un.shape == (M, K) and float((un - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -21
+    old = ops.SPLIT_MODE
+    try:
+        assert ops.linear_takes_split(8192, 2048, 512) and ops.linear_takes_split(8192, 512, 2048)
+        assert not ops.linear_takes_split(32768, 768, 256) and not ops.linear_takes_split(2048, 1024, 1024)
+        ops.SPLIT_MODE = "bf16x6"
+        assert not ops.linear_takes_split(8192, 2048, 512)
+    finally:
+        ops.SPLIT_MODE = old
