@@ -26,6 +26,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (same guide; the 5 PFLOP/s headline is with 2:1 sparsity)
+MFMA_F16_SUSTAINED_TFLOPS = 2090.0          # measured: 256 workgroups of back-to-back v_mfma_f32_32x32x16_f16 (tools/micro/mfma_rate.hip)
 
 
 def parse():
@@ -464,6 +465,10 @@ def main():
                         # the rate a SIX-product (bf16x6) kernel would need for the same launch time, as a fraction of the same peak: the
                         # round-1 / VERDICT yardstick (0.38 then), comparable across the two arithmetic forms
                         "six_product_equivalent_frac": 6.0 * flops32 / (g_ms * 1e-3) / 1e12 / BF16_PEAK_TFLOPS,
+                        # the rate the whole chip sustains on back-to-back f16 MFMAs (tools/micro/mfma_rate.hip, profiles/r02_k6_h3p_ablation.txt:
+                        # 2.04 GHz under that load, not the 2.4 GHz of the nominal figure) and the fraction of THAT
+                        "peak_sustained_measured": MFMA_F16_SUSTAINED_TFLOPS,
+                        "frac_of_sustained": prods * flops32 / (g_ms * 1e-3) / 1e12 / MFMA_F16_SUSTAINED_TFLOPS,
                         "avg_launch_ms": g_ms, "launches_timed": len(evs)}
         except Exception as e:                                           # informational only
             print(f"[bench] K6 roofline probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
