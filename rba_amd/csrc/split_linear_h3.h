@@ -494,8 +494,14 @@ __device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], co
 // tile 3 computes.  The interleaving is pinned with __builtin_amdgcn_sched_group_barrier (MFMA, DS read, 4 VALU, ...): left to
 // itself the compiler re-serialises reads and MFMAs (83 us instead of 69 us on Swin stage-3 fc1).  Register budget: 128
 // accumulators + 2 x 16 weight fragments + 2 x 16 activation operands + 16 raw activations + 16 weight staging.
-template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false>
-__global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+// KS = 2 (single-resident launches: at most one 128 x 128 tile per CU): the workgroup has EIGHT waves, two per SIMD; waves 4-7 are a second
+// copy of waves 0-3 that works on the odd 32-wide blocks of K (own weight ring in LDS, same barriers), so that every SIMD has a second
+// wave to issue from while the first waits -- what a second workgroup does for the larger launches.  After the loop the odd half's
+// accumulators are added to the even half's through LDS (two passes of 64 KiB, fixed order: deterministic) and waves 0-3 run the epilogue.
+// Instantiated by the tune library only (cfg 6004 / 6104): fc2 of Swin stage 3 62.6 -> 59.3 us, proj unchanged (26.4 us), and the halves'
+// summation order differs from the one-set kernel's -- not worth a second numerical form in the product.
+template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
                                                                  const float* R = nullptr) {
@@ -503,16 +509,18 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
   if (TIMING) tm[0] = wall_clock64();
   constexpr int CT = 4, BM = 128, BN = 128;
   constexpr int SUBW = 4 * BN, BLK = 2 * SUBW, UPL = BLK / 256;
-  __shared__ __attribute__((aligned(16))) u32x4_t lds[2 * BLK];
+  __shared__ __attribute__((aligned(16))) u32x4_t lds_all[2 * BLK * KS];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int ks = KS == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;     // which half of the k blocks
+  u32x4_t* const lds = lds_all + ks * 2 * BLK;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int nb = MT * NT;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   const int mt = bid / NT, nt = bid - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int NB = K >> 5, S16 = K >> 4;
+  const int NB = (K >> 5) / KS, S16 = K >> 4;                                       // NB: blocks THIS wave set walks (K / 32 even when KS = 2)
   const int l31 = lane & 31, lh = lane >> 5;
 
   const char* wbase = reinterpret_cast<const char*>(Wp + (int64_t)(n0 >> 7) * S16 * 512);
@@ -529,35 +537,37 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
     for (int r = 0; r < 16; ++r) accm[j][r] = accl[j][r] = 0.f;
 
   u32x4_t wr[UPL];
-  constexpr bool DEEP = OCC == 1;                                                  // registers to spare: activations two blocks ahead
-  constexpr bool DIRECT = PRE && OCC == 2;                                         // pieces straight into the next block's operand set
+  constexpr bool TWO = OCC == 2 || KS == 2;                                        // two waves per SIMD: 256 registers each
+  constexpr bool DEEP = !TWO;                                                      // registers to spare: activations two blocks ahead
+  constexpr bool DIRECT = PRE && TWO;                                              // pieces straight into the next block's operand set
   f32x4 xr[DEEP ? 2 : 1][4];
   f16x8_t ah[2][2], al[2][2];                                                      // [block parity][g]
   u32x4_t bq[2][4];                                                                // [column-tile parity][h g0, l g0, h g1, l g1]
   const int last = NB - 1;
+  auto bix = [&](int c) { return (c < last ? c : last) * KS + ks; };               // global 32-wide block of this set's step c (clamped)
   auto wload = [&](int c) {
-    const char* src = wbase + (int64_t)(c < last ? c : last) * 16384;
+    const char* src = wbase + (int64_t)bix(c) * 16384;
 #pragma unroll
     for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(src + q * 4096 + woff);
   };
   // PRE: A is the producer's fragment-ordered, already split image (frag_layout.h): per (32-row group, 32-wide block) four 1 KiB
   // pieces [h g0 | l g0 | h g1 | l g1], each [lane][8 f16] -- one contiguous wave load per operand register quad, no arithmetic here
   const int rgrp = min((m0 >> 5) + wave, ((M + 31) >> 5) - 1);
-  const char* fbase = reinterpret_cast<const char*>(A) + ((int64_t)rgrp * NB) * 4096 + lane * 16;
+  const char* fbase = reinterpret_cast<const char*>(A) + ((int64_t)rgrp * (K >> 5)) * 4096 + lane * 16;
   auto xload = [&](int c, f32x4 (&d)[4]) {
     if (PRE) {
-      const char* src = fbase + (c < last ? c : last) * 4096;
+      const char* src = fbase + bix(c) * 4096;
 #pragma unroll
       for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(src + q * 1024);
       return;
     }
     if (PROBE & 2048) {                                                            // ablation: the same bytes as contiguous 1 KiB wave loads
-      const char* src = xbase + (uint32_t)(32 * wave) * (uint32_t)K * 4u + (c < last ? c : last) * 4096 + lane * 16;
+      const char* src = xbase + (uint32_t)(32 * wave) * (uint32_t)K * 4u + bix(c) * 4096 + lane * 16;
 #pragma unroll
       for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(src + q * 1024);
       return;
     }
-    const char* src = xbase + (c < last ? c : last) * 128;
+    const char* src = xbase + bix(c) * 128;
 #pragma unroll
     for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const f32x4*>(src + q * 16 + xoff);
   };
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
   };
 
   auto xloadset = [&](int c, int p) {
-    const char* src = fbase + (c < last ? c : last) * 4096;
+    const char* src = fbase + bix(c) * 4096;
     ah[p][0] = *reinterpret_cast<const f16x8_t*>(src);
     al[p][0] = *reinterpret_cast<const f16x8_t*>(src + 1024);
     ah[p][1] = *reinterpret_cast<const f16x8_t*>(src + 2048);
@@ -697,6 +707,38 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
     tm[2] = wall_clock64();
     cyc = __builtin_readcyclecounter() - cyc;
   }
+  if (KS == 2) {
+    // odd-block half -> even-block half, 16 units per thread per pass: [group of four registers][thread]
+    f32x4* red = reinterpret_cast<f32x4*>(lds_all);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();                                                             // ring (pass 0) / previous pass read
+      if (ks == 1) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x16_t& a = pass ? accl[j] : accm[j];
+            red[(j * 4 + q) * 256 + tid] = (f32x4){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+          }
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = red[(j * 4 + q) * 256 + tid];
+            f32x16_t& a = pass ? accl[j] : accm[j];
+            a[4 * q] += v.x;
+            a[4 * q + 1] += v.y;
+            a[4 * q + 2] += v.z;
+            a[4 * q + 3] += v.w;
+          }
+      }
+    }
+    if (ks == 1) return;
+  }
   if (FOUT) h3_epilogue_split<ACT, CT>(accm, accl, bias, C, M, N, m0, n0, wave, l31, lh);
   else h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
@@ -708,13 +750,13 @@ __global__ __launch_bounds__(256, OCC) void split_linear_h3p_kernel(const float*
   }
 }
 
-template <int ACT, int PROBE = 0, int OCC = 2>
+template <int ACT, int PROBE = 0, int OCC = 2, int KS = 1>
 int launch_h3p(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t stream) {
   const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, PROBE, false, false, OCC>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out, (int)M, N, K,
-                     (int)MT, NT, nullptr);
+  hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, PROBE, false, false, OCC, false, false, KS>), dim3((unsigned)(MT * NT)), dim3(256 * KS), 0, stream, x,
+                     wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr);
   return 0;
 }
 

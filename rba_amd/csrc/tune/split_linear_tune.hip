@@ -140,6 +140,20 @@ extern "C" int rba_split_linear_h3_tune(const float* x, const void* weight_packe
       rc = act == 1 ? launch_h3p<1, 0, 1>(x, wp, bias, out, M, N, K, st) : act == 2 ? launch_h3p<2, 0, 1>(x, wp, bias, out, M, N, K, st)
                                                                                       : launch_h3p<0, 0, 1>(x, wp, bias, out, M, N, K, st);
       break;
+    case 6004:
+      rc = act == 1 ? launch_h3p<1, 0, 1, 2>(x, wp, bias, out, M, N, K, st) : act == 2 ? launch_h3p<2, 0, 1, 2>(x, wp, bias, out, M, N, K, st)
+                                                                                         : launch_h3p<0, 0, 1, 2>(x, wp, bias, out, M, N, K, st);
+      break;
+    case 6104: {                                                                     // timing only: x read as if it were a split image
+      const int64_t MT = (M + 127) / 128; const int NT = (N + 127) / 128;
+      hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 1, true, false, 2>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, x, wp, bias, out,
+                         (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
+    case 5104: {
+      const int64_t MT = (M + 127) / 128; const int NT = (N + 127) / 128;
+      hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 1, true, false, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out,
+                         (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
     case 4044: rc = launch_h3p<1, 4>(x, wp, bias, out, M, N, K, st); break;
     case 4014: rc = launch_h3p<1, 1>(x, wp, bias, out, M, N, K, st); break;
     case 4024: rc = launch_h3p<1, 2>(x, wp, bias, out, M, N, K, st); break;
