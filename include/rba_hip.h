@@ -195,6 +195,13 @@ int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* weight_packe
  *                                     (backbone/swin.py:165-168 -> :169); head_dim 32, 12 x 12 windows, bias_frag required. */
 int rba_swin_window_attn_split_out_f32(const float* qkv, const float* qkv_bias, const float* bias_frag, void* out_frag, int B, int H, int W,
                                        int nH, int hd, int ws, int shift, void* stream);
+/*   rba_resample_bilinear_nhwc_split_out_f32 -> rba_conv3x3_nhwc_f16x3_split_in_f32 = the FPN's `lateral + F.interpolate(prev)` sum handed to
+ *                                     its 3 x 3 output convolution as a split image of [B H W, C] rows (pixel_decoder/msdeformattn.py:352-361);
+ *                                     the convolution (>= 256 tiles of 128 x 128) gathers the pieces of the neighbour pixels' rows. */
+int rba_resample_bilinear_nhwc_split_out_f32(const float* in, const float* add, void* out_frag, int C, int h, int w, int H, int W,
+                                             int64_t row0, void* stream);
+int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const void* weight_packed, const float* bias, float* out, int B, int H, int W,
+                                        int C, int N, void* stream);
 /*   rba_split_linear_f16x3_gelu_split_out = GELU(x W^T + bias) written as the split image of the NEXT Linear (Mlp.fc1 -> fc2,
  *                                     backbone/swin.py:35-41): the GEMM runs with its MFMA operands swapped (D^T = W x^T), so a lane ends
  *                                     up with consecutive output channels of one row and stores 16-byte pieces.  x: fp32 rows

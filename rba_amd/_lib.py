@@ -41,6 +41,8 @@ SIGNATURES = {
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f16x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_conv3x3_nhwc_f16x3_split_in_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "rba_resample_bilinear_nhwc_split_out_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp],
     "rba_patch_im2col_u8": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "rba_patch_im2col_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "rba_group_norm_nhwc_workspace_bytes": [_i, _i, _i, _i],
@@ -59,7 +61,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 178        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 179        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

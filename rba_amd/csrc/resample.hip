@@ -60,15 +60,30 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 
 // channels-last variant: in [h, w, C] -> out [H, W, C] (+ add).  A thread owns one float4 of channels of one output pixel:
 // the four taps are four contiguous 16-byte loads, a wave covers whole pixel rows.  Same tap arithmetic as above.
-template <bool ADD>
+// SOUT: the result is written as the split image of the 3 x 3 convolution that consumes it (split_linear_h3.h "PRE" / "CONVP"): row =
+// row0 + pixel, the lane pair of an 8-channel piece exchanges halves with one DPP move (as the LayerNorm does).  C % 32 == 0.
+template <bool ADD, bool SOUT = false>
 __global__ __launch_bounds__(256) void resample_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ add,
                                                             float* __restrict__ out, int C4, int h, int w, int H, int W, float sh,
-                                                            float sw) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)H * W * C4;
-  if (idx >= total) return;
-  const int j = (int)(idx % C4);
-  const int64_t pix = idx / C4;
+                                                            float sw, int64_t row0 = 0) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int j;
+  int64_t pix;
+  if (SOUT) {
+    // a wave = 8 consecutive pixels x one 32-channel block (8 lanes x 16 bytes = the pixel's whole 128-byte line of `add`): the 8 pixels'
+    // pieces of one (k-half, g, h|l) column are 128 contiguous bytes of the image, so every store instruction writes whole lines
+    const int64_t wv = idx >> 6;
+    const int ln = (int)(idx & 63), nblk = C4 >> 3;
+    j = (int)(wv % nblk) * 8 + (ln & 7);
+    pix = (wv / nblk) * 8 + (ln >> 3);
+    if (pix >= (int64_t)H * W) return;
+    idx = pix * C4 + j;
+  } else {
+    const int64_t total = (int64_t)H * W * C4;
+    if (idx >= total) return;
+    j = (int)(idx % C4);
+    pix = idx / C4;
+  }
   const int x = (int)(pix % W), y = (int)(pix / W);
   const BilinearTap ty = bilinear_tap(y, sh, h), tx = bilinear_tap(x, sw, w);
   const f32x4* ip = reinterpret_cast<const f32x4*>(in) + j;
@@ -82,7 +97,22 @@ __global__ __launch_bounds__(256) void resample_nhwc_kernel(const float* __restr
     r[k] = ty.l0 * top + ty.l1 * bot;
   }
   if (ADD) r += reinterpret_cast<const f32x4*>(add)[idx];
-  reinterpret_cast<f32x4*>(out)[idx] = r;
+  if (SOUT) {
+    uint32_t hh[2], ll[2];
+    rba_split_f16x2(r.x, r.y, hh[0], ll[0]);
+    rba_split_f16x2(r.z, r.w, hh[1], ll[1]);
+    const bool odd = j & 1;                                                        // C4 is even: the pair (j, j ^ 1) is a lane pair
+    const uint32_t s0 = odd ? hh[0] : ll[0], s1 = odd ? hh[1] : ll[1];
+    const uint32_t r0 = __builtin_amdgcn_mov_dpp(s0, 0xB1, 0xf, 0xf, true), r1 = __builtin_amdgcn_mov_dpp(s1, 0xB1, 0xf, 0xf, true);
+    const rba_u32x4 piece = odd ? (rba_u32x4){r0, r1, ll[0], ll[1]} : (rba_u32x4){hh[0], hh[1], r0, r1};
+    const int64_t row = row0 + pix;
+    const int k8 = j >> 1;
+    const int64_t off = ((row >> 5) * (int64_t)(C4 >> 3) + (k8 >> 2)) * 4096 + ((k8 & 1) * 2 + (odd ? 1 : 0)) * 1024 +
+                        (((k8 >> 1) & 1) * 32 + (int)(row & 31)) * 16;
+    *reinterpret_cast<rba_u32x4*>(reinterpret_cast<char*>(out) + off) = piece;
+  } else {
+    reinterpret_cast<f32x4*>(out)[idx] = r;
+  }
 }
 
 }  // namespace
@@ -125,5 +155,25 @@ extern "C" int rba_resample_bilinear_nhwc_f32(const float* in, const float* add,
     hipLaunchKernelGGL(resample_nhwc_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, add, out, C >> 2, h, w, H, W, sh, sw);
   else
     hipLaunchKernelGGL(resample_nhwc_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, add, out, C >> 2, h, w, H, W, sh, sw);
+  return rba_launch_status();
+}
+
+// rba_resample_bilinear_nhwc_f32 with the result written as rows row0 .. row0 + H W - 1 of a split image of C-channel rows (the A operand
+// of rba_conv3x3_nhwc_f16x3_split_in_f32).  C % 32 == 0; total threads a multiple of 2 per pixel, so a lane pair never straddles pixels.
+extern "C" int rba_resample_bilinear_nhwc_split_out_f32(const float* in, const float* add, void* out_frag, int C, int h, int w, int H, int W,
+                                                        int64_t row0, void* stream) {
+  RBA_CHECK_ARG(C >= 32 && (C % 32) == 0 && h >= 1 && w >= 1 && H >= 0 && W >= 0 && row0 >= 0);
+  if (H == 0 || W == 0) return 0;
+  RBA_CHECK_ARG(in && out_frag && (((uintptr_t)in | (uintptr_t)add | (uintptr_t)out_frag) & 15) == 0);
+  const int64_t total = (((int64_t)H * W + 7) / 8) * 8 * (C >> 2);                   // whole 8-pixel groups: a multiple of 64 threads
+  RBA_CHECK_ARG((total + 255) / 256 <= 0x7fffffffLL);                              // (row0 % 8 != 0 only splits the 128-byte runs)
+  rba_begin();
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  float* o = reinterpret_cast<float*>(out_frag);
+  if (add)
+    hipLaunchKernelGGL((resample_nhwc_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, in, add, o, C >> 2, h, w, H, W, sh, sw, row0);
+  else
+    hipLaunchKernelGGL((resample_nhwc_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, add, o, C >> 2, h, w, H, W, sh, sw, row0);
   return rba_launch_status();
 }

@@ -137,3 +137,19 @@ extern "C" int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_spl
   if (rc) return rc;
   return rba_launch_status();
 }
+
+// The same convolution reading the split image of x (rba_resample_bilinear_nhwc_split_out_f32 writes it: the FPN's `lateral + upsample`
+// sum feeds only this convolution, pixel_decoder/msdeformattn.py:352-361): the pipelined kernel, no activation arithmetic.  x_frag =
+// image of [B H W, C] rows.  For launches of at least 256 tiles of 128 x 128 (the caller keeps the fp32 entry point otherwise).
+extern "C" int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const void* weight_packed, const float* bias, float* out, int B, int H,
+                                                   int W, int C, int N, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && C >= 32 && (C % 32) == 0 && C <= 2048 && N >= 1);
+  const int64_t M = (int64_t)B * H * W;
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x_frag && weight_packed && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x_frag | (uintptr_t)weight_packed | (uintptr_t)out | (uintptr_t)bias) & 15) == 0);
+  rba_begin();
+  const int rc = launch_h3p_conv_pre(x_frag, reinterpret_cast<const u32x4_t*>(weight_packed), bias, out, M, N, H, W, C, (hipStream_t)stream);
+  if (rc) return rc;
+  return rba_launch_status();
+}

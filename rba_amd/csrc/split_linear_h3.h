@@ -500,11 +500,15 @@ __device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], co
 // accumulators are added to the even half's through LDS (two passes of 64 KiB, fixed order: deterministic) and waves 0-3 run the epilogue.
 // Instantiated by the tune library only (cfg 6004 / 6104): fc2 of Swin stage 3 62.6 -> 59.3 us, proj unchanged (26.4 us), and the halves'
 // summation order differs from the one-set kernel's -- not worth a second numerical form in the product.
-template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false, int KS = 1>
+// CONVP (with PRE, two workgroups per CU): the 3 x 3 convolution as an implicit GEMM over the producer's split image of the NHWC input
+// (rows = pixels, K = 9 Cin, k = tap * Cin + channel): the four pieces of a lane's row for block (tap, channel block) are the pieces
+// of the NEIGHBOUR pixel's row (row + dy W + dx) -- 32 lanes still read one or two contiguous runs -- zeroed where the tap leaves the image.
+template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false, int KS = 1,
+          bool CONVP = false>
 __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
-                                                                 const float* R = nullptr) {
+                                                                 const float* R = nullptr, ConvShape cs = ConvShape{0, 0, 0}) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int CT = 4, BM = 128, BN = 128;
@@ -579,7 +583,33 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_
     d[3] = img[SUBW + fb + 2 * BN + 64 * j];
   };
 
+  // CONVP: this lane's output pixel and the per-tap source row
+  int cpy = 0, cpx = 0, crow = 0, cNB = 1, cinv = 0;
+  if (CONVP) {
+    crow = min(m0 + 32 * wave + l31, M - 1);
+    const int pix = crow % (cs.H * cs.W);
+    cpy = pix / cs.W;
+    cpx = pix - cpy * cs.W;
+    cNB = cs.Cin >> 5;
+    cinv = (65536 + cNB - 1) / cNB;                                                // block / cNB == (block * cinv) >> 16 for block < 9 * cNB <= 576
+  }
   auto xloadset = [&](int c, int p) {
+    if (CONVP) {
+      const int cc = bix(c);
+      const int tap = (cc * cinv) >> 16, cb = cc - tap * cNB;
+      const int ky = (tap * 11) >> 5, dy = ky - 1, dx = tap - 3 * ky - 1;              // tap / 3 for tap < 9
+      const bool ok = (unsigned)(cpy + dy) < (unsigned)cs.H && (unsigned)(cpx + dx) < (unsigned)cs.W;
+      const int rs = ok ? crow + dy * cs.W + dx : crow;
+      const char* src = reinterpret_cast<const char*>(A) + ((int64_t)(rs >> 5) * cNB + cb) * 4096 + (lh * 32 + (rs & 31)) * 16;
+      const f16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      const f16x8_t v0 = *reinterpret_cast<const f16x8_t*>(src), v1 = *reinterpret_cast<const f16x8_t*>(src + 1024);
+      const f16x8_t v2 = *reinterpret_cast<const f16x8_t*>(src + 2048), v3 = *reinterpret_cast<const f16x8_t*>(src + 3072);
+      ah[p][0] = ok ? v0 : z;
+      al[p][0] = ok ? v1 : z;
+      ah[p][1] = ok ? v2 : z;
+      al[p][1] = ok ? v3 : z;
+      return;
+    }
     const char* src = fbase + bix(c) * 4096;
     ah[p][0] = *reinterpret_cast<const f16x8_t*>(src);
     al[p][0] = *reinterpret_cast<const f16x8_t*>(src + 1024);
@@ -795,6 +825,16 @@ int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* o
   hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, false, OCC, PRE, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(x), wp, bias, reinterpret_cast<float*>(out_frag), (int)M, N, K, (int)MT, NT, nullptr,
                      nullptr);
+  return 0;
+}
+// 3 x 3 convolution (pad 1) over the split image of NHWC activations: M = B H W output pixels, K = 9 Cin (two workgroups per CU)
+inline int launch_h3p_conv_pre(const void* xf, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
+                               hipStream_t st) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 127) / 128;
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
+                     reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, 9 * Cin, (int)MT, NT, nullptr, nullptr, ConvShape{H, W, Cin});
   return 0;
 }
 template <int OCC>

@@ -178,9 +178,15 @@ class MSDeformAttnPixelDecoder(nn.Module):
             ad, ly = getattr(self, f"adapter_{j}"), getattr(self, f"layer_{j}")
             cur = ops.group_norm_nhwc(self._conv1x1(self._tokens(x), ad, use_bias=False), 32, ad.norm.weight, ad.norm.bias,
                                       ad.norm.eps)
-            ups = [ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d))
-                   for b in range(B)]                                                      # :357-358 fused sum
-            yy = ups[0][None] if B == 1 else torch.stack(ups)
+            if ops.conv3x3_takes_split(B * h * w, d) and d % 32 == 0:
+                # the sum feeds only the 3x3 convolution: written straight as that kernel's split operand (ops.SplitActivations)
+                yy = ops.SplitActivations.empty((B, h, w, d), prev.device)
+                for b in range(B):
+                    ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d), split_into=yy, image=b)
+            else:
+                ups = [ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d))
+                       for b in range(B)]                                                  # :357-358 fused sum
+                yy = ups[0][None] if B == 1 else torch.stack(ups)
             planes = self._cached(ly, "_rba_conv", lambda: ops.conv3x3_weight(ly.weight.detach()))
             z = ops.conv3x3_nhwc(yy, planes, None, out_features=d)
             prev = ops.group_norm_nhwc(z.view(B, h * w, d), 32, ly.norm.weight, ly.norm.bias, ly.norm.eps, relu=True)

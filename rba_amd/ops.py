@@ -649,14 +649,25 @@ def conv3x3_weight(weight, mode=None):
     return split_weight(weight.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), mode=mode)
 
 
+def conv3x3_takes_split(M, N):
+    """True when conv3x3_nhwc can read its input as SplitActivations (the pipelined f16x3 kernel: at least 256 tiles of 128 x 128)."""
+    return SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and ((M + 127) // 128) * ((N + 127) // 128) >= 256
+
+
 @_hip_op
 def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     """3x3, stride 1, pad 1 convolution of NHWC x [B,H,W,C] with conv3x3_weight(W) -> [B,H,W,N] (implicit GEMM on K6; the planes'
     dtype says for which form they were packed)."""
     lib = _lib.load()
-    _chk(x, "x", dim=4)
+    if not isinstance(x, SplitActivations):
+        _chk(x, "x", dim=4)
     f16 = planes.dtype == torch.float16
     _chk(planes, "planes", dtype=torch.float16 if f16 else torch.bfloat16, dim=6)
+    pre = isinstance(x, SplitActivations)
+    if pre:
+        _chk(x.data, "x.data", dtype=torch.int32, dim=1)
+        if len(x.shape) != 4:
+            raise RbaHipError("conv3x3_nhwc needs SplitActivations of logical shape [B,H,W,C]")
     B, H, W, C = x.shape
     N = planes.shape[0] * 128 if out_features is None else int(out_features)
     if (tuple(planes.shape[2:]) != ((2, 128, 2, 8) if f16 else (3, 128, 2, 8)) or planes.shape[1] * 16 != 9 * C or C % 32
@@ -667,6 +678,12 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
     out = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+    if pre:
+        if not f16 or not conv3x3_takes_split(B * H * W, N):
+            raise RbaHipError("conv3x3_nhwc: SplitActivations need f16x3 planes and conv3x3_takes_split(B*H*W, N)")
+        _lib.check(lib.rba_conv3x3_nhwc_f16x3_split_in_f32(_p(x.data), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()),
+                   "rba_conv3x3_nhwc_f16x3_split_in_f32")
+        return out
     fn, name = ((lib.rba_conv3x3_nhwc_f16x3_f32, "rba_conv3x3_nhwc_f16x3_f32") if f16 else (lib.rba_conv3x3_nhwc_f32, "rba_conv3x3_nhwc_f32"))
     _lib.check(fn(_p(x), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()), name)
     return out
@@ -715,19 +732,28 @@ def group_norm_nhwc(x, num_groups, weight, bias, eps=1e-5, relu=False):
 
 
 @_hip_op
-def resample_bilinear_nhwc(x, size, add=None):
-    """F.interpolate(mode="bilinear", align_corners=False) of channels-last x [h, w, C] -> [H, W, C], optional fused `+ add`."""
+def resample_bilinear_nhwc(x, size, add=None, split_into=None, image=0):
+    """F.interpolate(mode="bilinear", align_corners=False) of channels-last x [h, w, C] -> [H, W, C], optional fused `+ add`.
+    ``split_into``: a SplitActivations of logical shape [B, H, W, C] (SplitActivations.empty): the result becomes image `image` of it
+    (the 3x3 convolution's split operand, conv3x3_takes_split) and nothing else is written; returns split_into."""
     lib = _lib.load()
     _chk(x, "x", dim=3)
     h, w, C = x.shape
     H, W = int(size[0]), int(size[1])
     if C % 4:
         raise RbaHipError("resample_bilinear_nhwc needs C % 4 == 0")
-    out = torch.empty((H, W, C), dtype=torch.float32, device=x.device)
     if add is not None:
         _chk(add, "add")
-        if tuple(add.shape) != tuple(out.shape):
+        if tuple(add.shape) != (H, W, C):
             raise RbaHipError("add must have the output's shape")
+    if split_into is not None:
+        if (not isinstance(split_into, SplitActivations) or len(split_into.shape) != 4 or tuple(split_into.shape[1:]) != (H, W, C) or C % 32
+                or not 0 <= image < split_into.shape[0]):
+            raise RbaHipError("split_into must be SplitActivations of shape [B, H, W, C] (C % 32 == 0) with 0 <= image < B")
+        _lib.check(lib.rba_resample_bilinear_nhwc_split_out_f32(_p(x), _p(add), _p(split_into.data), C, h, w, H, W, image * H * W, _stream()),
+                   "rba_resample_bilinear_nhwc_split_out_f32")
+        return split_into
+    out = torch.empty((H, W, C), dtype=torch.float32, device=x.device)
     _lib.check(lib.rba_resample_bilinear_nhwc_f32(_p(x), _p(add), _p(out), C, h, w, H, W, _stream()),
                "rba_resample_bilinear_nhwc_f32")
     return out

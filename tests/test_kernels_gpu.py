@@ -547,6 +547,35 @@ def test_conv3x3_nhwc_vs_fp64(ops, B, H, W, C, N, has_bias, mode):
     assert maxerr(out, ref) < 2e-5 * (9 * C / 256) ** 0.5 + 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,C,N,has_bias", [(1, 128, 256, 256, 256, False), (2, 100, 167, 64, 256, True), (1, 256, 512, 256, 256, False),
+                                                  (3, 131, 90, 32, 200, True)])
+def test_conv3x3_nhwc_from_split_activations(ops, B, H, W, C, N, has_bias):
+    """The FPN hand-over: `lateral + upsample` written by the resample kernel as the convolution's split operand, and the pipelined
+    convolution gathering neighbour-pixel pieces from it: both bit-identical to the fp32-row forms (borders, ragged M, several images)."""
+    g = torch.Generator().manual_seed(B * 1000 + H * W + C)
+    assert ops.conv3x3_takes_split(B * H * W, N)
+    h2, w2 = (H + 1) // 2, (W + 1) // 2
+    prev, cur = dev(torch.randn(B, h2, w2, C, generator=g)), dev(torch.randn(B, H, W, C, generator=g))
+    w = dev(torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5)
+    b = dev(torch.randn(N, generator=g)) if has_bias else None
+    y32 = torch.stack([ops.resample_bilinear_nhwc(prev[i], (H, W), add=cur[i]) for i in range(B)])
+    ys = ops.SplitActivations.empty((B, H, W, C), prev.device)
+    for i in range(B):
+        assert ops.resample_bilinear_nhwc(prev[i], (H, W), add=cur[i], split_into=ys, image=i) is ys
+    want = ops.SplitActivations.pack(y32)
+    nfull = (B * H * W) // 32 * 32 * C
+    assert torch.equal(ys.data[:nfull], want.data[:nfull]) and torch.equal(ys.unpack(), want.unpack())
+    planes = ops.conv3x3_weight(w, mode="f16x3")
+    z32 = ops.conv3x3_nhwc(y32, planes, b, out_features=N)
+    zs = ops.conv3x3_nhwc(ys, planes, b, out_features=N)
+    ref = F.conv2d(y32.permute(0, 3, 1, 2).double(), w.double(), b.double() if has_bias else None, padding=1).permute(0, 2, 3, 1)
+    assert maxerr(zs, ref) < 2e-5 * (9 * C / 256) ** 0.5 + 2e-6
+    assert torch.equal(zs, z32)                           # same products, same order as the LDS-staged fp32-row kernel
+    no_add = ops.SplitActivations.empty((1, H, W, C), prev.device)
+    ops.resample_bilinear_nhwc(prev[0], (H, W), split_into=no_add)
+    assert torch.equal(no_add.unpack()[0], ops.SplitActivations.pack(ops.resample_bilinear_nhwc(prev[0], (H, W))).unpack())
+
+
 @pytest.mark.parametrize("B,P,K,N", [(1, 1000, 64, 128), (2, 384, 256, 256), (1, 777, 128, 40), (3, 130, 32, 300), (2, 640, 512, 256)])
 def test_split_linear_nchw_out(ops, B, P, K, N):
     g = torch.Generator().manual_seed(B + P + K + N)
