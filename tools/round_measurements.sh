@@ -12,5 +12,5 @@ python $R/tools/prof_summary.py $(find /tmp/p3 -name "*.db" | head -1) > $O/r02c
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o bench -- python $R/bench.py --no-cpu-baseline --streams 1 > $O/prof1.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p1 -name "*.db" | head -1) > $O/r02d_bench_streams1_kernel_trace.md
 cd $R
-python tools/evaluator_bench.py > $O/r02_evaluator_b.json 2> $O/r02_evaluator_b.err
+python tools/evaluator_bench.py 96 > $O/r02_evaluator_b.json 2> $O/r02_evaluator_b.err
 python tools/gemm_h3_sweep.py swin_b 4004 > $O/r02_k6_sweep_final.txt 2>&1
