@@ -24,15 +24,20 @@ struct MergeGeom {
 // arithmetic (split_linear_h3.h, "PRE"): per (32-row group, 32-wide block of C) four 1 KiB pieces [h g0 | l g0 | h g1 | l g1], each
 // [lh][row & 31][8 f16], k = 32 b + 16 lh + 8 g + i; h = f16(y), l = f16((y - h) 2^11).  A lane holds 4 consecutive channels; the even
 // lane of a pair stores the 16-byte h piece, the odd lane the l piece (one DPP exchange): as many bytes and stores as the fp32 row.
-template <int G, int NV, bool MERGE = false, bool FRAG = false>
-__global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, const float* __restrict__ t,
+// FRAG with WAVES = 8 (one row per wave, G = 64): the eight rows' pieces are transposed through LDS so that every global store
+// instruction writes whole 128-byte lines of the image (8 consecutive rows x 16 bytes of one piece column) instead of eight scattered
+// 16-byte fragments per row: [piece column][row & 7 XOR column & 7][16 B], conflict-free both ways.
+template <int G, int NV, bool MERGE = false, bool FRAG = false, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void add_layer_norm_kernel(const float* x, const float* __restrict__ t,
                                                              const float* __restrict__ tb, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* sum_out /* may alias x */,
                                                              float* __restrict__ y, int64_t rows, int C, float eps,
                                                              MergeGeom mg = MergeGeom{0, 0, 0}) {
   constexpr int RPW = 64 / G;                              // rows per wave
   const int lane = threadIdx.x & 63, sub = lane % G, rsel = lane / G;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + rsel;
+  const int64_t row = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW + rsel;
+  constexpr bool TR = FRAG && WAVES == 8 && G == 64;                               // transposed stores
+  __shared__ __attribute__((aligned(16))) rba_u32x4 tr_lds[TR ? NV * 64 * 8 : 1];
   const bool rvalid = row < rows;
   const int64_t base = (rvalid ? row : 0) * C;
   const int nv4 = C >> 2;
@@ -93,12 +98,12 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, con
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, RBA_WAVE);
   const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
-  if (!rvalid) return;
+  if (!TR && !rvalid) return;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c4 = sub + j * G;
     if (c4 < nv4) {
-      if (sum_out) *reinterpret_cast<f32x4*>(sum_out + base + 4 * c4) = v[j];
+      if (sum_out && rvalid) *reinterpret_cast<f32x4*>(sum_out + base + 4 * c4) = v[j];
       const f32x4 gj = EARLY ? g4[EARLY ? j : 0] : *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
       const f32x4 bj = EARLY ? b4[EARLY ? j : 0] : *reinterpret_cast<const f32x4*>(beta + 4 * c4);
       const f32x4 o = (v[j] - mean) * rstd * gj + bj;
@@ -111,12 +116,31 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* x, con
         const uint32_t r0 = __builtin_amdgcn_mov_dpp(s0, 0xB1, 0xf, 0xf, true), r1 = __builtin_amdgcn_mov_dpp(s1, 0xB1, 0xf, 0xf, true);
         const rba_u32x4 piece = odd ? (rba_u32x4){r0, r1, l[0], l[1]} : (rba_u32x4){h[0], h[1], r0, r1};
         const int k8 = c4 >> 1;
-        const int64_t off = ((row >> 5) * (int64_t)(C >> 5) + (k8 >> 2)) * 4096 + ((k8 & 1) * 2 + (odd ? 1 : 0)) * 1024 +
-                            (((k8 >> 1) & 1) * 32 + (int)(row & 31)) * 16;
-        *reinterpret_cast<rba_u32x4*>(reinterpret_cast<char*>(y) + off) = piece;
+        if (TR) {
+          // piece column = ((block * 4 + 2 g + (h|l)) * 2 + k-half): the order of the image within a row group, 512 bytes apart
+          const int pcol = (((k8 >> 2) * 4 + (k8 & 1) * 2 + (odd ? 1 : 0)) << 1) + ((k8 >> 1) & 1);
+          const int r8 = threadIdx.x >> 6;
+          tr_lds[pcol * 8 + (r8 ^ (pcol & 7))] = piece;
+        } else {
+          const int64_t off = ((row >> 5) * (int64_t)(C >> 5) + (k8 >> 2)) * 4096 + ((k8 & 1) * 2 + (odd ? 1 : 0)) * 1024 +
+                              (((k8 >> 1) & 1) * 32 + (int)(row & 31)) * 16;
+          *reinterpret_cast<rba_u32x4*>(reinterpret_cast<char*>(y) + off) = piece;
+        }
       } else {
         *reinterpret_cast<f32x4*>(y + base + 4 * c4) = o;
       }
+    }
+  }
+  if (TR) {
+    __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * 8;                                   // the workgroup's eight rows: one aligned octet of a row group
+    char* img = reinterpret_cast<char*>(y) + ((row0 >> 5) * (int64_t)(C >> 5)) * 4096 + (int)(row0 & 31) * 16;
+    const int npc = nv4;                                                            // piece columns per row (C / 8 h pieces + C / 8 l pieces)
+    for (int u = threadIdx.x; u < npc * 8; u += 64 * WAVES) {
+      const int pcol = u >> 3, r8 = u & 7;
+      const int x = pcol >> 1;
+      if (row0 + r8 < rows)
+        *reinterpret_cast<rba_u32x4*>(img + (int64_t)(x >> 2) * 4096 + (x & 3) * 1024 + (pcol & 1) * 512 + r8 * 16) = tr_lds[pcol * 8 + (r8 ^ (pcol & 7))];
     }
   }
 }
@@ -129,6 +153,16 @@ int launch(const float* x, const float* t, const float* tb, const float* gamma, 
   if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((add_layer_norm_kernel<G, NV, false, FRAG>), dim3((unsigned)blocks), dim3(256), 0, st, x, t, tb, gamma, beta, sum_out, y,
                      rows, C, eps);
+  return rba_launch_status();
+}
+
+template <int NV>
+int launch_frag8(const float* x, const float* t, const float* tb, const float* gamma, const float* beta, float* sum_out, float* y,
+                 int64_t rows, int C, float eps, hipStream_t st) {
+  const int64_t blocks = (rows + 7) / 8;
+  if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((add_layer_norm_kernel<64, NV, false, true, 8>), dim3((unsigned)blocks), dim3(512), 0, st, x, t, tb, gamma, beta, sum_out,
+                     y, rows, C, eps);
   return rba_launch_status();
 }
 
@@ -205,6 +239,11 @@ extern "C" int rba_add_layer_norm_frag_f32(const float* x, const float* t, const
   hipStream_t st = (hipStream_t)stream;
   const int nv4 = C / 4;
   float* y = reinterpret_cast<float*>(y_frag);
+  // 64 lanes per row (the fp32 kernel's own partition of the row, so the same sums bit for bit): eight rows per workgroup, stores
+  // transposed through LDS
+  if (nv4 > 64 && nv4 <= 128) return launch_frag8<2>(x, t, t_bias, gamma, beta, sum_out, y, rows, C, eps, st);
+  if (nv4 > 128 && nv4 <= 256) return launch_frag8<4>(x, t, t_bias, gamma, beta, sum_out, y, rows, C, eps, st);
+  if (nv4 > 256 && nv4 <= 512) return launch_frag8<8>(x, t, t_bias, gamma, beta, sum_out, y, rows, C, eps, st);
 #define RBA_L(G, NV) return launch<G, NV, true>(x, t, t_bias, gamma, beta, sum_out, y, rows, C, eps, st)
   if (nv4 <= 16) RBA_L(16, 1);
   if (nv4 <= 32) RBA_L(32, 1);
