@@ -202,6 +202,11 @@ int rba_resample_bilinear_nhwc_split_out_f32(const float* in, const float* add, 
                                              int64_t row0, void* stream);
 int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const void* weight_packed, const float* bias, float* out, int B, int H, int W,
                                         int C, int N, void* stream);
+/*   rba_swin_mlp_fused_f16x3_f32 = the whole Mlp + residual of a Swin block with C = 128 in one kernel (csrc/mlp_fused_h3.h): the [M, HID]
+ *                                     hidden tensor never leaves the registers (fc1's transposed accumulators become fc2's A fragments after
+ *                                     one v_permlane32_swap); bit-identical to the two-kernel hand-over below. */
+int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
+                                 const float* residual, float* out, int64_t M, int C, int HID, void* stream);
 /*   rba_split_linear_f16x3_gelu_split_out = GELU(x W^T + bias) written as the split image of the NEXT Linear (Mlp.fc1 -> fc2,
  *                                     backbone/swin.py:35-41): the GEMM runs with its MFMA operands swapped (D^T = W x^T), so a lane ends
  *                                     up with consecutive output channels of one row and stores 16-byte pieces.  x: fp32 rows

@@ -37,6 +37,7 @@ SIGNATURES = {
     "rba_split_linear_f16x3_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_linear_f16x3_res_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_f16x3_frag_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "rba_swin_mlp_fused_f16x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_f16x3_gelu_split_out": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -61,7 +62,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 179        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 180        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

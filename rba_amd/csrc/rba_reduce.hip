@@ -14,7 +14,7 @@
 
 using namespace rba_k1;
 
-extern "C" int rba_hip_version(void) { return 179; }
+extern "C" int rba_hip_version(void) { return 180; }
 
 static int reduce_impl(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax, int Q, int K, int64_t HW,
                        int score_mode, unsigned int* counters, void* stream) {

@@ -7,6 +7,7 @@
 //   * fewer than 256 such tiles (Swin stage 4 at one image): 128 x 64 tiles, persistent workgroups -- twice the workgroups, so every
 //     CU still gets two.
 #include "split_linear_h3.h"
+#include "mlp_fused_h3.h"
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {
@@ -150,6 +151,22 @@ extern "C" int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const voi
   RBA_CHECK_ARG((((uintptr_t)x_frag | (uintptr_t)weight_packed | (uintptr_t)out | (uintptr_t)bias) & 15) == 0);
   rba_begin();
   const int rc = launch_h3p_conv_pre(x_frag, reinterpret_cast<const u32x4_t*>(weight_packed), bias, out, M, N, H, W, C, (hipStream_t)stream);
+  if (rc) return rc;
+  return rba_launch_status();
+}
+
+// out = residual + fc2(GELU(fc1(x))) for C = 128 in one kernel (mlp_fused_h3.h): x [M, 128] fp32 rows, w1_packed = rba_split_weight_f16x2 of
+// fc1.weight [HID, 128], w2_packed of fc2.weight [128, HID], HID % 32 == 0; `out` may be `residual`.  Bit-identical to
+// rba_split_linear_f16x3_gelu_split_out + rba_split_linear_f16x3_frag_f32(residual).  (Mlp + residual of backbone/swin.py:35-41, 292.)
+extern "C" int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
+                                            const float* residual, float* out, int64_t M, int C, int HID, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && C == 128 && HID >= 64 && (HID % 32) == 0);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && w1_packed && w2_packed && residual && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1) & 15) == 0);
+  rba_begin();
+  const int rc = launch_mlp_fused(x, reinterpret_cast<const u32x4_t*>(w1_packed), b1, reinterpret_cast<const u32x4_t*>(w2_packed), b2, residual, out, M,
+                                  HID, (hipStream_t)stream);
   if (rc) return rc;
   return rba_launch_status();
 }

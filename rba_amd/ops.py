@@ -556,6 +556,32 @@ def linear_takes_split(M, N, K):
     return (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K > 256 and K % 32 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 160)
 
 
+MLP_FUSED_MIN_ROWS = 32768          # 256 workgroups of 128 rows: below that the unfused pair's 128 x 128 tiles fill the chip better
+
+
+def mlp_fused_ok(M, C, hidden):
+    """True when mlp_fused() applies: the one-kernel Swin MLP exists for C = 128 (Swin-B stage 1), f16x3 mode."""
+    return SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and C == 128 and hidden % 32 == 0 and hidden >= 64 and M >= MLP_FUSED_MIN_ROWS
+
+
+@_hip_op
+def mlp_fused(x, fc1, fc2, residual):
+    """residual + fc2(GELU(fc1(x))) in one kernel, in place over `residual` (Mlp + residual add of a Swin block, swin.py:35-41, 292): the
+    hidden tensor stays in registers.  Bit-identical to linear(split_out=True) + linear(residual=...)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(residual, "residual")
+    C, hidden = fc1.weight.shape[1], fc1.weight.shape[0]
+    M = x.numel() // C
+    if (x.shape[-1] != C or tuple(fc2.weight.shape) != (C, hidden) or tuple(residual.shape) != tuple(x.shape) or C != 128 or hidden % 32
+            or SPLIT_MODE != "f16x3"):
+        raise RbaHipError("mlp_fused needs C == 128, hidden % 32 == 0, matching fc1 / fc2 and the f16x3 mode")
+    _lib.check(lib.rba_swin_mlp_fused_f16x3_f32(_p(x), _p(_cached_planes(fc1, fc1.weight)), _p(fc1.bias), _p(_cached_planes(fc2, fc2.weight)),
+                                                _p(fc2.bias), _p(residual), _p(residual), M, C, hidden, _stream()),
+               "rba_swin_mlp_fused_f16x3_f32")
+    return residual
+
+
 def linear_residual_fused(M, N, K):
     """True when linear(..., residual=r) runs as ONE kernel (the f16x3 GEMM with the residual add in its epilogue)."""
     return SPLIT_MODE == "f16x3" and split_linear_pays(M, N, K)

@@ -431,6 +431,23 @@ def test_split_linear_gelu_split_output(ops, M, N, K):
         ops.split_linear(x, planes, b, out_features=N, split_out=True)
 
 
+@pytest.mark.parametrize("M,hidden", [(131072, 512), (3000, 512), (130, 96), (57600, 512), (128, 64)])
+def test_swin_mlp_fused(ops, M, hidden):
+    """One-kernel Mlp + residual for C = 128: bit-identical to fc1 (GELU, split output) -> fc2 (residual epilogue), and within the GEMM
+    tolerance of the fp64 composition."""
+    g = torch.Generator().manual_seed(M + hidden)
+    C = 128
+    fc1, fc2 = torch.nn.Linear(C, hidden).cuda(), torch.nn.Linear(hidden, C).cuda()
+    x, r = dev(torch.randn(M, C, generator=g) * 2), dev(torch.randn(M, C, generator=g))
+    with torch.no_grad():
+        want = ops.linear(ops.linear(x, fc1, gelu=True, split_out=True), fc2, residual=r.clone())
+        got = ops.mlp_fused(x, fc1, fc2, r.clone())
+        ref = r.double() + F.linear(F.gelu(F.linear(x.double(), fc1.weight.double(), fc1.bias.double())), fc2.weight.double(), fc2.bias.double())
+    assert maxerr(got, ref) < 3e-5
+    assert torch.equal(got, want)
+    assert ops.mlp_fused_ok(131072, 128, 512) and not ops.mlp_fused_ok(131072, 192, 768) and not ops.mlp_fused_ok(8192, 128, 512)
+
+
 @pytest.mark.parametrize("rows,C", [(8192, 512), (2048, 1024), (1000, 96), (33, 32), (4100, 1536), (70, 2048)])
 def test_add_layer_norm_split_output(ops, rows, C):
     """add_layer_norm(frag=True): the LayerNorm output written directly as SplitActivations == pack(fp32 output), bit for bit, with and
