@@ -51,19 +51,24 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
     }
   }
 
-  // ---- weight staging: W1 chunk j = rows 32 j .. 32 j + 31 of every (sub-stage, plane): unit (s, p, u) <- tile, s, p, (roff + u / 2), u % 2
+  // ---- weight staging.  Unit u = (W1 chunk u + 1, W2 k block u): what iteration u needs, because fc1 runs ONE chunk ahead of fc2 (its MFMAs
+  // overlap the GELU arithmetic of the previous chunk).  W1 chunk c = rows 32 c .. 32 c + 31 of every (sub-stage, plane):
+  // unit index (s, p, u) <- tile, s, p, (roff + u / 2), u % 2
   u32x4_t wr1[4], wr2[4];
   const int last = NJ - 1;
-  auto wload = [&](int j) {
-    const int jj = j < last ? j : last;
-    const int tile = (jj * 32) >> 7, roff = (jj * 32) & 127;
+  auto w1load = [&](int c) {
+    const int cc = c < last ? c : last;
+    const int tile = (cc * 32) >> 7, roff = (cc * 32) & 127;
     const u32x4_t* w1 = W1p + (int64_t)tile * S16_1 * 512 + roff * 2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;                                               // (s, p, u) = (idx / 128, idx / 64 % 2, idx % 64)
       wr1[q] = w1[(idx >> 7) * 512 + ((idx >> 6) & 1) * 256 + (idx & 63)];
     }
-    const u32x4_t* w2 = W2p + (int64_t)jj * 1024;
+  };
+  auto wload = [&](int u) {
+    w1load(u + 1);
+    const u32x4_t* w2 = W2p + (int64_t)(u < last ? u : last) * 1024;
 #pragma unroll
     for (int q = 0; q < 4; ++q) wr2[q] = w2[tid + 256 * q];
   };
@@ -82,16 +87,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) accm[t][r] = accl[t][r] = 0.f;
 
-  wload(0);
-  wstore(lds);
-  wload(1);
-  __syncthreads();
-
-  for (int j = 0; j < NJ; ++j) {
-    const u32x4_t* w1i = lds + (j & 1) * (W1U + W2U);
-    const u32x4_t* w2i = w1i + W1U;
-    // ---- fc1 chunk: S^T[hidden 32 j + ..][row] (operands swapped: A = W1 fragment, B = x fragment)
-    f32x16_t sm, sl;
+  // S^T of one chunk (operands swapped: A = W1 fragment, B = x fragment)
+  auto fc1 = [&](const u32x4_t* w1i, f32x16_t& sm, f32x16_t& sl) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sm[r] = sl[r] = 0.f;
 #pragma unroll
@@ -105,12 +102,32 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
       sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, xh[b][1], sl, 0, 0, 0);
       sl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xl[b][1], sl, 0, 0, 0);
     }
-    // ---- bias + GELU + split; lane holds hidden channels 32 j + 8 q + 4 lh + (0..3) of row l31
+  };
+
+  // prologue: W1 chunk 0 alone (into the W1 half of buffer 1), S(0); then unit 0 into buffer 0
+  w1load(0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lds[(W1U + W2U) + tid + 256 * q] = wr1[q];
+  wload(0);
+  __syncthreads();
+  f32x16_t sm, sl;
+  fc1(lds + (W1U + W2U), sm, sl);
+  wstore(lds);
+  wload(1);
+  __syncthreads();
+
+  for (int j = 0; j < NJ; ++j) {
+    const u32x4_t* w1i = lds + (j & 1) * (W1U + W2U);                               // W1 chunk j + 1
+    const u32x4_t* w2i = w1i + W1U;                                                // W2 k block j
+    // ---- fc1 of the NEXT chunk: independent of everything below until the end of the iteration, so its 24 MFMAs run under the GELU
+    f32x16_t nm, nl;
+    fc1(w1i, nm, nl);
+    // ---- bias + GELU + split of chunk j; lane holds hidden channels 32 j + 8 q + 4 lh + (0..3) of row l31
     uint32_t H[4][2], L[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = 32 * j + 8 * q + 4 * lh;
-      const f32x4 bv = b1 ? *reinterpret_cast<const f32x4*>(b1 + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + n);                    // (no null test: a branch here would fence the MFMA / VALU interleaving)
       f32x2 y0 = (f32x2){sl[4 * q], sl[4 * q + 1]} * 0.00048828125f + (f32x2){sm[4 * q], sm[4 * q + 1]};
       f32x2 y1 = (f32x2){sl[4 * q + 2], sl[4 * q + 3]} * 0.00048828125f + (f32x2){sm[4 * q + 2], sm[4 * q + 3]};
       y0 = gelu_erf2(y0 + (f32x2){bv.x, bv.y});
@@ -140,10 +157,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
       accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl1, accl[t], 0, 0, 0);
       accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh1, accl[t], 0, 0, 0);
     }
-    // ---- next chunk's weights into the other buffer (last read in iteration j - 1, before the barrier that ended it)
+    // ---- next unit into the other buffer (last read in iteration j - 1, before the barrier that ended it)
     wstore(lds + ((j + 1) & 1) * (W1U + W2U));
     wload(j + 2);
     __syncthreads();
+    sm = nm;
+    sl = nl;
   }
   h3_epilogue<0, CT, 0, true>(accm, accl, b2, C, R, M, N2, m0, 0, 128, 128, wave, l31, lh);
 }

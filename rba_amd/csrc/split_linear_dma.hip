@@ -162,7 +162,7 @@ extern "C" int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packe
                                             const float* residual, float* out, int64_t M, int C, int HID, void* stream) {
   RBA_CHECK_ARG(M >= 0 && C == 128 && HID >= 64 && (HID % 32) == 0);
   if (M == 0) return 0;
-  RBA_CHECK_ARG(x && w1_packed && w2_packed && residual && out && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG(x && w1_packed && b1 && w2_packed && residual && out && M < (int64_t)1 << 31);
   RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1) & 15) == 0);
   rba_begin();
   const int rc = launch_mlp_fused(x, reinterpret_cast<const u32x4_t*>(w1_packed), b1, reinterpret_cast<const u32x4_t*>(w2_packed), b2, residual, out, M,

@@ -83,6 +83,10 @@ class SwinTransformerBlock(nn.Module):
             # the residual adds ride in the GEMM epilogues (x is updated in place), the LayerNorms read one tensor and write one
             x = ops.linear(y, a.proj, residual=x)
             hidden = self.mlp.fc1.out_features
+            if ops.mlp_fused_ok(M, C, hidden):
+                # C = 128 (Swin-B stage 1): fc1 + GELU + fc2 + residual in ONE kernel, the 4C-wide hidden tensor never leaves the registers
+                y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]
+                return ops.mlp_fused(y, self.mlp.fc1, self.mlp.fc2, x), None
             # fc2 reads fc1's output as its split operand wherever it runs the pipelined kernel; fc1's own input comes split from
             # the LayerNorm only where K > 256 (below, the scattered 16-byte stores cost the LayerNorm more than the GEMM gains)
             y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, frag=ops.linear_takes_split(M, hidden, C))[1]
