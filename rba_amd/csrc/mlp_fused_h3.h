@@ -119,13 +119,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
   for (int j = 0; j < NJ; ++j) {
     const u32x4_t* w1i = lds + (j & 1) * (W1U + W2U);                               // W1 chunk j + 1
     const u32x4_t* w2i = w1i + W1U;                                                // W2 k block j
-    // ---- fc1 of the NEXT chunk: independent of everything below until the end of the iteration, so its 24 MFMAs run under the GELU
-    f32x16_t nm, nl;
-    fc1(w1i, nm, nl);
-    // ---- bias + GELU + split of chunk j; lane holds hidden channels 32 j + 8 q + 4 lh + (0..3) of row l31
+    // bias + GELU + split of piece q of chunk j (VALU only); the lane holds hidden channels 32 j + 8 q + 4 lh + (0..3) of row l31
     uint32_t H[4][2], L[4][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    auto epi = [&](int q) {
       const int n = 32 * j + 8 * q + 4 * lh;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + n);                    // (no null test: a branch here would fence the MFMA / VALU interleaving)
       f32x2 y0 = (f32x2){sl[4 * q], sl[4 * q + 1]} * 0.00048828125f + (f32x2){sm[4 * q], sm[4 * q + 1]};
@@ -134,32 +130,87 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
       y1 = gelu_erf2(y1 + (f32x2){bv.z, bv.w});
       rba_split_f16x2(y0.x, y0.y, H[q][0], L[q][0]);
       rba_split_f16x2(y1.x, y1.y, H[q][1], L[q][1]);
-    }
+    };
     // v_permlane32_swap(piece g, piece g + 2): a low lane keeps its half of piece g and receives the partner's half of piece g; a high lane
     // receives the partner's half of piece g + 2 and keeps its own: every lane ends with piece 2 lh + g whole = the A fragment of its k-half
-    f16x8_t ah[2], al[2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    auto pair = [&](int g, f16x8_t& ah, f16x8_t& al) {
       const auto h0 = __builtin_amdgcn_permlane32_swap(H[g][0], H[g + 2][0], false, false), h1 = __builtin_amdgcn_permlane32_swap(H[g][1], H[g + 2][1], false, false);
       const auto l0 = __builtin_amdgcn_permlane32_swap(L[g][0], L[g + 2][0], false, false), l1 = __builtin_amdgcn_permlane32_swap(L[g][1], L[g + 2][1], false, false);
-      ah[g] = __builtin_bit_cast(f16x8_t, (u32x4_t){h0[0], h1[0], h0[1], h1[1]});
-      al[g] = __builtin_bit_cast(f16x8_t, (u32x4_t){l0[0], l1[0], l0[1], l1[1]});
+      ah = __builtin_bit_cast(f16x8_t, (u32x4_t){h0[0], h1[0], h0[1], h1[1]});
+      al = __builtin_bit_cast(f16x8_t, (u32x4_t){l0[0], l1[0], l0[1], l1[1]});
+    };
+    // ---- phase A: the 24 MFMAs of fc1 for the NEXT chunk under the GELU arithmetic of pieces 0 and 2 of this one
+    u32x4_t f1[NB1][4], f2[CT][2];
+#pragma unroll
+    for (int b = 0; b < NB1; ++b) {
+      f1[b][0] = w1i[((2 * b) * 2 + 0) * 64 + fb];
+      f1[b][1] = w1i[((2 * b) * 2 + 1) * 64 + fb];
+      f1[b][2] = w1i[((2 * b + 1) * 2 + 0) * 64 + fb];
+      f1[b][3] = w1i[((2 * b + 1) * 2 + 1) * 64 + fb];
     }
-    // ---- fc2: k block j of the four 32-column output tiles
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {                                                 // fc2 fragments of k-half g = 0
+      f2[t][0] = w2i[fb + 64 * t];
+      f2[t][1] = w2i[fb + 2 * N2 + 64 * t];
+    }
+    f32x16_t nm, nl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nm[r] = nl[r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB1; ++b) {
+      const f16x8_t wh0 = __builtin_bit_cast(f16x8_t, f1[b][0]), wl0 = __builtin_bit_cast(f16x8_t, f1[b][1]);
+      const f16x8_t wh1 = __builtin_bit_cast(f16x8_t, f1[b][2]), wl1 = __builtin_bit_cast(f16x8_t, f1[b][3]);
+      nm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh[b][0], nm, 0, 0, 0);
+      nl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, xh[b][0], nl, 0, 0, 0);
+      nm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xh[b][1], nm, 0, 0, 0);
+      nl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xl[b][0], nl, 0, 0, 0);
+      nl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, xh[b][1], nl, 0, 0, 0);
+      nl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xl[b][1], nl, 0, 0, 0);
+    }
+    epi(0);
+    epi(2);
+#pragma unroll
+    for (int i_ = 0; i_ < 24; ++i_) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B: fc2's k-half g = 0 (12 MFMAs: per tile main, low, low -- the accumulation order of the unfused kernel is g-major within each
+    // accumulator, so this regrouping keeps every sum bit-identical) under the GELU arithmetic of pieces 1 and 3
+    f16x8_t ah0, al0, ah1, al1;
+    pair(0, ah0, al0);
+    u32x4_t f3[CT][2];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {                                                 // fc2 fragments of k-half g = 1
+      f3[t][0] = w2i[4 * N2 + fb + 64 * t];
+      f3[t][1] = w2i[4 * N2 + fb + 2 * N2 + 64 * t];
+    }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-      const f16x8_t bh0 = __builtin_bit_cast(f16x8_t, w2i[fb + 64 * t]), bl0 = __builtin_bit_cast(f16x8_t, w2i[fb + 2 * N2 + 64 * t]);
-      const f16x8_t bh1 = __builtin_bit_cast(f16x8_t, w2i[4 * N2 + fb + 64 * t]), bl1 = __builtin_bit_cast(f16x8_t, w2i[4 * N2 + fb + 2 * N2 + 64 * t]);
-      accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bh0, accm[t], 0, 0, 0);
-      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bl0, accl[t], 0, 0, 0);
-      accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bh1, accm[t], 0, 0, 0);
-      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bh0, accl[t], 0, 0, 0);
-      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bl1, accl[t], 0, 0, 0);
-      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bh1, accl[t], 0, 0, 0);
+      const f16x8_t bh0 = __builtin_bit_cast(f16x8_t, f2[t][0]), bl0 = __builtin_bit_cast(f16x8_t, f2[t][1]);
+      accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, accm[t], 0, 0, 0);
+      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, accl[t], 0, 0, 0);
+      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh0, accl[t], 0, 0, 0);
     }
-    // ---- next unit into the other buffer (last read in iteration j - 1, before the barrier that ended it)
+    epi(1);
+    epi(3);
+#pragma unroll
+    for (int i_ = 0; i_ < 12; ++i_) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase C: fc2's k-half g = 1, and the next unit's weights into the other LDS buffer (last read in iteration j - 1)
+    pair(1, ah1, al1);
     wstore(lds + ((j + 1) & 1) * (W1U + W2U));
     wload(j + 2);
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const f16x8_t bh1 = __builtin_bit_cast(f16x8_t, f3[t][0]), bl1 = __builtin_bit_cast(f16x8_t, f3[t][1]);
+      accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, accm[t], 0, 0, 0);
+      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, accl[t], 0, 0, 0);
+      accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, accl[t], 0, 0, 0);
+    }
     __syncthreads();
     sm = nm;
     sl = nl;
