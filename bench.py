@@ -40,14 +40,20 @@ def parse():
     ap.add_argument("--k1", choices=["fullres", "up4"], default="fullres",
                     help="fullres: materialise the x4-upsampled mask logits and run the HBM-bound K1 the metric names; "
                          "up4: K1 reads the low-res logits and upsamples on the fly (less traffic, compute bound)")
-    ap.add_argument("--graph", type=int, default=0, help="replay the forward from a captured hipGraph (0 = eager)")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1 = replay each stream's forward from a captured hipGraph, 0 = eager launches, -1 (default) = graphs when several streams are "
+                         "used (the Python thread needs ~6 ms per image to issue its 326 launches: on a loaded host that is the bottleneck of the "
+                         "three-stream step; K1 stays an eager launch bracketed by HIP events inside the timed region) and eager for --streams 1")
     ap.add_argument("--streams", type=int, default=3,
                     help="images per GPU per step, each on its own HIP stream (concurrent kernels fill under-occupied "
                          "stage-3/4 launches: +7..10 %% images/s at 2-3, but K1's live timing then includes contention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=1.0, help="scale of the wall-time bounds of the cpu_baseline legs")
     ap.add_argument("--n-images", type=int, default=4, help="distinct resident synthetic images cycled through")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.graph < 0:
+        args.graph = 1 if args.streams > 1 else 0
+    return args
 
 
 def _timed_runs(fn, reps, budget_s):

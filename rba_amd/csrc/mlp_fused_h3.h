@@ -1,4 +1,4 @@
-// Fused Swin MLP for C = 128 (backbone/swin.py:35-41 + the `x = x + mlp(norm2(x))` of :292): out = residual + fc2(GELU(fc1(y))) in ONE
+// Fused Swin MLP for C = 128 (backbone/swin.py:35-41 + the `x = x + mlp(norm2(x))` of :293): out = residual + fc2(GELU(fc1(y))) in ONE
 // kernel, the [M, 4C] hidden tensor never written.  At stage 1 of Swin-B (131 072 tokens) that tensor is 268 MB: the unfused pair is
 // bound by writing and re-reading it (fc1 147 us + fc2 74 us for 25 us of matrix work).
 //

@@ -157,7 +157,7 @@ extern "C" int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const voi
 
 // out = residual + fc2(GELU(fc1(x))) for C = 128 in one kernel (mlp_fused_h3.h): x [M, 128] fp32 rows, w1_packed = rba_split_weight_f16x2 of
 // fc1.weight [HID, 128], w2_packed of fc2.weight [128, HID], HID % 32 == 0; `out` may be `residual`.  Bit-identical to
-// rba_split_linear_f16x3_gelu_split_out + rba_split_linear_f16x3_frag_f32(residual).  (Mlp + residual of backbone/swin.py:35-41, 292.)
+// rba_split_linear_f16x3_gelu_split_out + rba_split_linear_f16x3_frag_f32(residual).  (Mlp + residual of backbone/swin.py:35-41, 293.)
 extern "C" int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
                                             const float* residual, float* out, int64_t M, int C, int HID, void* stream) {
   RBA_CHECK_ARG(M >= 0 && C == 128 && HID >= 64 && (HID % 32) == 0);

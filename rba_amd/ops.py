@@ -566,7 +566,7 @@ def mlp_fused_ok(M, C, hidden):
 
 @_hip_op
 def mlp_fused(x, fc1, fc2, residual):
-    """residual + fc2(GELU(fc1(x))) in one kernel, in place over `residual` (Mlp + residual add of a Swin block, swin.py:35-41, 292): the
+    """residual + fc2(GELU(fc1(x))) in one kernel, in place over `residual` (Mlp + residual add of a Swin block, swin.py:35-41, 293): the
     hidden tensor stays in registers.  Bit-identical to linear(split_out=True) + linear(residual=...)."""
     lib = _lib.load()
     _chk(x, "x")
