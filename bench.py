@@ -300,7 +300,7 @@ def main():
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     static_out = forward_once(record=False)
                 torch.cuda.synchronize()
             except Exception as e:                 # capture is an optimisation; report and run eagerly
@@ -325,7 +325,7 @@ def main():
                     torch.cuda.current_stream().wait_stream(st)
                     torch.cuda.synchronize()
                     gj = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gj, stream=st):
+                    with torch.cuda.graph(gj, stream=st, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
                         outs = predict_part(static_ins[j])
                     torch.cuda.synchronize()
                     part_graphs.append((gj, st, outs))
