@@ -18,7 +18,8 @@
 
 namespace {
 
-template <bool PROBE_DUMMY = false>
+// PROBE (tune builds only, results wrong): 1 no GELU arithmetic, 2 no fc1 MFMAs, 4 no fc2 MFMAs, 8 no weight staging / barrier in the loop
+template <int PROBE = 0>
 __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __restrict__ X, const u32x4_t* __restrict__ W1p,
                                                               const float* __restrict__ b1, const u32x4_t* __restrict__ W2p,
                                                               const float* __restrict__ b2, const float* R, float* C, int M, int HID) {
@@ -126,8 +127,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
       const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + n);                    // (no null test: a branch here would fence the MFMA / VALU interleaving)
       f32x2 y0 = (f32x2){sl[4 * q], sl[4 * q + 1]} * 0.00048828125f + (f32x2){sm[4 * q], sm[4 * q + 1]};
       f32x2 y1 = (f32x2){sl[4 * q + 2], sl[4 * q + 3]} * 0.00048828125f + (f32x2){sm[4 * q + 2], sm[4 * q + 3]};
-      y0 = gelu_erf2(y0 + (f32x2){bv.x, bv.y});
-      y1 = gelu_erf2(y1 + (f32x2){bv.z, bv.w});
+      y0 = y0 + (f32x2){bv.x, bv.y};
+      y1 = y1 + (f32x2){bv.z, bv.w};
+      if (!(PROBE & 1)) {
+        y0 = gelu_erf2(y0);
+        y1 = gelu_erf2(y1);
+      }
       rba_split_f16x2(y0.x, y0.y, H[q][0], L[q][0]);
       rba_split_f16x2(y1.x, y1.y, H[q][1], L[q][1]);
     };
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) nm[r] = nl[r] = 0.f;
 #pragma unroll
-    for (int b = 0; b < NB1; ++b) {
+    for (int b = 0; b < ((PROBE & 2) ? 0 : NB1); ++b) {
       const f16x8_t wh0 = __builtin_bit_cast(f16x8_t, f1[b][0]), wl0 = __builtin_bit_cast(f16x8_t, f1[b][1]);
       const f16x8_t wh1 = __builtin_bit_cast(f16x8_t, f1[b][2]), wl1 = __builtin_bit_cast(f16x8_t, f1[b][3]);
       nm = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh[b][0], nm, 0, 0, 0);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
       f3[t][1] = w2i[4 * N2 + fb + 2 * N2 + 64 * t];
     }
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
+    for (int t = 0; t < ((PROBE & 4) ? 0 : CT); ++t) {
       const f16x8_t bh0 = __builtin_bit_cast(f16x8_t, f2[t][0]), bl0 = __builtin_bit_cast(f16x8_t, f2[t][1]);
       accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh0, accm[t], 0, 0, 0);
       accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl0, accl[t], 0, 0, 0);
@@ -202,16 +207,18 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase C: fc2's k-half g = 1, and the next unit's weights into the other LDS buffer (last read in iteration j - 1)
     pair(1, ah1, al1);
-    wstore(lds + ((j + 1) & 1) * (W1U + W2U));
-    wload(j + 2);
+    if (!(PROBE & 8)) {
+      wstore(lds + ((j + 1) & 1) * (W1U + W2U));
+      wload(j + 2);
+    }
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
+    for (int t = 0; t < ((PROBE & 4) ? 0 : CT); ++t) {
       const f16x8_t bh1 = __builtin_bit_cast(f16x8_t, f3[t][0]), bl1 = __builtin_bit_cast(f16x8_t, f3[t][1]);
       accm[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh1, accm[t], 0, 0, 0);
       accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl1, accl[t], 0, 0, 0);
       accl[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh1, accl[t], 0, 0, 0);
     }
-    __syncthreads();
+    if (!(PROBE & 8)) __syncthreads();
     sm = nm;
     sl = nl;
   }
@@ -222,7 +229,7 @@ inline int launch_mlp_fused(const float* x, const u32x4_t* w1p, const float* b1,
                             int64_t M, int HID, hipStream_t st) {
   const int64_t MT = (M + 127) / 128;
   if (MT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((mlp_fused_h3_kernel<false>), dim3((unsigned)MT), dim3(256), 0, st, x, w1p, b1, w2p, b2, res, out, (int)M, HID);
+  hipLaunchKernelGGL((mlp_fused_h3_kernel<0>), dim3((unsigned)MT), dim3(256), 0, st, x, w1p, b1, w2p, b2, res, out, (int)M, HID);
   return 0;
 }
 

@@ -3,6 +3,7 @@
 // library contains only the configurations rba_split_linear_f32 dispatches to.
 #include "split_linear_experiments.h"
 #include "../split_linear_h3.h"
+#include "../mlp_fused_h3.h"
 
 // Timing build of one v5 configuration (tools only): dbg[8 wg + {0..3}] = MFMA wave 0 {barrier wait, compute, epilogue, total}
 // cycles, dbg[8 wg + {4..7}] = loader wave 0 {vmcnt wait, barrier wait, issue, total} (s_memtime ticks).
@@ -217,5 +218,22 @@ extern "C" int rba_split_linear_h3_timing(const float* x, const void* weight_pac
   else
     hipLaunchKernelGGL((split_linear_h3_kernel<1, 4, 127, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias,
                        out, (int)M, N, K, (int)MT, NT, dbg);
+  return rba_launch_status();
+}
+
+// ablations of the fused Swin MLP (mlp_fused_h3.h PROBE bits); timing only
+extern "C" int rba_mlp_fused_probe(const float* x, const void* w1p, const float* b1, const void* w2p, const float* b2, const float* res, float* out,
+                                   int64_t M, int HID, int probe, void* stream) {
+  rba_begin();
+  const u32x4_t* a = reinterpret_cast<const u32x4_t*>(w1p);
+  const u32x4_t* b = reinterpret_cast<const u32x4_t*>(w2p);
+  const dim3 grid((unsigned)((M + 127) / 128));
+  hipStream_t st = (hipStream_t)stream;
+#define RBA_P(P) case P: hipLaunchKernelGGL((mlp_fused_h3_kernel<P>), grid, dim3(256), 0, st, x, a, b1, b, b2, res, out, (int)M, HID); break;
+  switch (probe) {
+    RBA_P(0) RBA_P(1) RBA_P(2) RBA_P(4) RBA_P(6) RBA_P(7) RBA_P(8) RBA_P(9) RBA_P(15) RBA_P(14)
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef RBA_P
   return rba_launch_status();
 }
