@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
 #pragma unroll
     for (int i_ = 0; i_ < 24; ++i_) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase B: fc2's k-half g = 0 (12 MFMAs: per tile main, low, low -- the accumulation order of the unfused kernel is g-major within each
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
 #pragma unroll
     for (int i_ = 0; i_ < 12; ++i_) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+      __builtin_amdgcn_sched_group_barrier(0x402, 14, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase C: fc2's k-half g = 1, and the next unit's weights into the other LDS buffer (last read in iteration j - 1)
