@@ -19,8 +19,8 @@ for k in keys:
 tot_cyc = sum(a["GRBM_GUI_ACTIVE"] for a in agg.values()) / 8
 tot_mfma = sum(a["SQ_VALU_MFMA_BUSY_CYCLES"] for a in agg.values()) / 1024
 print(f"steady-state sample: {len(keys)} dispatches, {tot_cyc:.3e} GPU cycles in kernels, matrix pipe busy {tot_mfma / tot_cyc * 100:.1f} % of them\n")
-print("| kernel | calls | % of kernel cycles | matrix-pipe busy | bf16 / f32 MFMA Mops |\n|---|---|---|---|---|")
+print("| kernel | calls | % of kernel cycles | matrix-pipe busy | f16 / bf16 MFMA Mops |\n|---|---|---|---|---|")
 for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:16]:
     cyc = a["GRBM_GUI_ACTIVE"] / 8
     print(f"| `{name[:70]}` | {int(a['calls'])} | {cyc / tot_cyc * 100:.1f} | {a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc * 100:.1f} % | "
-          f"{a['SQ_INSTS_VALU_MFMA_MOPS_BF16']:.3g} / {a['SQ_INSTS_VALU_MFMA_MOPS_F32']:.3g} |")
+          f"{a['SQ_INSTS_VALU_MFMA_MOPS_F16']:.3g} / {a['SQ_INSTS_VALU_MFMA_MOPS_BF16']:.3g} |")
