@@ -278,9 +278,13 @@ def state_dict_shapes(arch: dict) -> dict:
     return out
 
 
-def seeded_weights(arch: dict, seed: int = 0) -> dict:
-    """Random-init weights of ``arch`` by the deterministic recipe of ``seeded_weights.py``."""
+def seeded_weights(arch: dict, seed: int = 0, recipe: str = None) -> dict:
+    """Random-init weights of ``arch`` by the deterministic recipe of ``seeded_weights.py`` (``recipe="heavy"``: its trained-like
+    stress variant)."""
     from .seeded_weights import seeded_state_dict
 
     a = complete(arch)
-    return seeded_state_dict(state_dict_shapes(a), seed, meta=dict(n_heads=a["nheads"], n_points=a["enc_points"]))
+    meta = dict(n_heads=a["nheads"], n_points=a["enc_points"])
+    if recipe is not None:
+        meta["recipe"] = recipe
+    return seeded_state_dict(state_dict_shapes(a), seed, meta=meta)

@@ -1,18 +1,25 @@
 """Checkpoint load path of the evaluator (reference: evaluate_ood.py:118-120 -> Detectron2
 DetectionCheckpointer.resume_or_load(path, resume=False)): ``model_final.pth`` = torch.save({"model": state_dict,
-...}); ``.pkl`` = pickle {"model": {name: ndarray}, "matching_heuristics": True}
-(tools/convert-pretrained-swin-model-to-d2.py:25-30)."""
+...}); ``.pkl`` = pickle {"model": {name: array}, ...}.  Detectron2's model-zoo ``.pkl`` files hold numpy arrays; the ones
+tools/convert-pretrained-swin-model-to-d2.py:24-30 writes hold *torch tensors* (``pkl.dump({"model": torch.load(...)["model"], ...})``),
+whose pickles reference ``torch._utils._rebuild_tensor_v2``: those cannot be read by a numpy-only unpickler and need the
+opt-in below (``trusted=True`` / ``RBA_TRUSTED_CHECKPOINT=1``), because rebuilding a pickled tensor runs the full torch unpickler."""
 import pickle
 
 import numpy as np
 import torch
 
+_TRUST_HINT = ("If you trust this file, load it with the full unpickler: load_checkpoint(..., trusted=True) / "
+               "read_state_dict(path, trusted=True), or set RBA_TRUSTED_CHECKPOINT=1 for get_model() and `python -m rba_amd.evaluate_ood`.")
+
 IGNORED_EXTRA = ("criterion.",)       # criterion.empty_weight is constructed even for eval (maskformer_model.py:148-150)
 
 
 class _TensorsOnlyUnpickler(pickle.Unpickler):
-    """.pkl checkpoints (convert-pretrained-swin-model-to-d2.py) hold a dict of numpy arrays and strings: allow exactly the
-    globals numpy needs to rebuild an ndarray, nothing else -- a pickle can otherwise run arbitrary code on load."""
+    """.pkl checkpoints in Detectron2's model-zoo format hold a dict of numpy arrays and strings: allow exactly the globals numpy
+    needs to rebuild an ndarray, nothing else -- a pickle can otherwise run arbitrary code on load.  (A .pkl that holds torch
+    tensors, as the reference's Swin converter writes, is refused with a hint; torch's rebuild functions are NOT allow-listed:
+    `torch.storage._load_from_bytes` is a full torch.load.)"""
     _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
                 ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"),
                 ("numpy._core.multiarray", "scalar"), ("collections", "OrderedDict")}
@@ -20,8 +27,8 @@ class _TensorsOnlyUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if (module, name) in self._ALLOWED:
             return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"checkpoint pickle references {module}.{name}; only numpy arrays are accepted "
-                                     "(pass trusted=True to load a checkpoint you trust with the full unpickler)")
+        raise pickle.UnpicklingError(f"checkpoint pickle references {module}.{name}; only numpy arrays are accepted by default.  "
+                                     + _TRUST_HINT)
 
 
 def read_state_dict(path, trusted=False):
@@ -32,7 +39,12 @@ def read_state_dict(path, trusted=False):
         with open(path, "rb") as f:
             data = pickle.load(f, encoding="latin1") if trusted else _TensorsOnlyUnpickler(f, encoding="latin1").load()
     else:
-        data = torch.load(path, map_location="cpu", weights_only=not trusted)
+        try:
+            data = torch.load(path, map_location="cpu", weights_only=not trusted)
+        except pickle.UnpicklingError as e:
+            if trusted:
+                raise
+            raise pickle.UnpicklingError(f"{path}: {e}\n{_TRUST_HINT}") from e
     sd = data["model"] if isinstance(data, dict) and "model" in data else data
     out = {}
     for k, v in sd.items():

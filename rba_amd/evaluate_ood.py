@@ -127,8 +127,17 @@ class GraphedScore:
     def __init__(self, model, score_func, stream):
         self.model, self.score_func, self.stream = model, score_func, stream
         self.graphs = {}             # shape -> None (seen once) | (graph, static_in, static_out) | False (capture failed: eager)
+        # score functions that end in MaskFormer.rba_scores are replayed by the model itself (one graph per image shape and stream,
+        # MaskFormer._graphed_scores): nothing to do here.  The others (DenseHybrid: forward(return_ood_pred=True) + torch ops) are
+        # captured whole, below, on a capture stream of this object's own (per-stream kernel state must not be shared between the
+        # graphs of different streams, which replay concurrently).
+        self.delegate = (getattr(score_func, "rba_score_mode", None) is not None and hasattr(model, "_graphed_scores")
+                         and getattr(model, "graph_replay", False))
+        self.capture_stream = None
 
     def __call__(self, x):
+        if self.delegate:
+            return self.score_func(self.model, x[None])
         key = tuple(x.shape)
         entry = self.graphs.get(key, "new")
         if entry == "new":
@@ -139,9 +148,13 @@ class GraphedScore:
             try:
                 static_in = x.clone()
                 g = torch.cuda.CUDAGraph()
-                # captured on torch's capture stream, replayed on self.stream; thread_local: the decode threads pin memory meanwhile
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if self.capture_stream is None:
+                    self.capture_stream = torch.cuda.Stream(device=x.device)
+                self.capture_stream.wait_stream(torch.cuda.current_stream(x.device))
+                # captured on this object's own stream, replayed on self.stream; thread_local: the decode threads pin memory meanwhile
+                with torch.cuda.graph(g, stream=self.capture_stream, capture_error_mode="thread_local"):
                     static_out = self.score_func(self.model, static_in[None])
+                torch.cuda.current_stream(x.device).wait_stream(self.capture_stream)
                 entry = self.graphs[key] = (g, static_in, static_out)
             except Exception as e:                                   # noqa: BLE001 -- an optimisation only
                 print(f"[rba_amd] hipGraph capture failed for shape {key} ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
@@ -178,11 +191,36 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     n_streams = max(1, int(getattr(args, "streams", 3))) if on_gpu else 1
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
+    use_graphs = on_gpu and bool(int(getattr(args, "graph", 0)))
+    prev_replay = getattr(model, "graph_replay", None)
+    if prev_replay is not None:
+        model.graph_replay = use_graphs                         # MaskFormer.rba_scores replays per (image shape, stream)
     graphed = ({id(st_): GraphedScore(model, score_func, st_) for st_ in streams}
-               if on_gpu and int(getattr(args, "graph", 0)) and not args.store_anomaly_scores else None)
+               if use_graphs and not args.store_anomaly_scores else None)
     scores, labels = [], []
     pending = []
     FLUSH = 32
+    fallbacks = []
+
+    def rescored(k_img, x):
+        """The f16x3 arithmetic of the token Linears answers an activation or weight beyond f16's range (|v| >= 65504) with NaN, never
+        with a wrong number (csrc/split_linear_h3.h) -- here that answer is acted upon: the image is scored again, eagerly, on the
+        full-range bf16x6 kernels.  A score that is still not finite is an error of the model or the image, and is raised."""
+        from . import ops
+        with ops.split_mode("bf16x6"):
+            prev = getattr(model, "graph_replay", None)
+            if prev is not None:
+                model.graph_replay = False
+            try:
+                s2 = score_func(model, x[None])
+            finally:
+                if prev is not None:
+                    model.graph_replay = prev
+        if not bool(torch.isfinite(s2).all()):
+            raise FloatingPointError(f"{dataset_name}: image {k_img} has a non-finite anomaly score in the f16x3 AND the bf16x6 arithmetic")
+        fallbacks.append(k_img)
+        print(f"[rba_amd] {dataset_name}: image {k_img}: non-finite score in f16x3 arithmetic, re-scored on the bf16x6 kernels", file=sys.stderr)
+        return s2.reshape(-1)
 
     def flush():
         if not pending:
@@ -191,11 +229,16 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
             for st_ in {p[2] for p in pending}:
                 if st_ is not main_stream:
                     main_stream.wait_stream(st_)
+        # one fused check per chunk: a NaN / inf score must never reach the sort of the rank statistics
+        finite = torch.stack([torch.isfinite(p[0]).all() for p in pending]).cpu()
+        for j in (~finite).nonzero().reshape(-1).tolist():
+            s_, y_, st_, x_, k_img = pending[j]
+            pending[j] = (rescored(k_img, x_), y_, main_stream, x_, k_img)
         ss, yy = select_labelled(torch.cat([p[0] for p in pending]), torch.cat([p[1] for p in pending]))
         if on_gpu:
             for p in pending:                                      # produced on a side stream, last used here on the main stream
-                p[0].record_stream(main_stream)
-                p[1].record_stream(main_stream)
+                for t_ in (p[0], p[1], p[3]):
+                    t_.record_stream(main_stream)
         scores.append(ss)
         labels.append(yy)
         pending.clear()
@@ -240,7 +283,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
                 # serialise host and GPU image by image -- the launches of image i + 1 could not be issued while image i runs
                 # (measured: 2-3 ms of waiting per image and no overlap between streams).  Park (score, label) maps instead and
                 # compact FLUSH images at a time: one wait per FLUSH images, at most FLUSH x 10 MB parked at 1024 x 2048.
-                pending.append((s.reshape(-1), y.reshape(-1), st))
+                pending.append((s.reshape(-1), y.reshape(-1), st, x, i))
                 host["score_calls_s"] += t_b - t_a
             if len(pending) >= FLUSH:
                 t_c = time.perf_counter()
@@ -259,9 +302,13 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if timing is not None:
+        n_graphs = (sum(1 for gs in graphed.values() for e in gs.graphs.values() if isinstance(e, tuple)) if graphed else 0)
+        n_graphs += model.live_graphs() if hasattr(model, "live_graphs") else 0
         timing.update(images=k, seconds=dt, images_per_s=(k / dt if dt > 0 else 0.0), num_workers=nw, streams=len(streams),
-                      hip_graphs=(sum(1 for gs in graphed.values() for e in gs.graphs.values() if isinstance(e, tuple)) if graphed else 0),
+                      hip_graphs=n_graphs, bf16x6_rescored_images=list(fallbacks),
                       host_thread={n: round(v, 3) for n, v in host.items()})
+    if prev_replay is not None:
+        model.graph_replay = prev_replay
     s_all = torch.cat(scores) if scores else torch.empty(0, device=dev)
     y_all = torch.cat(labels) if labels else torch.empty(0, dtype=torch.bool, device=dev)
     return D.pooled_ood_metrics(s_all, y_all)

@@ -32,6 +32,7 @@ class MaskFormer(nn.Module):
         self._mean3 = tuple(float(torch.tensor(v, dtype=torch.float32)) for v in a["pixel_mean"])      # fp32-rounded, as the buffers hold them
         self._std3 = tuple(float(torch.tensor(v, dtype=torch.float32)) for v in a["pixel_std"])
         self.fused_front_end = True
+        self.graph_replay = True        # rba_scores(): batch-1 forwards replayed from a per-shape hipGraph (opt out: False)
         self.fused_upsample = True      # K1 reads the low-res logits and up-samples on the fly (rba_reduce_up4)
         # panoptic inference (maskformer_model.py:202-220): off unless TEST.PANOPTIC_ON
         self.panoptic_on, self.open_panoptic = bool(a["panoptic_on"]), bool(a["open_panoptic"])
@@ -199,10 +200,90 @@ class MaskFormer(nn.Module):
             return results, ood_pred                            # :350-351
         return results
 
+    # ------------------------------------------------------------------ hipGraph replay of the scoring path
+    GRAPH_MAX = 8            # live graphs per model (each keeps its own activation pool: ~1.5 GB at 1024 x 2048)
+
+    def _weights_version(self):
+        v = 0
+        for p_ in self.parameters():
+            v += p_._version
+        return v
+
+    def _graph_key(self, image, return_argmax, score):
+        return (tuple(image.shape), image.dtype, image.device, torch.cuda.current_stream(image.device).cuda_stream, bool(return_argmax), score,
+                self.fused_upsample, self.fused_front_end, ops.SPLIT_MODE, ops.SPLIT_ACTIVATIONS, ops.TILES_MIN, ops.MLP_FUSED_MIN_ROWS,
+                getattr(self.sem_seg_head.predictor, "sparse_intermediate_heads", None), self._weights_version())
+
+    def drop_graphs(self):
+        """Forget every captured graph (their pools are freed); the next calls run eagerly, then capture again."""
+        self.__dict__.pop("_graphs", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.drop_graphs()                  # .to() / .cuda() / .float(): the captured graphs hold the old parameter addresses
+        return super()._apply(fn, *args, **kwargs)
+
+    def _graphed_scores(self, image, return_argmax, score):
+        """One batch-1 image (already on the device) -> (rba, argmax | None), replayed from a hipGraph captured per (image shape, dtype,
+        stream, outputs, arithmetic mode, weight version).  A forward is ~330 kernel launches that take the Python thread 6-7 ms to
+        issue against ~8 ms of GPU time; a caller that waits for every score (the reference's loop does: `.cpu()` per image,
+        support.py:375) therefore pays both in series.  The first call of a key runs eagerly (per-shape constants, weight planes), the
+        second captures, later ones copy the image into the graph's input and replay it on the CURRENT stream; the result is a fresh
+        tensor.  Returns None when the capture failed (the caller then runs eagerly; the failure is remembered for the key)."""
+        graphs = self.__dict__.setdefault("_graphs", {})
+        key = self._graph_key(image, return_argmax, score)
+        entry = graphs.get(key)
+        if entry is None:
+            graphs[key] = "seen"
+            while len(graphs) > self.GRAPH_MAX:                 # oldest first; a graph owns its pool, dropping it frees the memory
+                graphs.pop(next(iter(graphs)))
+            return None
+        if entry == "seen":
+            try:
+                static_in = image.clone()
+                cap = torch.cuda.Stream(device=image.device)       # its own capture stream: per-stream state (K1's tile counter) is this graph's alone
+                cap.wait_stream(torch.cuda.current_stream(image.device))
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                    r = self._rba_scores_eager([{"image": static_in}], return_argmax, score)[0]
+                torch.cuda.current_stream(image.device).wait_stream(cap)
+                entry = graphs[key] = (g, static_in, r, cap)
+            except Exception as e:                                   # noqa: BLE001 -- an optimisation only
+                import sys
+                print(f"[rba_amd] hipGraph capture failed for image shape {tuple(image.shape)} ({type(e).__name__}: {e}); eager launches",
+                      file=sys.stderr)
+                torch.cuda.synchronize(image.device)
+                entry = graphs[key] = False
+        if entry is False:
+            return None
+        graphs[key] = graphs.pop(key)                               # most recently used last
+        g, static_in, r, _ = entry
+        static_in.copy_(image, non_blocking=True)
+        g.replay()
+        return (r[0].clone(), r[1].clone()) if return_argmax else r.clone()
+
+    def live_graphs(self):
+        return sum(1 for e in self.__dict__.get("_graphs", {}).values() if isinstance(e, tuple))
+
     @torch.no_grad()
     def rba_scores(self, batched_inputs, return_argmax=False, score="rba"):
         """Fast path: anomaly-score maps (and optional int32 argmax maps) without materialising sem_seg.
-        score: "rba" (evaluate_ood.py:143-150), "energy" (:152-159) or "neg_logit_sum" (support.py:115-132)."""
+        score: "rba" (evaluate_ood.py:143-150), "energy" (:152-159) or "neg_logit_sum" (support.py:115-132).
+        Batch-1 calls on a HIP device are replayed from a captured hipGraph from the third call of an image shape on
+        (``model.graph_replay = False`` opts out; see _graphed_scores)."""
+        if (self.graph_replay and len(batched_inputs) == 1 and self.device.type == "cuda"
+                and not torch.cuda.is_current_stream_capturing()):
+            image = batched_inputs[0]["image"]
+            if torch.is_tensor(image) and image.dim() == 3 and image.dtype in (torch.uint8, torch.float32) \
+                    and set(batched_inputs[0]) <= {"image"}:
+                image = image.to(self.device, non_blocking=True).contiguous()
+                r = self._graphed_scores(image, return_argmax, score)
+                if r is not None:
+                    return [r]
+                batched_inputs = [{"image": image}]
+        return self._rba_scores_eager(batched_inputs, return_argmax, score)
+
+    @torch.no_grad()
+    def _rba_scores_eager(self, batched_inputs, return_argmax=False, score="rba"):
         mask_cls, mask_pred, sizes, padded = self.predict(batched_inputs)
         out = []
         for i in range(len(batched_inputs)):

@@ -187,12 +187,12 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 ups = [ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d))
                        for b in range(B)]                                                  # :357-358 fused sum
                 yy = ups[0][None] if B == 1 else torch.stack(ups)
-            planes = self._cached(ly, "_rba_conv", lambda: ops.conv3x3_weight(ly.weight.detach()))
+            planes = self._cached(ly, "_rba_conv_" + ops.SPLIT_MODE, lambda: ops.conv3x3_weight(ly.weight.detach()))    # per arithmetic form
             z = ops.conv3x3_nhwc(yy, planes, None, out_features=d)
             prev = ops.group_norm_nhwc(z.view(B, h * w, d), 32, ly.norm.weight, ly.norm.bias, ly.norm.eps, relu=True)
             ph, pw = h, w
         mfw = self.mask_features.weight
-        planes = self._cached(self.mask_features, "_rba_planes",
+        planes = self._cached(self.mask_features, "_rba_mf_planes",
                               lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous(), mode="bf16x6"))
         mf = ops.split_linear_nchw_out(prev.view(B * ph * pw, d), planes, self.mask_features.bias, ph * pw,
                                        out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)

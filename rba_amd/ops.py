@@ -5,6 +5,7 @@ Error behaviour mirrors the reference's native op (pixel_decoder/ops/src/cuda/ms
 AT_ASSERTM on contiguity and device -> RuntimeError): a bad argument raises RuntimeError (RbaHipError); there is
 no fallback path.
 """
+import contextlib
 import functools
 import os
 
@@ -539,12 +540,30 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None, split_o
 
 
 def _cached_planes(lin, w):
-    key = (w.data_ptr(), w._version, w.device, SPLIT_MODE)
-    cache = getattr(lin, "_rba_planes", None)
+    """split_weight(w) of the current SPLIT_MODE, cached on the module per mode (the bf16x6 planes of the non-finite fallback stay
+    beside the f16x3 ones: switching modes does not re-split)."""
+    key = (w.data_ptr(), w._version, w.device)
+    caches = getattr(lin, "_rba_planes", None)
+    if not isinstance(caches, dict):
+        caches = lin._rba_planes = {}
+    cache = caches.get(SPLIT_MODE)
     if cache is None or cache[0] != key:
-        cache = (key, split_weight(w.detach().contiguous()))
-        lin._rba_planes = cache
+        cache = caches[SPLIT_MODE] = (key, split_weight(w.detach().contiguous()))
     return cache[1]
+
+
+@contextlib.contextmanager
+def split_mode(mode):
+    """Run a block with ops.SPLIT_MODE = mode ("f16x3" | "bf16x6"), e.g. to re-score an image whose f16x3 result is not finite
+    (an activation or weight beyond f16's range) on the full-range kernels."""
+    global SPLIT_MODE
+    if mode not in ("f16x3", "bf16x6"):
+        raise RbaHipError(f"unknown split mode {mode!r}")
+    prev, SPLIT_MODE = SPLIT_MODE, mode
+    try:
+        yield
+    finally:
+        SPLIT_MODE = prev
 
 
 SPLIT_ACTIVATIONS = os.environ.get("RBA_SPLIT_ACTIVATIONS", "1") != "0"      # A/B switch (tools): producers keep writing fp32 rows

@@ -20,13 +20,18 @@ The scale per tensor class keeps activations O(1) through the 24 Swin blocks:
   (the ring follows reference ``ops/modules/ms_deform_attn.py:66-74``)
 * every other tensor with dim >= 2                     fan_in**-0.5 n
 * integer buffers (``relative_position_index``) are left untouched.
+
+``meta["recipe"] == "heavy"`` (round 3) is the trained-like stress variant on top of that: norm gammas log-uniform over
+0.1 .. 10, a handful of residual-stream outlier channels at 3e2 .. 1e3 (biases of the patch-embedding norm and of some
+proj / fc2 layers, the "massive activations" of trained transformers), and the last mask-embedding layer scaled so that
+the mask logits reach +-40.
 """
 import math
 import zlib
 
 import torch
 
-__all__ = ["seeded_tensor", "fill_state_dict_", "seeded_state_dict", "deform_ring_bias"]
+__all__ = ["seeded_tensor", "fill_state_dict_", "seeded_state_dict", "deform_ring_bias", "seeded_ood_labels"]
 
 
 def deform_ring_bias(n_heads: int, n_levels: int, n_points: int) -> torch.Tensor:
@@ -86,7 +91,40 @@ def seeded_tensor(key: str, like: torch.Tensor, seed: int = 0, meta: dict = None
         for s in like.shape[1:]:
             fan_in *= int(s)
         out = n * (float(fan_in) ** -0.5)
+    if (meta or {}).get("recipe") == "heavy":
+        out = _heavy(key, like, n, out)
     return out.to(like.dtype)
+
+
+_HEAVY_OUTLIERS = {          # key suffix -> ((channel, value), ...): residual-stream channels far outside the bulk
+    "backbone.patch_embed.norm.bias": ((3, 400.0), (77, -700.0)),
+    "backbone.layers.1.blocks.0.attn.proj.bias": ((11, -300.0),),
+    "backbone.layers.2.blocks.0.mlp.fc2.bias": ((5, 1000.0),),
+    "backbone.layers.2.blocks.9.mlp.fc2.bias": ((130, -600.0), (401, 350.0)),
+    "backbone.layers.3.blocks.0.attn.proj.bias": ((7, 500.0),),
+}
+HEAVY_MASK_EMBED_SCALE = 0.4
+HEAVY_CLASS_EMBED_SCALE = 0.15
+
+
+def _heavy(key, like, n, out):
+    if _is_norm_weight(key, like):
+        return torch.pow(10.0, torch.erf(n / math.sqrt(2.0)))          # log-uniform over 0.1 .. 10
+    for suffix, spots in _HEAVY_OUTLIERS.items():
+        if key.endswith(suffix):
+            out = out.clone()
+            for ch, v in spots:
+                out[ch % out.numel()] += v
+            return out
+    if key.endswith("mask_embed.layers.2.weight"):
+        return out * HEAVY_MASK_EMBED_SCALE
+    if key.endswith("class_embed.bias"):
+        out = out.clone()
+        out[-1] += 3.0
+        return out
+    if key.endswith("class_embed.weight"):
+        return out * HEAVY_CLASS_EMBED_SCALE          # decoder_norm's gammas (up to 10) would otherwise take every query off "void"
+    return out
 
 
 def seeded_state_dict(shapes: dict, seed: int = 0, meta: dict = None) -> dict:
@@ -112,3 +150,23 @@ def fill_state_dict_(module: torch.nn.Module, seed: int = 0, meta: dict = None, 
         if not t.dtype.is_floating_point:
             continue
         t.copy_(seeded_tensor(prefix + key, t, seed, meta))
+
+
+def seeded_ood_labels(h, w, seed, rba=None):
+    """Seeded OoD labels of the metric-parity fixtures (uint8 [h,w]; 1 = OoD, 0 = inlier, 255 = ignored 16-pixel border).
+    rba None: Bernoulli(0.03), independent of the scores (SURVEY.md 8d / BASELINE C3's synthetic labels).
+    rba given (the REFERENCE's score map): anomalies follow the score -- P(OoD) = 0.25 above the map's 0.9 quantile, 0.01 below --
+    so that the ranking statistics are far from chance and every misplaced score moves them."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(h, w, generator=g)
+    if rba is None:
+        lab = (u < 0.03)
+    else:
+        q = torch.quantile(rba.flatten()[:: max(1, rba.numel() // 1000003)].double(), 0.9).item()
+        lab = torch.where(rba > q, u < 0.25, u < 0.01)
+    lab = lab.to(torch.uint8)
+    lab[:16] = 255
+    lab[-16:] = 255
+    lab[:, :16] = 255
+    lab[:, -16:] = 255
+    return lab

@@ -10,6 +10,42 @@ from . import ops
 from .metrics import ood_metrics, select_labelled
 
 
+class _HostRing:
+    """Device -> host copies through `depth` reusable pinned staging buffers: push() enqueues an asynchronous copy and returns; the
+    slot's previous content is delivered (copied into a pageable numpy array, handed to its sink) when the slot comes round again or
+    at drain().  Page-locked memory: `depth` maps, whatever the number of images."""
+
+    def __init__(self, depth=4):
+        self.depth = depth
+        self.slots = [None] * depth             # [pinned buffer, event, sink | None]
+        self.n = 0
+
+    def _deliver(self, slot):
+        buf, ev, sink = slot
+        if sink is not None:
+            ev.synchronize()
+            sink(np.array(buf.numpy(), copy=True))
+            slot[2] = None
+
+    def push(self, t, sink):
+        i = self.n % self.depth
+        self.n += 1
+        slot = self.slots[i]
+        if slot is not None:
+            self._deliver(slot)
+        if slot is None or slot[0].shape != t.shape or slot[0].dtype != t.dtype:
+            slot = self.slots[i] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True), torch.cuda.Event(), None]
+        slot[0].copy_(t, non_blocking=True)
+        slot[1].record(torch.cuda.current_stream(t.device))
+        slot[2] = sink
+
+    def drain(self):
+        for k in range(self.depth):             # oldest first
+            slot = self.slots[(self.n + k) % self.depth]
+            if slot is not None:
+                self._deliver(slot)
+
+
 class OODEvaluator:
     def __init__(self, model, inference_func: Callable, anomaly_score_func: Callable):
         self.model = model
@@ -51,43 +87,90 @@ class OODEvaluator:
 
     def compute_anomaly_scores(self, loader, device=torch.device("cpu"), return_preds=False,
                                use_gaussian_smoothing=False, upper_limit=450):
-        """Batch-1 scoring loop (support.py:353-399).  Returns numpy arrays like the reference."""
+        """Batch-1 scoring loop (support.py:353-399).  Returns numpy arrays like the reference.
+
+        Device -> host: the reference's `.cpu()` per image (support.py:375, 390) stalls the stream once per image; here every map goes
+        through a small ring of reusable pinned staging buffers (`_HostRing`: 4 slots, events) into its final pageable numpy array, so
+        the launch thread never waits for the image it has just issued and page-locked memory stays at a few maps.
+        Non-finite scores: the f16x3 token Linears answer |value| >= 65504 with NaN (never a wrong number); once per CHUNK of images a
+        fused `isfinite` flag per image is read back, and an image whose score is not finite is scored again on the full-range bf16x6
+        kernels before anything reaches the rank statistics (FloatingPointError if that is not finite either)."""
         anomaly_score, ood_gts, predictions = [], [], []
         on_gpu = torch.device(device).type == "cuda"
+        ring = _HostRing(4) if on_gpu else None
+        mode = getattr(self.anomaly_score_func, "rba_score_mode", None)         # set on rba_amd.evaluate_ood's score functions
+        CHUNK = 16
+        chunk = []                                                              # (index, x, finite flag) of scores not yet checked
+        self.bf16x6_rescored_images = []
 
-        def to_host(t):
-            """device -> pinned host buffer without blocking the launch thread (the reference's .cpu() per image, support.py:375,
-            390, stalls the stream once per image); everything is synchronised once after the loop"""
-            if not (on_gpu and t.is_cuda):
-                return t.cpu()
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            h.copy_(t, non_blocking=True)
-            return h
+        def score_one(x):
+            preds = None
+            if return_preds and mode is not None and hasattr(self.model, "rba_scores"):
+                # one forward instead of the reference's two (support.py:380,386)
+                score, preds = self.model.rba_scores([{"image": x[0]}], return_argmax=True, score=mode)[0]
+                preds = preds.to(torch.int64).unsqueeze(0)
+            else:
+                score = self.get_anomaly_score(x)
+                if return_preds:
+                    preds = self.get_logits(x)[:, :19].max(dim=1)[1]
+            if use_gaussian_smoothing:                                          # transforms.GaussianBlur(7, sigma=1), support.py:366-383
+                score = ops.gaussian_blur(score.contiguous(), 7, 1.0)
+            return score, preds
+
+        def store(lst, idx, t):
+            while len(lst) <= idx:
+                lst.append(None)
+            if ring is not None and t.is_cuda:
+                ring.push(t, lambda a, lst=lst, idx=idx: lst.__setitem__(idx, a))
+            else:
+                lst[idx] = t.cpu().numpy()
+
+        def check_chunk():
+            if not chunk:
+                return
+            finite = torch.stack([c[2] for c in chunk]).cpu()                   # one read-back per chunk
+            for (idx, x, _), ok in zip(chunk, finite.tolist()):
+                if ok:
+                    continue
+                prev = getattr(self.model, "graph_replay", None)
+                with ops.split_mode("bf16x6"):
+                    if prev is not None:
+                        self.model.graph_replay = False
+                    try:
+                        score, preds = score_one(x)
+                    finally:
+                        if prev is not None:
+                            self.model.graph_replay = prev
+                if not bool(torch.isfinite(score).all()):
+                    raise FloatingPointError(f"image {idx}: non-finite anomaly score in the f16x3 AND the bf16x6 arithmetic")
+                self.bf16x6_rescored_images.append(idx)
+                store(anomaly_score, idx, score)
+                if return_preds:
+                    store(predictions, idx, preds)
+            chunk.clear()
 
         for jj, (x, y) in enumerate(loader):
             if jj >= upper_limit:
                 break
             x = x.to(device, non_blocking=True)
             ood_gts.append(np.asarray(y.cpu()))
-            mode = getattr(self.anomaly_score_func, "rba_score_mode", None)     # set on rba_amd.evaluate_ood's score functions
-            if return_preds and mode is not None and hasattr(self.model, "rba_scores"):
-                # one forward instead of the reference's two (support.py:380,386)
-                score, preds = self.model.rba_scores([{"image": x[0]}], return_argmax=True, score=mode)[0]
-                predictions.append(to_host(preds.to(torch.int64).unsqueeze(0)))
-            else:
-                score = self.get_anomaly_score(x)
-                if return_preds:
-                    logits = self.get_logits(x)
-                    predictions.append(to_host(logits[:, :19].max(dim=1)[1]))
-            if use_gaussian_smoothing:                                  # transforms.GaussianBlur(7, sigma=1), support.py:366-383
-                score = ops.gaussian_blur(score.contiguous(), 7, 1.0)
-            anomaly_score.append(to_host(score))
-        if on_gpu:
-            torch.cuda.synchronize(device)
+            score, preds = score_one(x)
+            store(anomaly_score, jj, score)
+            if return_preds:
+                store(predictions, jj, preds)
+            if score.is_cuda:
+                chunk.append((jj, x, torch.isfinite(score).all()))
+                if len(chunk) >= CHUNK:
+                    check_chunk()
+            elif not bool(torch.isfinite(score).all()):
+                raise FloatingPointError(f"image {jj}: non-finite anomaly score")
+        check_chunk()
+        if ring is not None:
+            ring.drain()
         ood_gts = np.array(ood_gts)
-        anomaly_score = np.array([t.numpy() for t in anomaly_score])
+        anomaly_score = np.array(anomaly_score)
         if return_preds:
-            return anomaly_score, ood_gts, np.array([t.numpy() for t in predictions])
+            return anomaly_score, ood_gts, np.array(predictions)
         return anomaly_score, ood_gts
 
     def evaluate_ood_bootstrapped(self, dataset, ratio, trials, device=torch.device("cpu"), batch_size=1, num_workers=10):

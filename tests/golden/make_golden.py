@@ -41,7 +41,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
 
-from rba_amd.seeded_weights import fill_state_dict_  # noqa: E402
+from rba_amd.seeded_weights import fill_state_dict_, seeded_ood_labels as parity_labels  # noqa: E402
 
 
 # --------------------------------------------------------------------------------------
@@ -378,11 +378,61 @@ def g_swin_parts(R):
     save("g3_swin_parts", **out)
 
 
-def g_end_to_end(R, arch, h, w, seed, img_seed, full_outputs, name, npix=4096):
+def _ref_model(R, arch, seed, recipe=None):
     a = ARCHS[arch]
     torch.manual_seed(0)
     model = RefModel(R, a).eval()
-    fill_state_dict_(model, seed, meta=dict(n_heads=a["nheads"], n_points=4))
+    meta = dict(n_heads=a["nheads"], n_points=4)
+    if recipe is not None:
+        meta["recipe"] = recipe
+    fill_state_dict_(model, seed, meta=meta)
+    return model
+
+
+def sk_metrics(score, gt):
+    """AUROC / AuPRC / FPR95 exactly as support.py:247-303 computes them (flat arrays; labels 1 = OoD, 0 = inlier, rest ignored)."""
+    from sklearn.metrics import roc_curve, auc, average_precision_score
+    score, gt = np.asarray(score).reshape(-1), np.asarray(gt).reshape(-1)
+    ood_out, ind_out = score[gt == 1], score[gt == 0]
+    val_out = np.concatenate((ind_out, ood_out))
+    val_label = np.concatenate((np.zeros(len(ind_out)), np.ones(len(ood_out))))
+    aupr = average_precision_score(val_label, val_out)
+    fpr, tpr, thr = roc_curve(val_label, val_out)
+    roc_auc = auc(fpr, tpr)
+    fpr_best = 0
+    for i, j, k in zip(tpr, fpr, thr):
+        if i > 0.95:
+            fpr_best = j
+            break
+    return np.array([roc_auc, aupr, fpr_best])
+
+
+def g_metric_parity(R, arch, h, w, seed, img_seeds, name):
+    """BASELINE configs[4]'s deliverable (and its configs[1] twin): AUROC / AuPRC / FPR95 of the REFERENCE's RbA maps on seeded
+    images under seeded labels, pooled over the images as evaluate_ood.py:195-235 + support.py:247-303 pool them.  Stored: the
+    three statistics for two label sets (independent Bernoulli labels regenerated from their seeds by the test; score-correlated
+    labels stored as packed bits), per-image score summaries, nothing else."""
+    model = _ref_model(R, arch, seed)
+    scores, lab_a, lab_b = [], [], []
+    for s in img_seeds:
+        o = ref_forward(model, rand_image(h, w, s))
+        scores.append(np_(o["rba"]))
+        lab_a.append(np_(parity_labels(h, w, 7000 + s)))
+        lab_b.append(np_(parity_labels(h, w, 9000 + s, o["rba"])))
+        print(f"  {name}: image seed {s} rba mean {o['rba'].mean():.4f}")
+    sc = np.stack(scores)
+    la, lb = np.stack(lab_a), np.stack(lab_b)
+    ma, mb = sk_metrics(sc, la), sk_metrics(sc, lb)
+    print(f"  {name}: independent labels auroc/aupr/fpr95 {ma}; score-correlated labels {mb}")
+    save(name, arch=np.array(arch), hw=np.array([h, w]), seed=np.array(seed), img_seeds=np.array(img_seeds),
+         label_seed_offsets=np.array([7000, 9000]), metrics_indep=ma, metrics_corr=mb,
+         labels_corr_bits=np.packbits((lb == 1).reshape(len(img_seeds), -1), axis=1),
+         rba_mean=sc.reshape(len(img_seeds), -1).mean(1), n_ood=np.array([(la == 1).sum(), (lb == 1).sum()]))
+
+
+def g_end_to_end(R, arch, h, w, seed, img_seed, full_outputs, name, npix=4096, recipe=None):
+    a = ARCHS[arch]
+    model = _ref_model(R, arch, seed, recipe)
     image = rand_image(h, w, img_seed)
     taps = {}
     o = ref_forward(model, image, taps)
@@ -392,8 +442,12 @@ def g_end_to_end(R, arch, h, w, seed, img_seed, full_outputs, name, npix=4096):
     gap = (top2[0] - top2[1]).min().item()
     print(f"  {name}: rba [{o['rba'].min():.3f},{o['rba'].max():.3f}] mean {o['rba'].mean():.3f}; "
           f"pred_masks std {o['pred_masks'].std():.2f}; attn-mask margin {margin:.2e}; argmax top-2 gap {gap:.2e}")
+    if recipe is not None:
+        fe = taps["feats"]
+        print(f"  {name} [{recipe}]: pred_masks [{o['pred_masks'].min():.1f},{o['pred_masks'].max():.1f}]; max|res2..res5| "
+              + ", ".join(f"{fe[k].abs().max():.0f}" for k in sorted(fe)) + f"; near-tie pixels (<1e-4) {(int(((top2[0] - top2[1]) < 1e-4).sum()))}")
     arrs = dict(arch=np.array(arch), hw=np.array([h, w]), seed=np.array(seed), img_seed=np.array(img_seed),
-                attn_mask_margin=np.array(margin), argmax_gap=np.array(gap),
+                recipe=np.array(recipe or "base"), attn_mask_margin=np.array(margin), argmax_gap=np.array(gap),
                 pred_logits=np_(o["pred_logits"]))
     if full_outputs:
         arrs.update(image=np_(image), pred_masks=np_(o["pred_masks"]), sem_seg=np_(sem), rba=np_(o["rba"]),
@@ -503,6 +557,11 @@ def main():
         jobs["g5c4"] = lambda: g_end_to_end(R, "swin_l_1dl", 512, 1024, 0, 1234, False, "g5_swin_l_1dl_512x1024")
         # ... and at C4's real size
         jobs["g5c4full"] = lambda: g_end_to_end(R, "swin_l_1dl", 1024, 2048, 0, 1234, False, "g5_swin_l_1dl_1024x2048")
+        # trained-like dynamic range (seeded_weights "heavy" recipe): gammas 0.1..10, residual outlier channels, mask logits to +-40
+        jobs["g5heavy"] = lambda: g_end_to_end(R, "swin_b_1dl", 512, 1024, 0, 1234, False, "g5_swin_b_1dl_heavy_512x1024", recipe="heavy")
+        # metric parity (BASELINE configs[4] "AuPRC/FPR95 parity check" and its configs[1] twin): 4 images each
+        jobs["g7c5"] = lambda: g_metric_parity(R, "swin_b_9dl", 720, 1280, 0, [1234, 1235, 1236, 1237], "g7_metrics_swin_b_9dl_720x1280")
+        jobs["g7c2"] = lambda: g_metric_parity(R, "swin_b_1dl", 1024, 2048, 0, [1234, 1235, 1236, 1237], "g7_metrics_swin_b_1dl_1024x2048")
     for k, fn in jobs.items():
         if args.only and k != args.only:
             continue

@@ -293,3 +293,60 @@ def test_split_activations_layout_and_predicate():
         assert not ops.linear_takes_split(8192, 2048, 512)
     finally:
         ops.SPLIT_MODE = old
+
+
+def test_shape_cache_pins_what_a_capture_reads(monkeypatch):
+    """a hipGraph replay never calls ShapeCache.get, so entries a capture read must not be LRU victims."""
+    from rba_amd import lru
+    c = lru.ShapeCache(2)
+    built = []
+
+    def mk(k):
+        return lambda: built.append(k) or ("v", k)
+    c.get("a", mk("a"))
+    c.get("b", mk("b"))
+    monkeypatch.setattr(lru, "_capturing", lambda: True)
+    assert c.get("a", mk("a")) == ("v", "a") and c.pinned() == 1           # read during a capture: pinned
+    assert c.get("z", mk("z")) == ("v", "z") and "z" not in c._d and "z" not in c._pinned       # built during a capture: never shared
+    monkeypatch.setattr(lru, "_capturing", lambda: False)
+    for k in "cdefg":
+        c.get(k, mk(k))
+    assert c.get("a", mk("a")) == ("v", "a") and built.count("a") == 1    # survived five evictions
+    assert len(c._d) == 2 and len(c) == 3
+    c.get("b", mk("b"))
+    assert built.count("b") == 2                                           # unpinned entries are still bounded
+
+
+def test_heavy_recipe_and_seeded_labels(golden):
+    """the trained-like stress recipe is deterministic, touches what it says, and the metric-parity fixtures' score-independent
+    labels regenerate from their seeds"""
+    from rba_amd.seeded_weights import seeded_ood_labels
+    a = A.complete(A.ARCHS["swin_b_1dl"])
+    base, heavy = A.seeded_weights(a, 0), A.seeded_weights(a, 0, recipe="heavy")
+    assert all(torch.equal(heavy[k], v) for k, v in A.seeded_weights(a, 0, recipe="heavy").items())
+    gam = heavy["backbone.layers.2.blocks.3.norm1.weight"]
+    assert 0.1 <= gam.min() < 0.2 and 5 < gam.max() <= 10
+    assert heavy["backbone.patch_embed.norm.bias"][77] < -600 and heavy["backbone.layers.2.blocks.0.mlp.fc2.bias"][5] > 900
+    same = [k for k in base if torch.equal(base[k], heavy[k])]
+    assert "backbone.layers.0.blocks.0.attn.qkv.weight" in same and "backbone.layers.2.blocks.3.norm1.weight" not in same
+    for fixture in ("g7_metrics_swin_b_9dl_720x1280", "g7_metrics_swin_b_1dl_1024x2048"):
+        g = golden(fixture)
+        h, w = (int(v) for v in g["hw"])
+        off = int(g["label_seed_offsets"][0])
+        labs = [seeded_ood_labels(h, w, off + int(s)) for s in g["img_seeds"]]
+        assert sum(int((l == 1).sum()) for l in labs) == int(g["n_ood"][0])
+        assert all(int((l == 255).sum()) == h * w - (h - 32) * (w - 32) for l in labs)
+        bits = np.unpackbits(g["labels_corr_bits"], axis=1)[:, : h * w]
+        assert int(bits.sum()) == int(g["n_ood"][1])
+        assert 0.80 < float(g["metrics_corr"][0]) < 0.85 and abs(float(g["metrics_indep"][0]) - 0.5) < 0.01
+
+
+def test_checkpoint_pickle_with_torch_tensors_is_refused_with_a_hint(tmp_path):
+    """tools/convert-pretrained-swin-model-to-d2.py pickles torch tensors: refused by default, the message says how to opt in"""
+    from rba_amd.checkpoint import read_state_dict
+    pth = tmp_path / "swin.pkl"
+    with open(pth, "wb") as f:
+        pickle.dump({"model": {"w": torch.ones(2, 2)}, "matching_heuristics": True}, f)
+    with pytest.raises(pickle.UnpicklingError, match="RBA_TRUSTED_CHECKPOINT=1"):
+        read_state_dict(str(pth))
+    assert torch.equal(read_state_dict(str(pth), trusted=True)["w"], torch.ones(2, 2))

@@ -523,13 +523,13 @@ def test_split_linear_dispatch_and_errors(ops):
     x = torch.randn(2, 16384, 512, device="cuda")
     assert ops.split_linear_pays(32768, 2048, 512, gelu=True) and not ops.split_linear_pays(100, 2048, 512, gelu=True)
     y = ops.linear(x, lin, gelu=True)
-    assert getattr(lin, "_rba_planes", None) is not None and lin._rba_planes[1].dtype == torch.float16, "f16x3 path not taken"
+    assert getattr(lin, "_rba_planes", None) is not None and lin._rba_planes["f16x3"][1].dtype == torch.float16, "f16x3 path not taken"
     assert maxerr(y, F.gelu(F.linear(x.double(), lin.weight.double(), lin.bias.double()))) < 3e-5
-    planes_before = lin._rba_planes[1]
+    planes_before = lin._rba_planes["f16x3"][1]
     with torch.no_grad():
         lin.weight.mul_(2.0)                                                 # new weights -> planes are re-split
     y2 = ops.linear(x, lin, use_bias=False)
-    assert lin._rba_planes[1] is not planes_before
+    assert lin._rba_planes["f16x3"][1] is not planes_before
     assert maxerr(y2, F.linear(x.double(), lin.weight.double())) < 3e-5
     small = torch.nn.Linear(96, 100).cuda()                                   # unsupported shape -> hipBLASLt, same result contract
     assert maxerr(ops.linear(x[..., :96].contiguous(), small), F.linear(x[..., :96].double(), small.weight.double(), small.bias.double())) < 3e-5

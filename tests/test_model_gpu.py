@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
-def build(name, seed=0):
+def build(name, seed=0, recipe=None):
     from rba_amd.checkpoint import load_checkpoint
     from rba_amd.maskformer_model import MaskFormer
     a = A.complete(A.ARCHS[name])
-    sd = A.seeded_weights(a, seed)
+    sd = A.seeded_weights(a, seed, recipe=recipe)
     model = load_checkpoint(MaskFormer(a), sd).cuda().eval()
     return model, a, sd
 
@@ -120,7 +120,8 @@ def _full_size(golden, fixture, arch_name, tol_rba):
     the COMPLETE argmax map -- a flip is forgiven only at a pixel whose two best classes are closer than 1e-4 in the
     reference's own output (their indices are in the fixture), and the count of flips is asserted, not printed."""
     g = golden(fixture)
-    model, a, sd = build(arch_name, int(g["seed"]))
+    recipe = str(g["recipe"]) if "recipe" in g else "base"
+    model, a, sd = build(arch_name, int(g["seed"]), None if recipe == "base" else recipe)
     h, w = (int(v) for v in g["hw"])
     gen = torch.Generator().manual_seed(int(g["img_seed"]))
     image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
@@ -187,6 +188,52 @@ def test_full_size_swin_b_9dl_720x1280(golden):
     _full_size(golden, "g5_swin_b_9dl_720x1280", "swin_b_9dl", 1e-4)
 
 
+def test_heavy_tailed_weights_swin_b_512x1024(golden):
+    """Trained-like dynamic range (seeded_weights "heavy": LayerNorm / GroupNorm gammas log-uniform over 0.1..10, residual-stream
+    outlier channels at 3e2..1e3, mask logits to +-34, RbA in its un-saturated range) through the default f16x3 arithmetic against
+    the reference's own modules: the same bars as the base recipe (|d rba| < 1e-4, no argmax flip outside the near-tie set)."""
+    from rba_amd import ops
+    assert ops.SPLIT_MODE == "f16x3"
+    _full_size(golden, "g5_swin_b_1dl_heavy_512x1024", "swin_b_1dl", 1e-4)
+
+
+@pytest.mark.parametrize("fixture, arch_name", [("g7_metrics_swin_b_9dl_720x1280", "swin_b_9dl"),
+                                                ("g7_metrics_swin_b_1dl_1024x2048", "swin_b_1dl")])
+def test_metric_parity_full_size(golden, fixture, arch_name):
+    """BASELINE configs[4] "AuPRC/FPR95 parity check" (Swin-B 9dl, 720x1280) and its configs[1] twin: AUROC / AuPRC / FPR95 of the
+    product's RbA maps on four seeded images, pooled as evaluate_ood.py:195-235 pools them, against the SAME statistics of the
+    reference's maps computed with scikit-learn by the support.py:247-303 logic (tests/golden/make_golden.py::g_metric_parity),
+    under score-independent Bernoulli(0.03) labels and under labels that follow the reference's score.  North star: 3 decimals."""
+    from rba_amd.metrics import ood_metrics, select_labelled
+    from rba_amd.seeded_weights import seeded_ood_labels
+    g = golden(fixture)
+    model, a, _ = build(arch_name, int(g["seed"]))
+    h, w = (int(v) for v in g["hw"])
+    off_a, off_b = (int(v) for v in g["label_seed_offsets"])
+    scores, lab_a, lab_b = [], [], []
+    for i, s in enumerate(int(v) for v in g["img_seeds"]):
+        gen = torch.Generator().manual_seed(s)
+        image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
+        rba = model.rba_scores([{"image": image}])[0]
+        assert abs(float(rba.mean()) - float(g["rba_mean"][i])) < 1e-4
+        scores.append(rba)
+        la = seeded_ood_labels(h, w, off_a + s)
+        lb = la.clone()
+        ood = T(np.unpackbits(g["labels_corr_bits"][i])[: h * w].reshape(h, w))
+        lb[lb != 255] = ood[lb != 255]
+        lab_a.append(la)
+        lab_b.append(lb)
+    sc = torch.stack(scores)
+    for labs, key, n_ood in ((lab_a, "metrics_indep", int(g["n_ood"][0])), (lab_b, "metrics_corr", int(g["n_ood"][1]))):
+        lab = torch.stack(labs).cuda()
+        assert int((lab == 1).sum()) == n_ood
+        got = ood_metrics(*select_labelled(sc, lab))
+        want = dict(zip(("auroc", "aupr", "fpr95"), (float(v) for v in g[key])))
+        d = {k: abs(got[k] - want[k]) for k in want}
+        print(f"{fixture} {key}: reference {want} product {got} |d| {d}")
+        assert all(v < 5e-4 for v in d.values()), d
+
+
 def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
     """`python -m rba_amd.evaluate_ood` flow: models folder (config.yaml + model_final.pth) x datasets on disk ->
     results/<model>/results.pkl = {dataset: {auroc, aupr, fpr95}} (evaluate_ood.py:238-288), checked against the oracle."""
@@ -224,7 +271,7 @@ def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
         scores = np.stack([ref_model.forward(torch.from_numpy(im.transpose(2, 0, 1).copy()), sd, a)["rba"].numpy() for im in imgs])
         want = ref_metrics.evaluate_ood(scores, np.stack(labs)[:, None])
         for k in want:
-            assert abs(res[name][k] - want[k]) < 2e-3, (name, k, res[name][k], want[k])     # rank statistics of scores that agree to ~1e-6
+            assert abs(res[name][k] - want[k]) < 5e-4, (name, k, res[name][k], want[k])     # north star: 3 decimals
     # second run: results exist -> skipped, file untouched
     mtime = (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns
     E.main(argv)
@@ -450,10 +497,10 @@ def test_split_mode_switch_bf16x6_matches_f16x3(monkeypatch):
     assert ops.SPLIT_MODE == "f16x3"
     r3 = model.rba_scores([{"image": image}])[0].clone()
     fc1 = model.backbone.layers[2].blocks[0].mlp.fc1
-    assert fc1._rba_planes[1].dtype == torch.float16
+    assert fc1._rba_planes["f16x3"][1].dtype == torch.float16
     monkeypatch.setattr(ops, "SPLIT_MODE", "bf16x6")
     r6 = model.rba_scores([{"image": image}])[0]
-    assert fc1._rba_planes[1].dtype == torch.bfloat16
+    assert fc1._rba_planes["bf16x6"][1].dtype == torch.bfloat16
     assert (r3 - r6).abs().max().item() < 5e-5
     monkeypatch.setattr(ops, "SPLIT_MODE", "f16x3")
     assert torch.equal(model.rba_scores([{"image": image}])[0], r3)

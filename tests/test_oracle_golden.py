@@ -146,12 +146,14 @@ def test_c_oracle_k1_k2(golden):
 
 @pytest.mark.parametrize("fixture,arch_name", [("g5_swin_b_1dl_1024x2048", "swin_b_1dl"),
                                                ("g5_swin_b_9dl_720x1280", "swin_b_9dl"),
-                                               ("g5_swin_l_1dl_512x1024", "swin_l_1dl")])
+                                               ("g5_swin_l_1dl_512x1024", "swin_l_1dl"),
+                                               ("g5_swin_b_1dl_heavy_512x1024", "swin_b_1dl")])
 def test_end_to_end_full_size(golden, fixture, arch_name):
     """BASELINE configs C2 / C5 at full size: oracle vs sampled outputs of the reference's own modules (about 10 s each)."""
     g = golden(fixture)
     a = A.complete(A.ARCHS[arch_name])
-    sd = A.seeded_weights(a, int(g["seed"]))
+    recipe = str(g["recipe"]) if "recipe" in g else "base"            # "heavy": the trained-like dynamic-range stress recipe
+    sd = A.seeded_weights(a, int(g["seed"]), recipe=None if recipe == "base" else recipe)
     h, w = (int(v) for v in g["hw"])
     gen = torch.Generator().manual_seed(int(g["img_seed"]))
     image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
