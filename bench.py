@@ -83,6 +83,13 @@ def exchange_inputs(rank, h, w, device):
     return lab, valid
 
 
+def baseline_config(arch, h, w):
+    """which BASELINE.json config a run corresponds to (the label in `config.workload`)"""
+    return {("swin_b_1dl", 1024, 2048): "BASELINE.json configs[1]; per GPU also configs[2]'s shard",
+            ("swin_l_1dl", 1024, 2048): "BASELINE.json configs[3]",
+            ("swin_b_9dl", 720, 1280): "BASELINE.json configs[4]"}.get((arch, h, w), "not a BASELINE.json configuration")
+
+
 def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0):
     """the oracle (oracle/ref_model.py + oracle/ref_ops.py = CPU restatement of the reference path,
     pinned by tests/golden) timed on this box's host cores, fp32, no_grad, batch 1, after a warm-up, median of repeated runs:
@@ -214,6 +221,7 @@ def self_launch(args):
 
 
 def main():
+    t_cmd0 = time.perf_counter()
     args = parse()
     from rba_amd import arch as A
     from rba_amd import distributed as D
@@ -229,11 +237,24 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = D.init_from_env(os.environ.get("RBA_BENCH_BACKEND", "gloo" if share else None))
     if world != args.gpus:
+        if not share and "RBA_BENCH_BACKEND" not in os.environ:
+            raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE {world}: one rank per GPU is the contract")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = torch.distributed if world > 1 else None
+    n_ranks_seen, backend_seen = 1, None
+    if dist is not None:
+        backend_seen = dist.get_backend()
+        if not share and "RBA_BENCH_BACKEND" not in os.environ:
+            # a real multi-GPU run: RCCL (torch's "nccl" backend on ROCm), one rank per device
+            assert backend_seen == "nccl", f"multi-GPU bench must run on RCCL (backend 'nccl'), got {backend_seen!r}"
+            assert torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world)), "fewer visible devices than local ranks"
+        ones = torch.ones(1, dtype=torch.int64, device=dev if backend_seen == "nccl" else "cpu")
+        dist.all_reduce(ones)                                   # the collective library's own count of participating ranks
+        n_ranks_seen = int(ones.item())
+        assert n_ranks_seen == world == dist.get_world_size(), (n_ranks_seen, world)
 
     a = A.complete(A.ARCHS[args.arch])
     model = load_checkpoint(MaskFormer(a), A.seeded_weights(a, 0)).to(dev).eval()
@@ -386,11 +407,15 @@ def main():
         step(i)
     k1_events.clear()
     barrier()
+    ev_first, ev_last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_first.record()
     for i in range(args.steps):
         out = step(args.warmup + i)
+    ev_last.record()                                   # main stream: every step ends there (the streams join before K1)
     barrier()
     elapsed = time.perf_counter() - t0
+    gpu_busy_s = ev_first.elapsed_time(ev_last) * 1e-3   # device-side span of the timed steps, first launch to last completion
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -479,6 +504,58 @@ def main():
         except Exception as e:                                           # informational only
             print(f"[bench] K6 roofline probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
 
+    # ---- K1 in the three forms the reference's consumers need, each on the live tensors of the last step, HIP events
+    # on the launch stream, outside the timed region: score only (the line's `roofline`), + sem_seg materialised (the stock
+    # get_RbA / get_logits read out[0]["sem_seg"], maskformer_model.py:381-386), + the int32 argmax map (support.py:385-388)
+    k1_forms = None
+    single = None
+    if rank == 0:
+        try:
+            with torch.no_grad():
+                mask_cls, mask_pred, sizes, padded = model.predict([{"image": static_in}])
+                prob = torch.softmax(mask_cls[0], dim=-1)[..., :-1].contiguous()
+                up = ops.resample_bilinear(mask_pred[0].contiguous(), padded)
+                k1_forms = {}
+                for name, (ws_, wa_), extra in (("score_only", (False, False), 0), ("with_sem_seg", (True, False), 4 * K * H * W),
+                                                ("with_sem_seg_and_argmax", (True, True), 4 * K * H * W + 4 * H * W)):
+                    for _ in range(2):
+                        ops.rba_reduce(up, prob, ws_, wa_)
+                    evs = []
+                    for _ in range(10):
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record(); ops.rba_reduce(up, prob, ws_, wa_); e1.record()
+                        evs.append((e0, e1))
+                    torch.cuda.synchronize()
+                    ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+                    nb = 4 * Q * H * W + 4 * Q * K + 4 * H * W + extra
+                    k1_forms[name] = {"algorithmic_bytes_per_launch": nb, "avg_launch_ms": ms, "achieved_GBps": nb / (ms * 1e-3) / 1e9,
+                                      "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": len(evs)}
+                del up
+        except Exception as e:                                           # informational only
+            print(f"[bench] K1 form probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        # ---- the same step on ONE stream, one image at a time (what a caller that scores serially gets): eager launches, and the
+        # model's own per-shape hipGraph replay (MaskFormer.rba_scores, the drop-in path of get_RbA); the caller waits for every score
+        try:
+            n1 = max(10, min(args.steps, 30))
+            single = {}
+            prev_fused = model.fused_upsample
+            for label, replay in (("eager", False), ("model_graph_replay", True)):
+                model.graph_replay = replay
+                model.fused_upsample = True                                # the product default of rba_scores (K1-up4)
+                for i in range(3):
+                    model.rba_scores([{"image": images[i % len(images)]}])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n1):
+                    r1 = model.rba_scores([{"image": images[i % len(images)]}])[0]
+                    r1.sum().item()                                        # the serial caller reads every score back (reference: .cpu() per image)
+                single[label] = n1 / (time.perf_counter() - t1)
+            model.fused_upsample = prev_fused
+            model.graph_replay = True
+            model.drop_graphs()
+        except Exception as e:
+            print(f"[bench] single-stream probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
+
     traffic = None
     pmc = os.path.join(REPO, "profiles", "k1_pmc.json")
     if args.k1 == "fullres" and os.path.exists(pmc):
@@ -503,7 +580,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per stream per step "
-                                   f"(BASELINE.json configs[1]); random-init seeded weights",
+                                   f"({baseline_config(args.arch, h, w)}); random-init seeded weights",
                        "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",
@@ -512,14 +589,46 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg_ms,
                          "min_launch_ms": k1_ms[0], "launches_timed": len(k1_ms)},
         }
+        # ---- whole-step roofline: algorithmic flops and bytes of every stage (rba_amd/cost_model.py, table in
+        # DESIGN.md section 5) over the measured time per image
+        try:
+            from rba_amd import cost_model
+            tot = cost_model.totals(a, h, w)
+            img_s = res["value"] / world                                 # per GPU
+            f16x3_ceiling = BF16_PEAK_TFLOPS / 3.0
+            res["roofline_e2e"] = {
+                "algorithmic_flops_per_image": tot["flops"], "algorithmic_bytes_per_image": tot["bytes"],
+                "images_per_s_per_gpu": img_s,
+                "achieved_GBps": tot["bytes"] * img_s / 1e9, "frac_of_hbm_peak": tot["bytes"] * img_s / 1e9 / HBM_PEAK_GBS,
+                "achieved_fp32_equivalent_tflops": tot["flops"] * img_s / 1e12,
+                "f16x3_ceiling_tflops": f16x3_ceiling, "frac_of_f16x3_ceiling": tot["flops"] * img_s / 1e12 / f16x3_ceiling,
+                "fp32_mfma_peak_tflops": 157.3, "x_fp32_mfma_peak": tot["flops"] * img_s / 1e12 / 157.3,
+                "note": "fp32-equivalent flops (2 per multiply-add) and unfused per-operator bytes, rba_amd/cost_model.py; the ceiling is the dense f16 "
+                        "MFMA peak / 3 (three f16 products per fp32 product)",
+                "stages": [{"stage": n_, "gflop": round(f_ / 1e9, 2), "mb": round(b_ / 1e6, 2)} for n_, f_, b_ in tot["stages"]]}
+        except Exception as e:
+            print(f"[bench] roofline_e2e skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        if k1_forms is not None:
+            res["roofline_k1_forms"] = k1_forms
+        if single is not None:
+            res["single_stream_images_per_s"] = single["eager"] if "eager" in single else None
+            res["single_stream"] = {"images_per_s": single, "what": "one image at a time on one stream through MaskFormer.rba_scores (fused x4 upsample + K1), "
+                                    "the caller reads every score back before issuing the next image"}
+        res["n_ranks_seen"] = n_ranks_seen
+        res["dist_backend"] = backend_seen
         if gemm is not None:
             res["roofline_gemm"] = gemm
         if exch_ms is not None:
             res["metric_exchange_ms"] = exch_ms
             res["pooled_metrics"] = m
+        t_gpu_done = time.perf_counter()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.arch, h, w, k1_gpu_ms=k1_avg_ms if args.k1 == "fullres" else None,
                                                budget_scale=args.cpu_budget)
+        # where the command's wall time goes: the timed region is short by contract (K steps); the CPU baseline is most of the rest
+        res["wall_time_s"] = {"command_total": time.perf_counter() - t_cmd0, "timed_region": elapsed,
+                              "setup_warmup_probes_gpu_phase": t_gpu_done - t_cmd0 - elapsed, "cpu_baseline": time.perf_counter() - t_gpu_done,
+                              "gpu_span_of_timed_region_s": gpu_busy_s}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -114,6 +114,11 @@ def build_parser():
                    help="1: replay the forward of each (stream, image shape) from a captured hipGraph -- the scoring thread then issues one "
                         "launch per image instead of ~370 (it is the bottleneck beside the decode threads); falls back to eager launches "
                         "if the capture fails")
+    p.add_argument("--dist_backend", type=str, default=os.environ.get("RBA_EVAL_BACKEND") or None, choices=[None, "nccl", "gloo"],
+                   help="torch.distributed backend under torchrun (default: nccl = RCCL when a HIP device is visible, else gloo)")
+    p.add_argument("--share_device", type=int, default=int(os.environ.get("RBA_EVAL_SHARE_DEVICE", "0")),
+                   help="1: every rank uses device 0 and the metric exchange runs on gloo -- a plumbing test of the sharded evaluator on a "
+                        "one-GPU box (RCCL refuses two ranks on one device), never a measurement")
     return p
 
 
@@ -327,8 +332,12 @@ def main(argv=None):
     from . import distributed as D
     from .datasets import available_datasets, get_dataset
     args = build_parser().parse_args(argv)
-    rank, world, local = D.init_from_env()
+    if args.share_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = D.init_from_env(args.dist_backend or ("gloo" if args.share_device else None))
     device = torch.device(args.device, local) if args.device == "cuda" else torch.device(args.device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
     names = args.selected_datasets if args.dataset_mode == "selective" else ["road_anomaly", "fishyscapes_laf"]
     if not names:
         raise ValueError("Selective Mode is chosen but number of selected datasets is 0")

@@ -130,7 +130,9 @@ def _full_size(golden, fixture, arch_name, tol_rba):
     gy, gx = T(g["gy"]).long(), T(g["gx"]).long()
     e_logits = maxerr(mask_cls[0], g["pred_logits"])
     e_masks = maxerr(mask_pred[0].cpu()[:, ys4, xs4], g["pred_masks_s"])
-    assert e_logits < 1e-4 and e_masks < 5e-4, (e_logits, e_masks)
+    # mask logits: 5e-4 at the base recipe's range (|x| <~ 10); the heavy recipe's reach +-34, the bound scales with the range
+    tol_masks = 5e-4 * max(1.0, float(np.abs(g["pred_masks_s"]).max()) / 10.0)
+    assert e_logits < 1e-4 and e_masks < tol_masks, (e_logits, e_masks, tol_masks)
     ref_arg = T(g["argmax_full"].astype(np.int64))
     tie = torch.zeros(h * w, dtype=torch.bool)
     tie[T(g["neartie_idx"])] = True
@@ -556,3 +558,108 @@ def test_fused_front_end_matches_library_path(name, h, w):
         assert r1.shape == r0.shape == (h, w)
         assert (r1 - r0).abs().max().item() < 2e-5
 
+
+
+def test_evaluate_ood_two_ranks_share_device_equals_single_process(tmp_path):
+    """The sharded evaluator itself (image i -> rank i mod world, pooled ranking of all ranks' labelled pixels, support.py:275-290) under
+    `torch.distributed.run --nproc-per-node 2`: both ranks on device 0, metric exchange over gloo (--share_device 1; RCCL refuses two
+    ranks on one device) -- results.pkl must equal the single-process file."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import yaml
+    from tests.test_datasets_cpu import make_fs_laf, make_road_anomaly
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = A.complete(A.ARCHS["tiny1"])
+    mdir = tmp_path / "ckpts" / "tiny"
+    mdir.mkdir(parents=True)
+    cfg = {"MODEL": {"SWIN": {"EMBED_DIM": 32, "DEPTHS": [2, 2, 2, 2], "NUM_HEADS": [1, 2, 4, 8], "WINDOW_SIZE": 6},
+                     "SEM_SEG_HEAD": {"CONVS_DIM": 64, "MASK_DIM": 64, "TRANSFORMER_ENC_LAYERS": 2,
+                                      "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res5"]},
+                     "MASK_FORMER": {"HIDDEN_DIM": 64, "NHEADS": 2, "NUM_OBJECT_QUERIES": 16, "DIM_FEEDFORWARD": 128, "DEC_LAYERS": 2}}}
+    (mdir / "config.yaml").write_text(yaml.safe_dump(cfg))
+    torch.save({"model": A.seeded_weights(a, 0)}, mdir / "model_final.pth")
+    data = tmp_path / "data"
+    make_road_anomaly(str(data), n=7, h=96, w=160)                 # odd image counts: the shards are unequal
+    make_fs_laf(str(data), n=5, h=80, w=144)
+    common = ["--models_folder", str(tmp_path / "ckpts"), "--datasets_folder", str(data), "--verbose", "0", "--num_workers", "2"]
+    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, "-m", "rba_amd.evaluate_ood"] + common + ["--out_path", str(tmp_path / "single")],
+                        env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29631", "-m", "rba_amd.evaluate_ood"] + common +
+                        ["--out_path", str(tmp_path / "sharded"), "--share_device", "1"],
+                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    with open(tmp_path / "single" / "tiny" / "results.pkl", "rb") as f:
+        one = pickle.load(f)
+    with open(tmp_path / "sharded" / "tiny" / "results.pkl", "rb") as f:
+        two = pickle.load(f)
+    assert sorted(one) == sorted(two) == ["fishyscapes_laf", "road_anomaly"]
+    for d in one:
+        for k in one[d]:
+            assert abs(one[d][k] - two[d][k]) < 1e-12, (d, k, repr(one[d][k]), repr(two[d][k]))
+
+
+def test_model_graph_replay_equals_eager_and_survives_shape_churn():
+    """MaskFormer.rba_scores replays a captured hipGraph from the third call of an image shape: bit-identical to the eager launches,
+    per stream, and -- ADVICE r2 -- three interleaved image shapes do not evict each other's per-shape constants (the ShapeCache
+    pins what a capture read)."""
+    model, a, _ = build("tiny3", 0)
+    shapes = [(60, 90), (64, 96), (96, 64), (48, 80), (80, 112)]
+    g = torch.Generator().manual_seed(3)
+    imgs = [[torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8).cuda() for _ in range(3)] for h, w in shapes]
+    model.graph_replay = False
+    want = [[model.rba_scores([{"image": im}], return_argmax=True)[0] for im in row] for row in imgs]
+    model.graph_replay = True
+    for rnd in range(4):                                            # round 0 eager, round 1 captures, rounds 2-3 replay, shapes interleaved
+        for si, row in enumerate(imgs):
+            for ii, im in enumerate(row):
+                rba, arg = model.rba_scores([{"image": im}], return_argmax=True)[0]
+                assert torch.equal(rba, want[si][ii][0]) and torch.equal(arg, want[si][ii][1]), (rnd, si, ii)
+    assert model.live_graphs() == len(shapes)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                   # another stream: its own graphs
+        for rnd in range(3):
+            r = model.rba_scores([{"image": imgs[0][1]}])[0]
+            assert torch.equal(r, want[0][1][0])
+    torch.cuda.current_stream().wait_stream(side)
+    assert model.live_graphs() == len(shapes) + 1
+    model.cpu()
+    assert model.live_graphs() == 0
+
+
+def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
+    """A residual-stream value beyond f16's range makes the f16x3 Linear answer NaN (never a wrong number); both evaluator loops must
+    catch the non-finite map before it reaches the rank statistics and score that image again on the full-range bf16x6 kernels."""
+    from rba_amd import evaluate_ood as E
+    from rba_amd import ops
+    from rba_amd.support import OODEvaluator
+    monkeypatch.setattr(ops, "TILES_MIN", 1)                        # the tiny net's Linears on K6 too (they are below the product's tile threshold)
+    model, a, sd = build("tiny3", 0)
+    with torch.no_grad():                                           # one LayerNorm output channel at 1e5: beyond f16 (65504), fine in fp32 / bf16x6
+        model.backbone.layers[1].blocks[0].norm1.bias[3] = 1.0e5
+    g = torch.Generator().manual_seed(8)
+    imgs = [torch.randint(0, 256, (3, 128, 192), generator=g, dtype=torch.uint8) for _ in range(3)]
+    model.graph_replay = False
+    bad = model.rba_scores([{"image": imgs[0].cuda()}])[0]
+    if bool(torch.isfinite(bad).all()):
+        pytest.skip("this geometry does not run the f16x3 Linear on the poisoned activation")
+    with ops.split_mode("bf16x6"):
+        want = [model.rba_scores([{"image": im.cuda()}])[0] for im in imgs]
+    assert all(bool(torch.isfinite(w_).all()) for w_ in want)
+    model.graph_replay = True
+    ev = OODEvaluator(model, E.get_logits, E.get_RbA)
+    gt = torch.zeros(1, 128, 192, dtype=torch.long)
+    gt[:, 10:40, 10:60] = 1
+    scores, gts = ev.compute_anomaly_scores([(im[None], gt) for im in imgs], device=torch.device("cuda"))
+    assert np.isfinite(scores).all() and ev.bf16x6_rescored_images == [0, 1, 2]
+    for s_, w_ in zip(scores, want):
+        assert np.array_equal(s_, w_.cpu().numpy())
+    r = ev.evaluate_ood(scores, gts, verbose=False)
+    assert all(np.isfinite(v) for v in r.values())
