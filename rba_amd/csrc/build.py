@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["rba_reduce.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn.hip", "mask_logits.hip",
            "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "split_linear_dma.hip", "gaussian_blur.hip", "open_panoptic.hip", "dense_hybrid.hip", "patch_embed.hip"]
-HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "mlp_fused_h3.h", "swin_window_attn_h3.h",
+HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h",
            os.path.join("..", "..", "include", "rba_hip.h")]
 TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip")]
 TUNE_LIB = os.path.join(HERE, "tune", "librba_tune.so")
@@ -17,6 +17,24 @@ LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+# Matrix-pipe kernels are compiled WITHOUT packed fp32 instructions.  Measured on MI355X (tools/micro/mfma_valu_overlap.hip,
+# profiles/r03_mfma_valu_overlap.txt): v_pk_fma_f32 / v_pk_mul_f32 execute on the matrix pipe's own datapath -- issued beside
+# v_mfma_f32_32x32x16_f16 (from the same or from another wave of the SIMD) their time ADDS to the MFMAs' time, while plain v_fma_f32 /
+# v_mul_f32 / v_exp_f32 / v_rcp_f32 / conversions / integer ops of another wave run entirely in the MFMAs' shadow.  A GELU or softmax
+# written with packed arithmetic ("half the VALU issues") therefore stalls the very MFMAs it was meant to hide under.  The target
+# feature switch makes the backend scalarise every <2 x float> operation of these files (results are bit-identical).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+MFMA_SOURCES = {"split_linear.hip", "split_linear_dma.hip", "mask_logits.hip", "masked_xattn.hip", "skinny_linear.hip"}
+
+
+def _run(cmd):
+    """hipcc also hands the device-only target feature to its host pass, which answers with one warning per use: drop those lines"""
+    r = subprocess.run(cmd, cwd=HERE, stderr=subprocess.PIPE, text=True)
+    err = "\n".join(ln for ln in r.stderr.splitlines() if "not a recognized feature for this target" not in ln)
+    if err.strip():
+        print(err, file=sys.stderr, flush=True)
+    if r.returncode:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
 
 
 def _stale(target, deps) -> bool:
@@ -39,10 +57,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src):
         s, o = os.path.join(HERE, src), os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if src in MFMA_SOURCES else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True, cwd=HERE)
+            _run(cmd)
         return o
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
@@ -59,7 +77,16 @@ def build_tune(force: bool = False, verbose: bool = True) -> str:
     deps = [os.path.join(HERE, f) for f in TUNE_SOURCES + HEADERS + [os.path.join("tune", "split_linear_experiments.h"), os.path.join("tune", "rba_reduce_experiments.h")]]
     if not force and not _stale(TUNE_LIB, deps):
         return TUNE_LIB
-    cmd = [HIPCC] + FLAGS + ["-shared"] + [os.path.join(HERE, f) for f in TUNE_SOURCES] + ["-o", TUNE_LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    objs = []
+    for src in TUNE_SOURCES:
+        o = os.path.join(OBJ, "tune_" + os.path.basename(src).replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if "split_linear" in src else []) + ["-c", os.path.join(HERE, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        _run(cmd)
+        objs.append(o)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", TUNE_LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)

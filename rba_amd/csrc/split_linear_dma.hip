@@ -7,7 +7,13 @@
 //   * fewer than 256 such tiles (Swin stage 4 at one image): 128 x 64 tiles, persistent workgroups -- twice the workgroups, so every
 //     CU still gets two.
 #include "split_linear_h3.h"
+#include "split_linear_h3q.h"
 #include "mlp_fused_h3.h"
+
+// A/B switch for tools and tests (not part of the ABI contract): 0 = product dispatch, 1 = always the round-2 pipelined 128 x 128 kernel
+// (split_linear_h3p_kernel), 2 = the sub-tile kernel with the deferred epilogue (split_linear_h3q.h) wherever it applies, 100 + p = its ablation builds
+extern "C" __attribute__((visibility("default"))) int rba_k6_variant = 0;
+extern "C" __attribute__((visibility("default"))) int rba_k6_stagger = 0;
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {
@@ -113,8 +119,22 @@ extern "C" int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* w
   rba_begin();
   const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
   hipStream_t st = (hipStream_t)stream;
-  const int rc = h3p_single_resident(M, N) ? launch_h3p_pre_act<1>(act, x_frag, wp, bias, residual, out, M, N, K, st)
-                                           : launch_h3p_pre_act<2>(act, x_frag, wp, bias, residual, out, M, N, K, st);
+  int rc;
+  // Where the sub-tile kernel wins (tools/k6_h3q_ab.py on the Swin-B / Swin-L / C5 shapes, profiles/r03_k6_h3q.txt): launches of fewer than 256
+  // tiles of 128 x 128, where the 128 x 128 kernel leaves every SIMD a single wave (Swin stage 4: proj 30 -> 22 us, fc2 91 -> 66 us; C5 stage 3-4
+  // fc2 1.5x); with 256 tiles or more its doubled A-operand traffic (a 64-column sub-tile re-reads the row panel twice as often) costs more
+  // than the second wave and the deferred epilogue bring (stage-3 qkv 45 -> 61 us), so those stay on the 128 x 128 kernel.
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const bool sub_tiles = rba_k6_variant == 2 || (rba_k6_variant == 0 && tiles128 < (residual ? 256 : 200));
+  if (sub_tiles && h3q_supported(M, N, K)) {
+    if (residual) rc = launch_h3q<H3Q_RES, 0>(x_frag, wp, bias, residual, out, M, N, K, st);
+    else if (act == 1) rc = launch_h3q<H3Q_F32, 1>(x_frag, wp, bias, nullptr, out, M, N, K, st);
+    else if (act == 2) rc = launch_h3q<H3Q_F32, 2>(x_frag, wp, bias, nullptr, out, M, N, K, st);
+    else rc = launch_h3q<H3Q_F32, 0>(x_frag, wp, bias, nullptr, out, M, N, K, st);
+  } else {
+    rc = h3p_single_resident(M, N) ? launch_h3p_pre_act<1>(act, x_frag, wp, bias, residual, out, M, N, K, st)
+                                   : launch_h3p_pre_act<2>(act, x_frag, wp, bias, residual, out, M, N, K, st);
+  }
   if (rc) return rc;
   return rba_launch_status();
 }
@@ -131,7 +151,18 @@ extern "C" int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_spl
   const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (h3p_single_resident(M, N))
+  if (x_is_split && rba_k6_variant >= 100 && h3q_supported(M, N, K)) {            // tools: ablation builds of the sub-tile kernel
+    switch (rba_k6_variant - 100) {
+#define H3Q_PROBE(P) case P: rc = launch_h3q<H3Q_SPLIT, 1, P>(x, wp, bias, nullptr, out_frag, M, N, K, st); break;
+      H3Q_PROBE(1) H3Q_PROBE(2) H3Q_PROBE(4) H3Q_PROBE(8) H3Q_PROBE(16) H3Q_PROBE(3) H3Q_PROBE(7) H3Q_PROBE(15) H3Q_PROBE(31) H3Q_PROBE(5)
+#undef H3Q_PROBE
+      default: rc = launch_h3q<H3Q_SPLIT, 1>(x, wp, bias, nullptr, out_frag, M, N, K, st);
+    }
+  } else if (x_is_split && h3q_supported(M, N, K) && (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768)))
+    // fc1 + GELU with the epilogue deferred into the next sub-tile's k loop: pays from K = 768 (Swin-L stage 3: 165 -> 143 us; at K = 512 the
+    // epilogue units are a larger share of a 16-block loop and the doubled A traffic wins: 65 -> 71 us)
+    rc = launch_h3q<H3Q_SPLIT, 1>(x, wp, bias, nullptr, out_frag, M, N, K, st);
+  else if (h3p_single_resident(M, N))
     rc = x_is_split ? launch_h3p_fout<1, true, 1>(x, wp, bias, out_frag, M, N, K, st) : launch_h3p_fout<1, false, 1>(x, wp, bias, out_frag, M, N, K, st);
   else
     rc = x_is_split ? launch_h3p_fout<1, true, 2>(x, wp, bias, out_frag, M, N, K, st) : launch_h3p_fout<1, false, 2>(x, wp, bias, out_frag, M, N, K, st);

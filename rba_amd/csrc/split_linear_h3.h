@@ -25,6 +25,9 @@
 #pragma once
 #include "split_linear_dma.h"
 
+// tools-only knobs (exported by split_linear_dma.hip; zero in the product): see the `stagger` parameter of split_linear_h3p_kernel
+extern "C" int rba_k6_stagger;
+
 namespace {
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -508,9 +511,15 @@ template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC
 __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
-                                                                 const float* R = nullptr, ConvShape cs = ConvShape{0, 0, 0}) {
+                                                                 const float* R = nullptr, ConvShape cs = ConvShape{0, 0, 0}, int stagger = 0) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
+  // experiment (tools): the second workgroup of every CU (the dispatcher hands out workgroups 256 .. 511 after every CU has its first)
+  // starts `stagger` ticks of the 100 MHz clock late, so that the two workgroups of a CU reach their epilogues at different times
+  if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(8);
+  }
   constexpr int CT = 4, BM = 128, BN = 128;
   constexpr int SUBW = 4 * BN, BLK = 2 * SUBW, UPL = BLK / 256;
   __shared__ __attribute__((aligned(16))) u32x4_t lds_all[2 * BLK * KS];
@@ -813,7 +822,7 @@ int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const f
   const int NT = (N + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, OCC, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
-                     reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr, res);
+                     reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr, res, ConvShape{0, 0, 0}, rba_k6_stagger);
   return 0;
 }
 // out = the split fragment image of act(x W^T + bias) (FOUT); x either fp32 rows or a split image (PRE)
@@ -824,7 +833,7 @@ int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* o
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, false, OCC, PRE, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(x), wp, bias, reinterpret_cast<float*>(out_frag), (int)M, N, K, (int)MT, NT, nullptr,
-                     nullptr);
+                     nullptr, ConvShape{0, 0, 0}, rba_k6_stagger);
   return 0;
 }
 // 3 x 3 convolution (pad 1) over the split image of NHWC activations: M = B H W output pixels, K = 9 Cin (two workgroups per CU)

@@ -39,12 +39,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias, float* __restrict__ out,
     int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale) {
   constexpr int HD = 32, NP = NT * 16, PL = NP * 64;                         // bytes per f16 plane
+  // NT = 9 is only ever launched for 12 x 12 windows (144 tokens = 9 full key tiles): a compile-time window size turns the token -> (row,
+  // column) divisions of the gather into multiply-shifts and removes the "key beyond the window" tests of the softmax (round 3: K5 is
+  // bound by the instructions it issues -- ~9 waves per SIMD per stage-3 launch at ~600 VALU instructions each -- not by the matrix pipe)
+  if (NT == 9) ws = 12;
   extern __shared__ __attribute__((aligned(16))) unsigned char k5h_lds[];
   unsigned char* Kh = k5h_lds;                                                  // + PL: Kl; + 2 PL: Vh; + 3 PL: Vl
   int* tok = reinterpret_cast<int*>(k5h_lds + 4 * PL);
   int* rid = tok + NP;
-  const int N = ws * ws;
+  const int N = NT == 9 ? 144 : ws * ws;
   const int wx = blockIdx.x, wy = blockIdx.y;
+  // the shift mask (swin.py:413-440) only separates tokens inside the LAST row / column of windows: everywhere else all 144 tokens share
+  // region 0 and the 36 compare / add pairs per lane are skipped (workgroup-uniform branch)
+  const bool need_mask = shift > 0 && (wy == (int)gridDim.y - 1 || wx == (int)gridDim.x - 1);
   const int h = blockIdx.z % nH, b = blockIdx.z / nH;
   const int C = nH * HD;
   const int64_t tok_stride = 3 * (int64_t)C;
@@ -189,18 +196,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       S[c] = a0;
     }
     // ---- shift mask, padding keys; row max
-    const int myrid = rid[qt];
     float m = -INFINITY;
+    if (need_mask) {
+      const int myrid = rid[qt];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const int k0i = c * 16 + kk * 4;
+        const int4 kr4 = *reinterpret_cast<const int4*>(rid + k0i);
+        const int krid[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (krid[r] != myrid) S[c][r] += -100.0f;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
       const int k0i = c * 16 + kk * 4;
-      const int4 kr4 = *reinterpret_cast<const int4*>(rid + k0i);
-      const int krid[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = S[c][r];
-        if (shift > 0 && krid[r] != myrid) v += -100.0f;
-        if (k0i + r >= N) v = -INFINITY;
+        if (NT != 9 && k0i + r >= N) v = -INFINITY;
         S[c][r] = v;
         m = fmaxf(m, v);
       }
@@ -208,11 +223,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
     m = fmaxf(m, __shfl_xor(m, 16, RBA_WAVE));
     m = fmaxf(m, __shfl_xor(m, 32, RBA_WAVE));
     float lsum = 0.f;
+    const float mneg = -m * 1.44269504088896340736f;                              // exp(s - m) = exp2(s log2(e) - m log2(e)): one fma + v_exp_f32
 #pragma unroll
     for (int c = 0; c < NT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(S[c][r] - m);
+        const float p = __builtin_amdgcn_exp2f(fmaf(S[c][r], 1.44269504088896340736f, mneg));
         S[c][r] = p;
         lsum += p;
       }
