@@ -91,6 +91,12 @@ int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes
 int rba_msda_prepare_f32(const float* raw, const float* reference_points, const int64_t* spatial_shapes, float* loc, float* attw,
                          int64_t rows, int M, int L, int P, void* stream);
 
+/* MSDeformAttn.forward's core in one launch: sampling locations + softmax (ms_deform_attn.py:95-115) computed inside the gather kernel
+ * from `raw` (layout as rba_msda_prepare_f32), reference_points [N*Lq, L, 2], value [N, S, M, 32] -> out [N, Lq, M*32].
+ * head_dim 32, P = 4, L in {1, 3}; bit-identical to rba_msda_prepare_f32 + rba_ms_deform_attn_fwd_f32. */
+int rba_msda_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* raw,
+                       const float* reference_points, float* out, int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+
 /* K3.  Masked multi-head cross attention core (projections are done by the caller):
  * q [B,Q,nH,hd] (already includes the in_proj bias, NOT yet scaled), k,v [B,S,nH,hd];
  * mask_logits [B,Q,S] or NULL: key s is blocked for query q (all heads) iff sigmoid(mask_logits) < 0.5,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_msda_prepare_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "rba_msda_fused_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_masked_xattn_workspace_bytes": [_i, _i, _i, _i],
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_mask_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],

@@ -353,6 +353,10 @@ int launch_reduce_pk(const float* mask, const float* prob, float* rba, float* se
   if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   const int64_t cap = 256 * WPS;
   int64_t grid = tiles;
+  // no more tiles than workgroup slots (e.g. 736 x 1280: 920 tiles on 1024 slots): every workgroup takes exactly one tile, and fetching it from
+  // the atomic counter (two barriers, an atomic round trip, the exit count) only delays its first loads -- measured 0.54 -> 0.67 of 8 TB/s
+  // (tools/k1_sweep.py 60 --hw 736 1280, profiles/r03_k1_c5.txt); the dynamic hand-out pays when workgroups take several tiles each
+  if (tiles <= cap) counters = nullptr;
   if (tiles > cap) {
     const int64_t rounds = (tiles + cap - 1) / cap;
     grid = counters ? cap : (tiles + rounds - 1) / rounds;

@@ -222,16 +222,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
     }
     m = fmaxf(m, __shfl_xor(m, 16, RBA_WAVE));
     m = fmaxf(m, __shfl_xor(m, 32, RBA_WAVE));
-    float lsum = 0.f;
-    const float mneg = -m * 1.44269504088896340736f;                              // exp(s - m) = exp2(s log2(e) - m log2(e)): one fma + v_exp_f32
+    // exp(s - m) = exp2(s log2(e) - m log2(e)): one packed fma per PAIR of scores + v_exp_f32 each; the row sum in packed pairs too (this
+    // kernel is bound by the vector instructions it issues, and its MFMAs are short dependent chains with nothing to hide under)
+    const float mneg = -m * 1.44269504088896340736f;
+    f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NT; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(S[c][r], 1.44269504088896340736f, mneg));
-        S[c][r] = p;
-        lsum += p;
+      for (int r = 0; r < 4; r += 2) {
+        const f32x2 t = (f32x2){S[c][r], S[c][r + 1]} * 1.44269504088896340736f + mneg;
+        const f32x2 pp = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        S[c][r] = pp.x;
+        S[c][r + 1] = pp.y;
+        ls2 += pp;
       }
+    float lsum = ls2.x + ls2.y;
     lsum += __shfl_xor(lsum, 16, RBA_WAVE);
     lsum += __shfl_xor(lsum, 32, RBA_WAVE);
     // ---- O = P . V: 32 keys (two key tiles) per step, two 16-wide d tiles, main + low accumulators

@@ -362,6 +362,33 @@ def msda_prepare(raw, reference_points, spatial_shapes, M, L, P):
     return loc, attw
 
 
+def msda_fused_ok(D, L, P):
+    """Geometries of the one-launch deformable attention core (head_dim 32, 4 points, 1 or 3 levels: every released configuration)."""
+    return D == 32 and P == 4 and L in (1, 3)
+
+
+@_hip_op
+def msda_fused(value, spatial_shapes, level_start_index, raw, reference_points, M, L, P):
+    """MSDeformAttn.forward's core in one launch: value [N,S,M,32], raw [N,Lq,M*L*P*3] (offsets | logits of the fused sampling Linear),
+    reference_points [N,Lq,L,2] -> [N,Lq,M*32]; sampling locations and the softmax over the L*P logits are computed inside the gather
+    kernel (bit-identical to msda_prepare + ms_deform_attn_forward)."""
+    lib = _lib.load()
+    _chk(value, "value", dim=4)
+    _chk(spatial_shapes, "spatial_shapes", torch.int64, 2)
+    _chk(level_start_index, "level_start_index", torch.int64, 1)
+    _chk(raw, "raw", dim=3)
+    _chk(reference_points, "reference_points", dim=4)
+    N, S, M2, D = value.shape
+    _, Lq, W3 = raw.shape
+    if (M2 != M or not msda_fused_ok(D, L, P) or W3 != 3 * M * L * P or raw.shape[0] != N or tuple(reference_points.shape) != (N, Lq, L, 2)
+            or spatial_shapes.shape[0] != L or level_start_index.shape[0] != L):
+        raise RbaHipError("msda_fused: shapes do not match (head_dim 32, P = 4, L in {1, 3})")
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    _lib.check(lib.rba_msda_fused_f32(_p(value), _p(spatial_shapes), _p(level_start_index), _p(raw), _p(reference_points), _p(out),
+                                      N, S, M, D, L, Lq, P, _stream()), "rba_msda_fused_f32")
+    return out
+
+
 @_hip_op
 def merge_layer_norm(x, H, W, weight, bias, eps=1e-5):
     """PatchMerging's gather + LayerNorm: x [B, H*W, C] -> [B, ceil(H/2)*ceil(W/2), 4C] = LN over the 2x2 neighbourhoods in the order

@@ -836,3 +836,37 @@ def test_msda_prepare(ops, N, Lq, M, L, P):
     assert torch.equal(loc2.cpu(), loc)
     assert maxerr(w2, weights) < 2e-7
 
+
+
+@pytest.mark.parametrize("N,Lq,L,edge", [(1, 2048, 1, False), (1, 19320, 3, False), (2, 333, 3, True), (1, 77, 1, True)])
+def test_msda_fused_equals_prepare_plus_forward(ops, N, Lq, L, edge):
+    """round 3: the one-launch deformable attention core (sampling locations + softmax computed inside the locality-mapped gather kernel)
+    is bit-identical to rba_msda_prepare_f32 + the generic rba_ms_deform_attn_fwd_f32 kernel, which the reference-generated K2 fixtures pin;
+    `edge`: reference points and offsets that push samples across and beyond the image border (zero taps, skipped samples)"""
+    import ctypes
+    from rba_amd import _lib
+    M, D, P = 8, 32, 4
+    g = torch.Generator().manual_seed(N * Lq + L)
+    if L == 3:
+        hw = [(92, 160), (46, 80), (23, 40)] if Lq == 19320 else [(12, 20), (6, 10), (3, 5)]
+    else:
+        hw = [(32, 64)] if Lq == 2048 else [(7, 11)]
+    shapes = torch.tensor(hw, dtype=torch.int64)
+    S = int(shapes.prod(1).sum())
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, M, D, generator=g)
+    raw = torch.randn(N, Lq, 3 * M * L * P, generator=g) * (6.0 if edge else 1.5)
+    ref_pts = torch.rand(N, Lq, L, 2, generator=g) * (1.4 if edge else 1.0) - (0.2 if edge else 0.0)
+    loc, w = ops.msda_prepare(dev(raw), dev(ref_pts), dev(shapes), M, L, P)
+    fused = ops.msda_fused(dev(value), dev(shapes), dev(lsi), dev(raw), dev(ref_pts), M, L, P)
+    two_step = ops.ms_deform_attn_forward(dev(value), dev(shapes), dev(lsi), loc, w)          # round-3 kernel, parameters from memory
+    variant = ctypes.c_int.in_dll(_lib.load(), "rba_k2_variant")
+    variant.value = 1
+    try:
+        generic = ops.ms_deform_attn_forward(dev(value), dev(shapes), dev(lsi), loc, w)       # the kernel the K2 fixtures pin
+    finally:
+        variant.value = 0
+    assert torch.equal(fused, two_step) and torch.equal(fused, generic)
+    from oracle import ref_ops
+    want = ref_ops.ms_deform_attn(value.double(), shapes, loc.cpu().double(), w.cpu().double())
+    assert maxerr(fused, want) < 1e-4            # fp32 sample positions (y H - 0.5 at H = 92..160) against the float64 restatement

@@ -15,6 +15,10 @@ fn = lib.rba_reduce_f32_tune
 fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
 fn.restype = ctypes.c_int
 Q, H, W = 100, 1024, 2048
+if "--hw" in sys.argv:
+    i = sys.argv.index("--hw")
+    H, W = int(sys.argv[i + 1]), int(sys.argv[i + 2])
+    del sys.argv[i:i + 3]
 g = torch.Generator(device="cuda").manual_seed(0)
 mask = torch.randn(Q, H, W, device="cuda", generator=g) * 5
 prob = torch.softmax(torch.randn(Q, 20, device="cuda", generator=g) * 3, -1)[:, :19].contiguous()
