@@ -256,6 +256,10 @@ def main():
         n_ranks_seen = int(ones.item())
         assert n_ranks_seen == world == dist.get_world_size(), (n_ranks_seen, world)
 
+    if os.environ.get("RBA_K6_OCC"):                          # tools: A/B of the single-resident K6 build (see csrc/split_linear_h3.h)
+        import ctypes
+        from rba_amd import _lib
+        ctypes.c_int.in_dll(_lib.load(), "rba_k6_occ").value = int(os.environ["RBA_K6_OCC"])
     a = A.complete(A.ARCHS[args.arch])
     model = load_checkpoint(MaskFormer(a), A.seeded_weights(a, 0)).to(dev).eval()
     model.fused_upsample = args.k1 == "up4"

@@ -14,6 +14,7 @@
 // (split_linear_h3p_kernel), 2 = the sub-tile kernel with the deferred epilogue (split_linear_h3q.h) wherever it applies, 100 + p = its ablation builds
 extern "C" __attribute__((visibility("default"))) int rba_k6_variant = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_stagger = 0;
+extern "C" __attribute__((visibility("default"))) int rba_k6_occ = 2;
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {

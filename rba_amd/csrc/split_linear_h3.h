@@ -801,7 +801,12 @@ int launch_h3p(const float* x, const u32x4_t* wp, const float* bias, float* out,
 
 // At most one workgroup per CU (<= 256 tiles): the OCC = 1 build (no second workgroup to share the register file with, so the
 // activations are prefetched two blocks ahead): -4 ... -9 % on Swin stage-3/4 proj and fc2 (profiles/r02_k6_h3p_ablation.txt).
-inline bool h3p_single_resident(int64_t M, int N) { return ((M + 127) / 128) * ((N + 127) / 128) <= 256; }
+// 2 (default since round 3): every launch runs the 256-register build, so that a single-resident launch (<= 256 tiles: stage-3 proj / fc2)
+// leaves half of every SIMD's register file to ANOTHER stream's kernel; 1: such launches run the 364-register OCC = 1 build with its deeper
+// prefetch -- 4-9 % faster alone, but it monopolises the CU: 128.8 -> 132.7 images/s with three streams, single stream unchanged
+// (profiles/r03_k6_occ.txt)
+extern "C" int rba_k6_occ;
+inline bool h3p_single_resident(int64_t M, int N) { return rba_k6_occ == 1 && ((M + 127) / 128) * ((N + 127) / 128) <= 256; }
 
 inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t st) {
   if (h3p_single_resident(M, N)) {
@@ -925,7 +930,7 @@ inline int launch_h3p_res(const float* x, const u32x4_t* wp, const float* bias, 
   const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  if (MT * NT <= 256)
+  if (rba_k6_occ == 1 && MT * NT <= 256)
     hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, true, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out, (int)M,
                        N, K, (int)MT, NT, nullptr, res);
   else

@@ -3,6 +3,7 @@
 // library contains only the configurations rba_split_linear_f32 dispatches to.
 #include "split_linear_experiments.h"
 #include "../split_linear_h3.h"
+extern "C" int rba_k6_occ = 1;
 extern "C" int rba_k6_stagger = 0;          // the product library's tools-only knob, defined here for this separate library
 #include "../mlp_fused_h3.h"
 
