@@ -114,3 +114,23 @@ def prefetch(dataset, indices, num_threads=4, depth=None, pin=False, label_dtype
                 pending.append(ex.submit(get, i))
                 break
             yield item
+
+
+class ThreadLoader:
+    """``DataLoader(dataset, shuffle=False, batch_size=1, num_workers=N)`` for the reference's scoring loop (evaluate_ood.py:210-211,
+    support.py:353-399) with decode THREADS instead of worker processes: yields ``(x [1,3,H,W] uint8, y [1,H,W])`` in order, decoded
+    ahead of the consumer, in pinned host memory when a HIP device is present.  Starting 15 DataLoader worker processes from a process
+    that holds the model costs ~10 s (8.6 images/s on a 96-image set, tools/evaluator_bench.py); threads start instantly and Pillow's
+    decoders release the interpreter lock (78 images/s through the unmodified OODEvaluator loop)."""
+
+    def __init__(self, dataset, num_workers=8, upper_limit=None, pin=None):
+        self.dataset, self.num_workers = dataset, int(num_workers)
+        self.n = len(dataset) if upper_limit is None else min(len(dataset), int(upper_limit))
+        self.pin = torch.cuda.is_available() if pin is None else bool(pin)
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for item in prefetch(self.dataset, range(self.n), self.num_workers, pin=self.pin and self.num_workers > 0):
+            yield tuple(t[None] for t in item[:2])

@@ -64,3 +64,17 @@ def test_fishyscapes_laf(tmp_path):
         assert np.array_equal(x.numpy().transpose(1, 2, 0), imgs[i]) and np.array_equal(y.numpy(), labs[i].astype(np.int64))
     with pytest.raises(KeyError):
         DS.get_dataset("cityscapes", str(tmp_path))
+
+
+def test_thread_loader_matches_the_dataset_order(tmp_path):
+    """ThreadLoader = the reference loop's DataLoader(batch_size=1, shuffle=False) with decode threads: same items, same order"""
+    from rba_amd.datasets import ThreadLoader, get_dataset
+    imgs, labs = make_road_anomaly(str(tmp_path), n=5, h=24, w=40)
+    ds = get_dataset("road_anomaly", str(tmp_path))
+    for workers in (0, 3):
+        out = list(ThreadLoader(ds, workers, pin=False))
+        assert len(out) == 5 == len(ThreadLoader(ds, workers))
+        for i, (x, y) in enumerate(out):
+            assert x.shape == (1, 3, 24, 40) and y.shape == (1, 24, 40)
+            assert torch.equal(x[0], ds[i][0]) and torch.equal(y[0], ds[i][1])
+    assert len(list(ThreadLoader(ds, 2, upper_limit=3, pin=False))) == 3

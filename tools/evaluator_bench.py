@@ -76,6 +76,40 @@ def main():
                     "num_workers": timing["num_workers"], "streams": timing["streams"], "host_thread": timing.get("host_thread"), "hip_graphs": timing.get("hip_graphs")}
         del model
         torch.cuda.empty_cache()
+    # ---- the reference's OWN loop with the drop-in classes: evaluate_ood.py:205-235 builds
+    # DataLoader(dataset, batch_size, num_workers=15) and calls OODEvaluator.compute_anomaly_scores + evaluate_ood -- batch 1, one
+    # stream, every score leaves the GPU.  What that loop gets from rba_amd without any change of its own: hipGraph replay inside
+    # MaskFormer.rba_scores, device -> host copies through the pinned ring, no per-image stream stall.
+    from torch.utils.data import DataLoader
+    from rba_amd.datasets import ThreadLoader, get_dataset
+    from rba_amd.support import OODEvaluator
+    ds = get_dataset("fishyscapes_laf", os.path.join(work, "data"))
+
+    def thread_loader(nthreads):
+        return ThreadLoader(ds, nthreads)
+
+    for tag, make_loader, replay in (("reference_loop_dataloader_15_workers", lambda: DataLoader(ds, shuffle=False, batch_size=1, num_workers=15, timeout=300), True),
+                                     ("reference_loop_dataloader_15_workers_no_graph", lambda: DataLoader(ds, shuffle=False, batch_size=1, num_workers=15, timeout=300), False),
+                                     ("reference_loop_thread_loader_8", lambda: thread_loader(8), True),
+                                     ("reference_loop_no_workers", lambda: DataLoader(ds, shuffle=False, batch_size=1, num_workers=0), True)):
+        try:
+            model = E.get_model(os.path.join(mdir, "config.yaml"), os.path.join(mdir, "model_final.pth"))
+            model.graph_replay = replay
+            ev = OODEvaluator(model, E.get_logits, E.get_RbA)
+            warm = [(ds[i][0][None], ds[i][1][None]) for i in range(3)]
+            ev.compute_anomaly_scores(warm, device=torch.device("cuda"))             # plans, weight planes, graph capture
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            scores, gts = ev.compute_anomaly_scores(make_loader(), device=torch.device("cuda"), upper_limit=n)
+            t1 = time.perf_counter()
+            m = ev.evaluate_ood(scores, gts, verbose=False)
+            t2 = time.perf_counter()
+            res[tag] = {"images_per_s_scoring_loop": round(len(scores) / (t1 - t0), 2), "images_per_s_with_metrics": round(len(scores) / (t2 - t0), 2),
+                        "seconds_loop": round(t1 - t0, 3), "seconds_metrics": round(t2 - t1, 3), "metrics": m, "hip_graphs": model.live_graphs()}
+            del model, ev, scores, gts
+            torch.cuda.empty_cache()
+        except Exception as e:                                                       # noqa: BLE001 -- a bench tool: record and go on
+            res[tag] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(res))
 
 
