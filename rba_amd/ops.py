@@ -596,10 +596,15 @@ def split_mode(mode):
 SPLIT_ACTIVATIONS = os.environ.get("RBA_SPLIT_ACTIVATIONS", "1") != "0"      # A/B switch (tools): producers keep writing fp32 rows
 
 
+# smallest K whose Linear takes its A operand as a split image.  Round 2 stopped at K > 256 (the LDS-staged fp32-row kernel served Swin stages
+# 1-2); round 3 hands the operand over from K = 128 on: those launches are HBM-bound either way (+0.8 % images/s, tools: RBA_SPLIT_MIN_K)
+SPLIT_MIN_K = int(os.environ.get("RBA_SPLIT_MIN_K", "128"))
+
+
 def linear_takes_split(M, N, K):
     """True when linear() on this shape runs the pipelined 128-column f16x3 kernel, whose A operand a producer can hand over as
-    SplitActivations (the same dispatch as csrc/split_linear_dma.hip: K > 256 and at least 160 tiles of 128 x 128)."""
-    return (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K > 256 and K % 32 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 160)
+    SplitActivations (K >= SPLIT_MIN_K and at least 160 tiles of 128 x 128)."""
+    return (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K >= SPLIT_MIN_K and K % 32 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 160)
 
 
 MLP_FUSED_MIN_ROWS = 32768          # 256 workgroups of 128 rows: below that the unfused pair's 128 x 128 tiles fill the chip better
