@@ -260,6 +260,10 @@ def main():
         import ctypes
         from rba_amd import _lib
         ctypes.c_int.in_dll(_lib.load(), "rba_k6_occ").value = int(os.environ["RBA_K6_OCC"])
+    if os.environ.get("RBA_K6_STAGGER"):                      # tools: late start of every CU's second K6 workgroup (100 MHz ticks)
+        import ctypes
+        from rba_amd import _lib
+        ctypes.c_int.in_dll(_lib.load(), "rba_k6_stagger").value = int(os.environ["RBA_K6_STAGGER"])
     a = A.complete(A.ARCHS[args.arch])
     model = load_checkpoint(MaskFormer(a), A.seeded_weights(a, 0)).to(dev).eval()
     model.fused_upsample = args.k1 == "up4"

@@ -17,14 +17,17 @@ LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
-# Matrix-pipe kernels are compiled WITHOUT packed fp32 instructions.  Measured on MI355X (tools/micro/mfma_valu_overlap.hip,
-# profiles/r03_mfma_valu_overlap.txt): v_pk_fma_f32 / v_pk_mul_f32 execute on the matrix pipe's own datapath -- issued beside
-# v_mfma_f32_32x32x16_f16 (from the same or from another wave of the SIMD) their time ADDS to the MFMAs' time, while plain v_fma_f32 /
-# v_mul_f32 / v_exp_f32 / v_rcp_f32 / conversions / integer ops of another wave run entirely in the MFMAs' shadow.  A GELU or softmax
-# written with packed arithmetic ("half the VALU issues") therefore stalls the very MFMAs it was meant to hide under.  The target
-# feature switch makes the backend scalarise every <2 x float> operation of these files (results are bit-identical).
+# Packed fp32 and the matrix pipe.  Measured on MI355X (tools/micro/mfma_valu_overlap.hip, profiles/r03_mfma_valu_overlap.txt):
+# v_pk_fma_f32 / v_pk_mul_f32 execute on the matrix pipe's datapath -- issued beside v_mfma_f32_32x32x16_f16, from the same or from another
+# wave of the SIMD, their time ADDS to the MFMAs' time -- while plain v_fma_f32 / v_mul_f32 / v_exp_f32 / v_rcp_f32 / conversions / integer
+# ops of another wave run entirely in the MFMAs' shadow.  The switch below makes the backend scalarise every <2 x float> operation of the
+# listed files (bit-identical results).  It is OFF in the product: the GELU / split epilogues of K6 are bound by the NUMBER of vector
+# instructions they issue (22 per output unpacked), and halving that number with packed arithmetic wins even though it stalls the MFMAs of
+# the other wave -- fc1 of Swin stage 3: 65 us packed, 70 us unpacked; the whole network: equal within noise; the one-kernel stage-1 MLP: 174
+# vs 169 us (profiles/r03_k6_h3q.txt).  RBA_NO_PACKED_FP32=1 python -m rba_amd.csrc.build --force rebuilds the matrix-pipe files without it.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-MFMA_SOURCES = {"split_linear.hip", "split_linear_dma.hip", "mask_logits.hip", "masked_xattn.hip", "skinny_linear.hip"}
+MFMA_SOURCES = ({"split_linear.hip", "split_linear_dma.hip", "mask_logits.hip", "masked_xattn.hip", "skinny_linear.hip"}
+                if os.environ.get("RBA_NO_PACKED_FP32") == "1" else set())
 
 
 def _run(cmd):
@@ -81,7 +84,7 @@ def build_tune(force: bool = False, verbose: bool = True) -> str:
     objs = []
     for src in TUNE_SOURCES:
         o = os.path.join(OBJ, "tune_" + os.path.basename(src).replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if "split_linear" in src else []) + ["-c", os.path.join(HERE, src), "-o", o]
+        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if MFMA_SOURCES and "split_linear" in src else []) + ["-c", os.path.join(HERE, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         _run(cmd)
