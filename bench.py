@@ -47,12 +47,19 @@ def parse():
     ap.add_argument("--streams", type=int, default=3,
                     help="images per GPU per step, each on its own HIP stream (concurrent kernels fill under-occupied "
                          "stage-3/4 launches: +7..10 %% images/s at 2-3, but K1's live timing then includes contention)")
+    ap.add_argument("--k1-alone", type=int, default=-1,
+                    help="with several graphed streams: how many of the step's images run their x4 upsample + K1 ALONE on the main stream after the "
+                         "streams have joined (their HIP events are the `roofline` object: uncontended launches inside the timed region); the other "
+                         "images' upsample + K1 are part of their stream's graph and overlap the other streams' forwards.  Round 2 ran all of them alone "
+                         "(--k1-alone = --streams): 0.3 ms per image during which only an HBM-bound kernel ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=1.0, help="scale of the wall-time bounds of the cpu_baseline legs")
     ap.add_argument("--n-images", type=int, default=4, help="distinct resident synthetic images cycled through")
     args = ap.parse_args()
     if args.graph < 0:
         args.graph = 1 if args.streams > 1 else 0
+    if args.k1_alone < 0:
+        args.k1_alone = args.streams
     return args
 
 
@@ -353,11 +360,19 @@ def main():
                         predict_part(static_ins[j])                      # warm the stream's allocator pool
                     torch.cuda.current_stream().wait_stream(st)
                     torch.cuda.synchronize()
+                    whole = j >= max(1, args.k1_alone)                 # this stream's graph runs its own upsample + K1
+                    if whole:
+                        with torch.cuda.stream(st):
+                            post_part(*predict_part(static_ins[j]), record=False)     # warm K1's per-stream workspace too
+                        torch.cuda.current_stream().wait_stream(st)
+                        torch.cuda.synchronize()
                     gj = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gj, stream=st, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
                         outs = predict_part(static_ins[j])
+                        if whole:
+                            outs = post_part(*outs, record=False)
                     torch.cuda.synchronize()
-                    part_graphs.append((gj, st, outs))
+                    part_graphs.append((gj, st, outs, whole))
         except Exception as e:
             if rank == 0:
                 print(f"[bench] per-stream hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -367,16 +382,18 @@ def main():
     def step(i):
         if part_graphs is not None:
             main = torch.cuda.current_stream()
-            for j, (gj, st, outs) in enumerate(part_graphs):
+            for j, (gj, st, outs, whole) in enumerate(part_graphs):
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     static_ins[j].copy_(images[(i + j) % len(images)], non_blocking=True)
                     gj.replay()
             r = None
             with torch.no_grad():
-                for gj, st, outs in part_graphs:
-                    main.wait_stream(st)
-                for gj, st, outs in part_graphs:
+                for gj, st, outs, whole in part_graphs:
+                    main.wait_stream(st)                                # join: the K1 launches timed below run with nothing beside them
+                for gj, st, outs, whole in part_graphs:
+                    if whole:
+                        continue                                        # this image's RbA map was produced inside its stream's graph
                     rr = post_part(*outs)
                     k1_events.append(k1_probe["ev"])
                     r = rr if r is None else r
@@ -590,6 +607,7 @@ def main():
             "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per stream per step "
                                    f"({baseline_config(args.arch, h, w)}); random-init seeded weights",
                        "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
+                       "k1_launches_alone_on_main_stream_per_step": (sum(1 for g_ in part_graphs if not g_[3]) if part_graphs is not None else S),
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
