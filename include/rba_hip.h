@@ -225,6 +225,11 @@ int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_split, const v
 int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N,
                                   int K, int rows_per_image, void* stream);
 
+/* The same operator (NHWC rows in, NCHW out) on the f16x3 kernel; weight_packed = rba_split_weight_f16x2.  The mask-feature projection
+ * `self.mask_features(y)` (pixel_decoder/msdeformattn.py:362). */
+int rba_split_linear_nchw_out_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                                        int rows_per_image, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution over NHWC activations as an implicit GEMM on the same kernel:
  * x [B,H,W,C] -> out [B,H,W,N]; weight_packed = rba_split_weight_bf16x3 of the [N, 9*C] matrix w[n][(3*ky + kx)*C + c]
  * (conv weight [N,C,3,3] permuted to [N,3,3,C]); bias [N] or NULL.  C % 32 == 0.

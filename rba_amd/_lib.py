@@ -41,6 +41,7 @@ SIGNATURES = {
     "rba_swin_mlp_fused_f16x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_f16x3_gelu_split_out": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "rba_split_linear_nchw_out_f16x3_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f16x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f16x3_split_in_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -202,3 +202,21 @@ extern "C" int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packe
   if (rc) return rc;
   return rba_launch_status();
 }
+
+// x [B * P, K] (NHWC rows) -> out [B, N, P] (NCHW) on the f16x3 kernel: the mask-feature projection (pixel_decoder/msdeformattn.py:362,
+// `self.mask_features(y)`), whose consumer K4 reads [C][pixels].  weight_packed = rba_split_weight_f16x2.  (The bf16x6 form of the same
+// operator is rba_split_linear_nchw_out_f32.)
+extern "C" int rba_split_linear_nchw_out_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N,
+                                                   int K, int rows_per_image, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0 && rows_per_image >= 1);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out && (M % rows_per_image) == 0 && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out) & 15) == 0);
+  rba_begin();
+  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const int rc = (tiles128 >= 160 || N <= 64) ? launch_h3l_nchw<4>(x, wp, bias, out, M, N, K, rows_per_image, (hipStream_t)stream)
+                                              : launch_h3l_nchw<2>(x, wp, bias, out, M, N, K, rows_per_image, (hipStream_t)stream);
+  if (rc) return rc;
+  return rba_launch_status();
+}

@@ -143,6 +143,40 @@ __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f3
   }
 }
 
+// The same accumulators written channel-major: out[b][n][p] for row m = b P + p (NHWC rows in, NCHW out: the mask-feature projection,
+// pixel_decoder/msdeformattn.py:362, whose consumer K4 wants [C][pixels]).  A lane's register quad r = 4 q .. 4 q + 3 is four CONSECUTIVE rows
+// (pixels) of one column (channel): one 16-byte store along the pixel axis when P % 4 == 0 (quads then never straddle two images).
+template <int CT>
+__device__ __forceinline__ void h3_epilogue_nchw(const f32x16_t (&accm)[CT], const f32x16_t (&accl)[CT], const float* __restrict__ bias, float* C,
+                                                 int M, int N, int P, int m0, int n0, int wave, int l31, int lh) {
+  const bool vec = (P & 3) == 0;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = n0 + 32 * j + l31;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = m0 + 32 * wave + 8 * q + 4 * lh;
+      if (row >= M) continue;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaf(accl[j][4 * q + i], 0.00048828125f, accm[j][4 * q + i]) + bv;
+      if (vec && row + 3 < M) {
+        const int b = row / P, p = row - b * P;
+        *reinterpret_cast<f32x4*>(C + ((int64_t)b * N + col) * P + p) = v;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (row + i < M) {
+            const int b = (row + i) / P, p = row + i - b * P;
+            C[((int64_t)b * N + col) * P + p] = v[i];
+          }
+      }
+    }
+  }
+}
+
 // ACT: 0 none, 1 exact GELU, 2 ReLU.  CT: 32-column MFMA tiles per wave = tile width / 32 (BN = 32 CT; 128 must be a multiple).
 // Tile 128 x BN, four waves, wave w owns rows 32 w .. 32 w + 31 x all BN columns; two workgroups per CU (256 registers a wave).
 // PROBE (tune builds only, results wrong): bit 0 no weight loads in the loop, bit 1 no activation loads in the loop, bit 2 no epilogue,
@@ -299,11 +333,11 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __
 struct ConvShape {
   int H, W, Cin;
 };
-template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false>
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false, bool NCHW = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
-                                                                 ConvShape cs = ConvShape{0, 0, 0}, const float* R = nullptr) {
+                                                                 ConvShape cs = ConvShape{0, 0, 0}, const float* R = nullptr, int rows_per_image = 0) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int BM = 128, BN = 32 * CT;
@@ -434,7 +468,8 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   }
 
   if (TIMING) tm[2] = wall_clock64();
-  h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
+  if (NCHW) h3_epilogue_nchw<CT>(accm, accl, bias, C, M, N, rows_per_image, m0, n0, wave, l31, lh);
+  else h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
@@ -879,6 +914,17 @@ int launch_h3l_conv(const float* x, const u32x4_t* wp, const float* bias, float*
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3l_kernel<0, CT, 0, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out,
                      (int)M, N, 9 * Cin, (int)MT, NT, nullptr, ConvShape{H, W, Cin});
+  return 0;
+}
+
+// x [B P, K] fp32 rows -> out [B, N, P] (no activation): the LDS-staged kernel with the channel-major epilogue
+template <int CT>
+int launch_h3l_nchw(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, int P, hipStream_t stream) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3l_kernel<0, CT, 0, false, false, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out,
+                     (int)M, N, K, (int)MT, NT, nullptr, ConvShape{0, 0, 0}, nullptr, P);
   return 0;
 }
 

@@ -192,8 +192,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
             prev = ops.group_norm_nhwc(z.view(B, h * w, d), 32, ly.norm.weight, ly.norm.bias, ly.norm.eps, relu=True)
             ph, pw = h, w
         mfw = self.mask_features.weight
-        planes = self._cached(self.mask_features, "_rba_mf_planes",
-                              lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous(), mode="bf16x6"))
+        planes = self._cached(self.mask_features, "_rba_mf_planes_" + ops.SPLIT_MODE,           # per arithmetic form (f16x3 since round 3)
+                              lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous()))
         mf = ops.split_linear_nchw_out(prev.view(B * ph * pw, d), planes, self.mask_features.bias, ph * pw,
                                        out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)
         return mf, outs[0], outs[:self.maskformer_num_feature_levels]

@@ -696,13 +696,15 @@ def split_linear(x, planes, bias=None, gelu=False, out_features=None, relu=False
 
 @_hip_op
 def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
-    """x [B*P, K] (NHWC rows) -> [B, N, P]: the Linear of split_linear written channel-major (NHWC in, NCHW out)."""
+    """x [B*P, K] (NHWC rows) -> [B, N, P]: the Linear of split_linear written channel-major (NHWC in, NCHW out); the planes' dtype says
+    for which arithmetic form they were packed (float16: f16x3, bfloat16: bf16x6)."""
     lib = _lib.load()
     _chk(x, "x", dim=2)
-    _chk(planes, "planes", dtype=torch.bfloat16, dim=6)
+    f16 = planes.dtype == torch.float16
+    _chk(planes, "planes", dtype=torch.float16 if f16 else torch.bfloat16, dim=6)
     M, K = x.shape
     N = planes.shape[0] * 128 if out_features is None else int(out_features)
-    if (tuple(planes.shape[2:]) != (3, 128, 2, 8) or planes.shape[1] * 16 != K or (N + 127) // 128 != planes.shape[0]
+    if (tuple(planes.shape[2:]) != ((2, 128, 2, 8) if f16 else (3, 128, 2, 8)) or planes.shape[1] * 16 != K or (N + 127) // 128 != planes.shape[0]
             or rows_per_image < 1 or M % rows_per_image):
         raise RbaHipError("split_linear_nchw_out needs x [B*P, K], split_weight(W [N,K]) and M % rows_per_image == 0")
     if bias is not None:
@@ -710,8 +712,9 @@ def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
     out = torch.empty((M // rows_per_image, N, rows_per_image), dtype=torch.float32, device=x.device)
-    _lib.check(lib.rba_split_linear_nchw_out_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, rows_per_image, _stream()),
-               "rba_split_linear_nchw_out_f32")
+    fn, name = ((lib.rba_split_linear_nchw_out_f16x3_f32, "rba_split_linear_nchw_out_f16x3_f32") if f16
+                else (lib.rba_split_linear_nchw_out_f32, "rba_split_linear_nchw_out_f32"))
+    _lib.check(fn(_p(x), _p(planes), _p(bias), _p(out), M, N, K, rows_per_image, _stream()), name)
     return out
 
 

@@ -603,6 +603,16 @@ def test_split_linear_nchw_out(ops, B, P, K, N):
     assert out.shape == (B, N, P) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
     same = ops.split_linear(dev(x), planes, dev(b), out_features=N).view(B, P, N).permute(0, 2, 1)
     assert maxerr(out, same.double()) < 1e-5      # same six terms; the operand roles (and so the summation order) are swapped
+    # round 3: the f16x3 form (what the mask-feature projection runs): the LDS-staged kernel with a channel-major epilogue -- the same
+    # accumulators as the row-major Linear, so the two agree bit for bit; P % 4 != 0 takes the scalar-store path, bias may be absent
+    p3 = ops.split_weight(dev(w), mode="f16x3")
+    out3 = ops.split_linear_nchw_out(dev(x), p3, dev(b), P, out_features=N)
+    same3 = ops.split_linear(dev(x), p3, dev(b), out_features=N).view(B, P, N).permute(0, 2, 1)
+    assert out3.shape == (B, N, P) and maxerr(out3, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
+    if K <= 256:                                  # the row-major Linear runs the same LDS-staged kernel there
+        assert torch.equal(out3, same3.contiguous())
+    nb = ops.split_linear_nchw_out(dev(x), p3, None, P, out_features=N)
+    assert maxerr(nb, ref - b.double()[None, :, None]) < 2e-5 * (K / 256) ** 0.5 + 2e-6
 
 
 # ----------------------------------------------------------------------------------- channels-last GroupNorm / resample
