@@ -16,6 +16,9 @@ using namespace rba_k1;
 
 extern "C" int rba_hip_version(void) { return 180; }
 
+// tools / tests only: 1 = rba_reduce_up4_f32 runs the generic (round 1-2) kernel for K = 19 / 20 too
+extern "C" __attribute__((visibility("default"))) int rba_k1_up4_variant = 0;
+
 static int reduce_impl(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax, int Q, int K, int64_t HW,
                        int score_mode, unsigned int* counters, void* stream) {
   RBA_CHECK_ARG(Q >= 1 && K >= 1 && K <= 160 && HW >= 0 && score_mode >= 0 && score_mode <= 2);
@@ -56,6 +59,8 @@ extern "C" int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_pro
   hipStream_t st = (hipStream_t)stream;
   // vector stores need 16 B aligned rows; the kernel falls back to scalar stores when crop_w % 4 != 0
   RBA_CHECK_ARG((((uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
+  if (K == 19 && rba_k1_up4_variant == 0) return launch_up4_pk<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, h, w, crop_h, crop_w, st, score_mode);
+  if (K == 20 && rba_k1_up4_variant == 0) return launch_up4_pk<20>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, h, w, crop_h, crop_w, st, score_mode);
   if (K == 19) return launch_up4<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st, score_mode);
   return launch_up4<32>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st, score_mode);
 }

@@ -487,6 +487,109 @@ int launch_reduce(const float* mask, const float* prob, float* rba, float* sem, 
   return rba_launch_status();
 }
 
+// The same fused kernel for a compile-time K with the arithmetic of rba_reduce_pk_kernel (round 3: this is the product's default K1 path --
+// MaskFormer.rba_scores, i.e. what the evaluator runs -- and it is VALU-bound: 52 MB in, 8 MB out).  Per query and 4 output pixels the generic
+// kernel above issues ~120 scalar vector instructions; here the two column pairs (r = 0, 1 share low-res columns j-1, j; r = 2, 3 share j, j+1)
+// are interpolated with packed fp32 (ATen's operation order per element), the sigmoids are rba_sigmoid2 and the 4 K class FMAs are 2 K
+// v_pk_fma_f32 with the class probability as a scalar operand: ~54 packed + 8 transcendental.  Two queries per trip, the twelve taps of the
+// next two requested before the current two are consumed.
+template <int K, bool SEM, bool ARG>
+__global__ __launch_bounds__(256) void rba_reduce_up4_pk_kernel(const float* __restrict__ low, const float* __restrict__ prob,
+                                                                float* __restrict__ rba, float* __restrict__ sem,
+                                                                int32_t* __restrict__ argmax, int Q, int h, int w, int crop_h, int crop_w,
+                                                                int wq, int mode) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (j >= wq) return;
+  const BilinearTap ty = bilinear_tap(y, 0.25f, h);
+  BilinearTap tx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tx[r] = bilinear_tap(4 * j + r, 0.25f, w);
+  const int jm = j > 0 ? j - 1 : 0, jc = j < w ? j : w - 1, jp = j < w - 1 ? j + 1 : w - 1;
+  const f32x2 l0a = {tx[0].l0, tx[1].l0}, l1a = {tx[0].l1, tx[1].l1}, l0b = {tx[2].l0, tx[3].l0}, l1b = {tx[2].l1, tx[3].l1};
+  f32x2 a01[K], a23[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) a01[k] = a23[k] = (f32x2){0.f, 0.f};
+  const int64_t plane = (int64_t)h * w;
+  const float* r0 = low + (int64_t)ty.i0 * w;
+  const float* r1 = low + (int64_t)ty.i1 * w;
+  float t[2][6];
+  auto taps = [&](int q, float (&d)[6]) {
+    const int qc = q < Q ? q : Q - 1;
+    const float* p0 = r0 + qc * plane;
+    const float* p1 = r1 + qc * plane;
+    d[0] = p0[jm]; d[1] = p0[jc]; d[2] = p0[jp];
+    d[3] = p1[jm]; d[4] = p1[jc]; d[5] = p1[jp];
+  };
+  auto one = [&](int q, const float (&d)[6]) {
+    // ATen: l0h * (l0w * v00 + l1w * v01) + l1h * (l0w * v10 + l1w * v11); columns r < 2 -> (j-1, j), r >= 2 -> (j, j+1)
+    const f32x2 topa = l0a * d[0] + l1a * d[1], bota = l0a * d[3] + l1a * d[4];
+    const f32x2 topb = l0b * d[1] + l1b * d[2], botb = l0b * d[4] + l1b * d[5];
+    const f32x2 s01 = rba_sigmoid2(topa * ty.l0 + bota * ty.l1);
+    const f32x2 s23 = rba_sigmoid2(topb * ty.l0 + botb * ty.l1);
+    const float* pq = prob + q * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const f32x2 pk = {pq[k], pq[k]};
+      a01[k] = __builtin_elementwise_fma(pk, s01, a01[k]);
+      a23[k] = __builtin_elementwise_fma(pk, s23, a23[k]);
+    }
+  };
+  taps(0, t[0]);
+  taps(1, t[1]);
+  int q = 0;
+  for (; q + 1 < Q; q += 2) {
+    float n0[6], n1[6];
+    taps(q + 2, n0);
+    taps(q + 3, n1);
+    one(q, t[0]);
+    one(q + 1, t[1]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { t[0][i] = n0[i]; t[1][i] = n1[i]; }
+  }
+  if (q < Q) one(q, t[0]);
+  float acc[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { acc[k][0] = a01[k].x; acc[k][1] = a01[k].y; acc[k][2] = a23[k].x; acc[k][3] = a23[k].y; }
+  const int64_t oplane = (int64_t)crop_h * crop_w;
+  const int64_t p0 = (int64_t)y * crop_w + 4 * j;
+  if (4 * j + 3 < crop_w && (crop_w & 3) == 0) {
+    rba_epilogue<K, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, oplane);
+  } else {
+    float r[4];
+    rba_score<K, 4>(acc, K, mode, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (4 * j + i >= crop_w) break;
+      float bv = acc[0][i];
+      int b = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (acc[k][i] > bv) { bv = acc[k][i]; b = k; }
+        if (SEM) sem[(int64_t)k * oplane + p0 + i] = acc[k][i];
+      }
+      rba[p0 + i] = r[i];
+      if (ARG) argmax[p0 + i] = b;
+    }
+  }
+}
+
+template <int K>
+int launch_up4_pk(const float* low, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int h, int w, int crop_h, int crop_w,
+                  hipStream_t st, int mode) {
+  const int wq = (crop_w + 3) / 4;
+  const int threads = wq >= 256 ? 256 : (wq >= 128 ? 128 : 64);
+  dim3 grid((wq + threads - 1) / threads, crop_h);
+#define RBA_L(S, A) \
+  hipLaunchKernelGGL((rba_reduce_up4_pk_kernel<K, S, A>), grid, dim3(threads), 0, st, low, prob, rba, sem, argmax, Q, h, w, crop_h, crop_w, wq, mode)
+  if (sem && argmax) RBA_L(true, true);
+  else if (sem) RBA_L(true, false);
+  else if (argmax) RBA_L(false, true);
+  else RBA_L(false, false);
+#undef RBA_L
+  return rba_launch_status();
+}
+
 template <int KMAX>
 int launch_up4(const float* low, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K, int h, int w,
                int crop_h, int crop_w, hipStream_t st, int mode) {
