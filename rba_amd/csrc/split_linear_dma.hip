@@ -159,9 +159,11 @@ extern "C" int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_spl
 #undef H3Q_PROBE
       default: rc = launch_h3q<H3Q_SPLIT, 1>(x, wp, bias, nullptr, out_frag, M, N, K, st);
     }
-  } else if (x_is_split && h3q_supported(M, N, K) && (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768)))
-    // fc1 + GELU with the epilogue deferred into the next sub-tile's k loop: pays from K = 768 (Swin-L stage 3: 165 -> 143 us; at K = 512 the
-    // epilogue units are a larger share of a 16-block loop and the doubled A traffic wins: 65 -> 71 us)
+  } else if (x_is_split && h3q_supported(M, N, K) &&
+             (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768 && ((M + 127) / 128) * ((N + 127) / 128) > 512)))
+    // fc1 + GELU with the epilogue deferred into the next sub-tile's k loop: pays where the 128 x 128 kernel needs more than one round of
+    // workgroups AND the k loop is long (Swin-L: stage 3 165 -> 143 us, stage 4 147 -> 142 us); a one-round launch (Swin-B stage 4: 512
+    // tiles, 61 vs 72 us) or a 16-block loop (Swin-B stage 3: 65 vs 71 us) is better off on the 128 x 128 kernel
     rc = launch_h3q<H3Q_SPLIT, 1>(x, wp, bias, nullptr, out_frag, M, N, K, st);
   else if (h3p_single_resident(M, N))
     rc = x_is_split ? launch_h3p_fout<1, true, 1>(x, wp, bias, out_frag, M, N, K, st) : launch_h3p_fout<1, false, 1>(x, wp, bias, out_frag, M, N, K, st);

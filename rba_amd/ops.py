@@ -602,9 +602,13 @@ SPLIT_MIN_K = int(os.environ.get("RBA_SPLIT_MIN_K", "128"))
 
 
 def linear_takes_split(M, N, K):
-    """True when linear() on this shape runs the pipelined 128-column f16x3 kernel, whose A operand a producer can hand over as
-    SplitActivations (K >= SPLIT_MIN_K and at least 160 tiles of 128 x 128)."""
-    return (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K >= SPLIT_MIN_K and K % 32 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 160)
+    """True when linear() on this shape runs a kernel whose A operand a producer can hand over as SplitActivations: the pipelined
+    128-column f16x3 kernel (K >= SPLIT_MIN_K, at least 160 tiles of 128 x 128) or, for smaller launches, the sub-tile kernel of
+    csrc/split_linear_h3q.h (K % 64 == 0, K >= 256, N % 32 == 0, at least 32 tiles: Swin stage 4's proj / fc2 with 128 tiles)."""
+    if not (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K >= SPLIT_MIN_K and K % 32 == 0):
+        return False
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    return tiles >= 160 or (tiles >= 32 and K % 64 == 0 and K >= 256 and N % 32 == 0)
 
 
 MLP_FUSED_MIN_ROWS = 32768          # 256 workgroups of 128 rows: below that the unfused pair's 128 x 128 tiles fill the chip better

@@ -289,7 +289,8 @@ def test_split_activations_layout_and_predicate():
     try:
         assert ops.linear_takes_split(8192, 2048, 512) and ops.linear_takes_split(8192, 512, 2048)
         assert ops.linear_takes_split(32768, 768, 256) and ops.linear_takes_split(131072, 384, 128)          # from K = 128 since round 3
-        assert not ops.linear_takes_split(131072, 384, 96) and not ops.linear_takes_split(2048, 1024, 1024)      # K below SPLIT_MIN_K / too few tiles
+        assert not ops.linear_takes_split(131072, 384, 96) and not ops.linear_takes_split(256, 1024, 1024)      # K below SPLIT_MIN_K / too few tiles
+        assert ops.linear_takes_split(2048, 1024, 1024) and not ops.linear_takes_split(2048, 1024, 160)           # 128 tiles: the sub-tile kernel (K % 64, K >= 256)
         ops.SPLIT_MODE = "bf16x6"
         assert not ops.linear_takes_split(8192, 2048, 512)
     finally:
