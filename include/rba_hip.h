@@ -206,6 +206,16 @@ int rba_swin_window_attn_split_out_f32(const float* qkv, const float* qkv_bias, 
  *                                     the convolution (>= 256 tiles of 128 x 128) gathers the pieces of the neighbour pixels' rows. */
 int rba_resample_bilinear_nhwc_split_out_f32(const float* in, const float* add, void* out_frag, int C, int h, int w, int H, int W,
                                              int64_t row0, void* stream);
+
+/* The FPN's top-down step with its GroupNorms folded into the loads (pixel_decoder/msdeformattn.py:352-358): in = the previous level's raw
+ * output-convolution result (normalised + ReLU'd on the fly when in_mr is given), add = the raw lateral-convolution result (normalised on
+ * the fly when add_mr is given); *_mr = [G][2] (mean, rstd) of the image from rba_group_norm_nhwc_stats_f32.  out = fp32 [H, W, C] or, with
+ * split_out, rows row0 .. of the split image the 3 x 3 convolution reads.  The arithmetic of the unfused GroupNorm + resample launches (equal up to fma contraction: one ulp). */
+int rba_resample_bilinear_nhwc_gn_f32(const float* in, const float* in_mr, const float* in_gamma, const float* in_beta, int in_relu,
+                                      const float* add, const float* add_mr, const float* add_gamma, const float* add_beta, void* out,
+                                      int split_out, int C, int G, int h, int w, int H, int W, int64_t row0, void* stream);
+/* (mean, rstd) per image and group of channels-last x [B, P, C]: the statistics half of rba_group_norm_nhwc_f32. */
+int rba_group_norm_nhwc_stats_f32(const float* x, float* mr, float* workspace, int B, int P, int C, int G, float eps, void* stream);
 int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const void* weight_packed, const float* bias, float* out, int B, int H, int W,
                                         int C, int N, void* stream);
 /*   rba_swin_mlp_fused_f16x3_f32 = the whole Mlp + residual of a Swin block with C = 128 in one kernel (csrc/mlp_fused_h3.h): the [M, HID]

@@ -23,6 +23,8 @@ SIGNATURES = {
     "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_msda_prepare_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "rba_resample_bilinear_nhwc_gn_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp],
+    "rba_group_norm_nhwc_stats_f32": [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp],
     "rba_msda_fused_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_masked_xattn_workspace_bytes": [_i, _i, _i, _i],
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

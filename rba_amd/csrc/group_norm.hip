@@ -230,3 +230,18 @@ extern "C" int rba_group_norm_nhwc_f32(const float* x, const float* gamma, const
     hipLaunchKernelGGL(gn_apply_nhwc_kernel<false>, grid, dim3(256), 0, st, x, mr, gamma, beta, y, P, C, cpg);
   return rba_launch_status();
 }
+
+// The statistics half of rba_group_norm_nhwc_f32 alone: mr [B][G][2] = (mean, rstd) per image and group, for consumers that fold the
+// normalisation into their own loads (rba_resample_bilinear_nhwc_gn_f32).  workspace: rba_group_norm_nhwc_workspace_bytes; `mr` may point
+// anywhere (B * G * 2 floats).
+extern "C" int rba_group_norm_nhwc_stats_f32(const float* x, float* mr, float* workspace, int B, int P, int C, int G, float eps, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && C >= 4 && P >= 0 && G >= 1 && C % G == 0 && (C / G) % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && G <= 256);
+  if (B == 0 || P == 0) return 0;
+  RBA_CHECK_ARG(x && mr && workspace && B <= 65535 && (((uintptr_t)x) & 15) == 0);
+  const int splits = (P + PIX_CHUNK - 1) / PIX_CHUNK;
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_nhwc_kernel, dim3(splits, B), dim3(256), 0, st, x, workspace, P, C, C / G, splits);
+  hipLaunchKernelGGL(gn_merge_kernel, dim3(B * G), dim3(64), 0, st, workspace, mr, splits, eps);
+  return rba_launch_status();
+}

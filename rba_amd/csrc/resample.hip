@@ -62,10 +62,40 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 // the four taps are four contiguous 16-byte loads, a wave covers whole pixel rows.  Same tap arithmetic as above.
 // SOUT: the result is written as the split image of the 3 x 3 convolution that consumes it (split_linear_h3.h "PRE" / "CONVP"): row =
 // row0 + pixel, the lane pair of an 8-channel piece exchanges halves with one DPP move (as the LayerNorm does).  C % 32 == 0.
-template <bool ADD, bool SOUT = false>
+// GroupNorm folded into the loads (round 3: the FPN's `GroupNorm(lateral)` and `ReLU(GroupNorm(conv))` feed nothing but this kernel, so their
+// "apply" passes -- 268 MB each at the 256 x 512 level -- disappear): a tensor that arrives with (mean, rstd) per group is normalised on the
+// fly, v * (gamma rstd) + (beta - mean gamma rstd), the arithmetic of gn_apply_nhwc_kernel, ReLU optional.
+struct GnFold {
+  const float* mr;      // [G][2] (mean, rstd) of this image, or nullptr: the tensor is used as it is
+  const float* gamma;
+  const float* beta;
+  int cpg;              // channels per group
+  int relu;
+};
+__device__ __forceinline__ void gn_fold_coeff(const GnFold& g, int j, f32x4& a, f32x4& b) {
+  const int grp = (j << 2) / g.cpg;
+  const float mean = g.mr[2 * grp], rstd = g.mr[2 * grp + 1];
+  const f32x4 ga = reinterpret_cast<const f32x4*>(g.gamma)[j], be = reinterpret_cast<const f32x4*>(g.beta)[j];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = ga[k] * rstd;
+    b[k] = be[k] - mean * a[k];
+  }
+}
+__device__ __forceinline__ f32x4 gn_fold_apply(f32x4 v, const f32x4 a, const f32x4 b, int relu) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = fmaf(v[k], a[k], b[k]);
+    if (relu) v[k] = fmaxf(v[k], 0.f);
+  }
+  return v;
+}
+
+template <bool ADD, bool SOUT = false, bool GN = false>
 __global__ __launch_bounds__(256) void resample_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ add,
                                                             float* __restrict__ out, int C4, int h, int w, int H, int W, float sh,
-                                                            float sw, int64_t row0 = 0) {
+                                                            float sw, int64_t row0 = 0, GnFold gin = GnFold{nullptr, nullptr, nullptr, 4, 0},
+                                                            GnFold gadd = GnFold{nullptr, nullptr, nullptr, 4, 0}) {
   int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int j;
   int64_t pix;
@@ -87,8 +117,16 @@ __global__ __launch_bounds__(256) void resample_nhwc_kernel(const float* __restr
   const int x = (int)(pix % W), y = (int)(pix / W);
   const BilinearTap ty = bilinear_tap(y, sh, h), tx = bilinear_tap(x, sw, w);
   const f32x4* ip = reinterpret_cast<const f32x4*>(in) + j;
-  const f32x4 v00 = ip[((int64_t)ty.i0 * w + tx.i0) * C4], v01 = ip[((int64_t)ty.i0 * w + tx.i1) * C4];
-  const f32x4 v10 = ip[((int64_t)ty.i1 * w + tx.i0) * C4], v11 = ip[((int64_t)ty.i1 * w + tx.i1) * C4];
+  f32x4 v00 = ip[((int64_t)ty.i0 * w + tx.i0) * C4], v01 = ip[((int64_t)ty.i0 * w + tx.i1) * C4];
+  f32x4 v10 = ip[((int64_t)ty.i1 * w + tx.i0) * C4], v11 = ip[((int64_t)ty.i1 * w + tx.i1) * C4];
+  if (GN && gin.mr) {
+    f32x4 a, b;
+    gn_fold_coeff(gin, j, a, b);
+    v00 = gn_fold_apply(v00, a, b, gin.relu);
+    v01 = gn_fold_apply(v01, a, b, gin.relu);
+    v10 = gn_fold_apply(v10, a, b, gin.relu);
+    v11 = gn_fold_apply(v11, a, b, gin.relu);
+  }
   f32x4 r;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -96,7 +134,15 @@ __global__ __launch_bounds__(256) void resample_nhwc_kernel(const float* __restr
     const float bot = tx.l0 * v10[k] + tx.l1 * v11[k];
     r[k] = ty.l0 * top + ty.l1 * bot;
   }
-  if (ADD) r += reinterpret_cast<const f32x4*>(add)[idx];
+  if (ADD) {
+    f32x4 av = reinterpret_cast<const f32x4*>(add)[idx];
+    if (GN && gadd.mr) {
+      f32x4 a, b;
+      gn_fold_coeff(gadd, j, a, b);
+      av = gn_fold_apply(av, a, b, gadd.relu);
+    }
+    r += av;
+  }
   if (SOUT) {
     uint32_t hh[2], ll[2];
     rba_split_f16x2(r.x, r.y, hh[0], ll[0]);
@@ -175,5 +221,31 @@ extern "C" int rba_resample_bilinear_nhwc_split_out_f32(const float* in, const f
     hipLaunchKernelGGL((resample_nhwc_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, in, add, o, C >> 2, h, w, H, W, sh, sw, row0);
   else
     hipLaunchKernelGGL((resample_nhwc_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, add, o, C >> 2, h, w, H, W, sh, sw, row0);
+  return rba_launch_status();
+}
+
+// The FPN's top-down step with both GroupNorms folded in (pixel_decoder/msdeformattn.py:352-358: `cur_fpn = lateral_conv(x)` [conv + GN],
+// `y = cur_fpn + F.interpolate(prev, size=cur_fpn.shape[-2:], mode="bilinear")` where prev = the previous level's `output_conv` [conv + GN + ReLU]):
+// in [h, w, C] = the previous level's RAW convolution output (in_mr == nullptr: used as it is), add [H, W, C] = the RAW lateral convolution output;
+// *_mr = [G][2] (mean, rstd) from rba_group_norm_nhwc_stats_f32.  out: fp32 [H, W, C] (split_out == 0) or rows row0 .. of a split image.
+extern "C" int rba_resample_bilinear_nhwc_gn_f32(const float* in, const float* in_mr, const float* in_gamma, const float* in_beta, int in_relu,
+                                                 const float* add, const float* add_mr, const float* add_gamma, const float* add_beta, void* out,
+                                                 int split_out, int C, int G, int h, int w, int H, int W, int64_t row0, void* stream) {
+  RBA_CHECK_ARG(C >= 4 && (C % 4) == 0 && G >= 1 && (C % G) == 0 && ((C / G) % 4) == 0 && h >= 1 && w >= 1 && H >= 0 && W >= 0 && row0 >= 0);
+  RBA_CHECK_ARG(!split_out || (C % 32) == 0);
+  if (H == 0 || W == 0) return 0;
+  RBA_CHECK_ARG(in && add && out && (!in_mr || (in_gamma && in_beta)) && (!add_mr || (add_gamma && add_beta)));
+  RBA_CHECK_ARG((((uintptr_t)in | (uintptr_t)add | (uintptr_t)out | (uintptr_t)in_gamma | (uintptr_t)in_beta | (uintptr_t)add_gamma | (uintptr_t)add_beta) & 15) == 0);
+  const int64_t total = split_out ? (((int64_t)H * W + 7) / 8) * 8 * (C >> 2) : (int64_t)H * W * (C >> 2);
+  RBA_CHECK_ARG((total + 255) / 256 <= 0x7fffffffLL);
+  rba_begin();
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  const GnFold gi{in_mr, in_gamma, in_beta, C / G, in_relu}, ga{add_mr, add_gamma, add_beta, C / G, 0};
+  float* o = reinterpret_cast<float*>(out);
+  if (split_out)
+    hipLaunchKernelGGL((resample_nhwc_kernel<true, true, true>), grid, dim3(256), 0, (hipStream_t)stream, in, add, o, C >> 2, h, w, H, W, sh, sw, row0, gi, ga);
+  else
+    hipLaunchKernelGGL((resample_nhwc_kernel<true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, add, o, C >> 2, h, w, H, W, sh, sw, row0, gi, ga);
   return rba_launch_status();
 }

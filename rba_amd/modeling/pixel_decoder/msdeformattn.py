@@ -1,6 +1,8 @@
 """MSDeformAttn pixel decoder, inference only (reference: pixel_decoder/msdeformattn.py:32-367).
 Same parameter names; K2 (deformable attention) and the bilinear FPN top-down sum are HIP kernels, 1x1/3x3
 convolutions and the encoder FFN are MFMA GEMMs/convs through rocBLAS/MIOpen."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -120,6 +122,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self.pe_layer = PositionEmbeddingSine(d // 2, normalize=True)
         self.mask_features = nn.Conv2d(d, a["mask_dim"], kernel_size=1)
         self.num_fpn_levels = num_fpn_levels(a)
+        self.fold_group_norm = os.environ.get("RBA_FOLD_GN", "1") != "0"          # channels-last FPN: GroupNorm "apply" passes folded into the resample kernel (A/B: False)
         for j in range(1, self.num_fpn_levels + 1):
             self.add_module(f"adapter_{j}", ConvNorm(chans[FEATURE_NAMES[j - 1]], d, 1, bias=False, norm=True))
             self.add_module(f"layer_{j}", ConvNorm(d, d, 3, bias=False, norm=True, relu=True))
@@ -171,26 +174,47 @@ class MSDeformAttnPixelDecoder(nn.Module):
         toks = [z.contiguous() for z in torch.split(y, [h * w for h, w in shapes], dim=1)]
         outs = [z.view(B, h, w, d).permute(0, 3, 1, 2).contiguous() for z, (h, w) in zip(toks, shapes)]
         prev, (ph, pw) = toks[-1], shapes[-1]
+        prev_norm = None                                   # (mr [B, G, 2], module) once `prev` is a raw convolution output awaiting GroupNorm + ReLU
+        fold = self.fold_group_norm
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             j = self.num_fpn_levels - idx
             x = features[f]
             h, w = int(x.shape[-2]), int(x.shape[-1])
             ad, ly = getattr(self, f"adapter_{j}"), getattr(self, f"layer_{j}")
-            cur = ops.group_norm_nhwc(self._conv1x1(self._tokens(x), ad, use_bias=False), 32, ad.norm.weight, ad.norm.bias,
-                                      ad.norm.eps)
-            if ops.conv3x3_takes_split(B * h * w, d) and d % 32 == 0:
-                # the sum feeds only the 3x3 convolution: written straight as that kernel's split operand (ops.SplitActivations)
-                yy = ops.SplitActivations.empty((B, h, w, d), prev.device)
+            lat = self._conv1x1(self._tokens(x), ad, use_bias=False)                       # raw lateral convolution [B, h*w, d]
+            split = ops.conv3x3_takes_split(B * h * w, d) and d % 32 == 0
+            yy = ops.SplitActivations.empty((B, h, w, d), prev.device) if split else None
+            if fold:
+                # round 3: both GroupNorms of the top-down step are folded into the resample kernel's loads -- the lateral's (no ReLU) into its
+                # `add` operand, the previous level's (+ ReLU) into its taps: their "apply" passes (268 MB each at 256 x 512) are never run
+                lat_mr = ops.group_norm_nhwc_stats(lat, 32, ad.norm.eps)
+                ups = []
                 for b in range(B):
-                    ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d), split_into=yy, image=b)
+                    xn = None if prev_norm is None else (prev_norm[0][b], prev_norm[1].weight, prev_norm[1].bias, True)
+                    r = ops.resample_bilinear_nhwc_gn(prev[b].view(ph, pw, d), (h, w), lat[b].view(h, w, d), 32, x_norm=xn,
+                                                      add_norm=(lat_mr[b], ad.norm.weight, ad.norm.bias), split_into=yy, image=b)
+                    if not split:
+                        ups.append(r)
+                if not split:
+                    yy = ups[0][None] if B == 1 else torch.stack(ups)
             else:
-                ups = [ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d))
-                       for b in range(B)]                                                  # :357-358 fused sum
-                yy = ups[0][None] if B == 1 else torch.stack(ups)
+                if prev_norm is not None:
+                    prev = ops.group_norm_nhwc(prev, 32, prev_norm[1].weight, prev_norm[1].bias, prev_norm[1].eps, relu=True)
+                cur = ops.group_norm_nhwc(lat, 32, ad.norm.weight, ad.norm.bias, ad.norm.eps)
+                if split:
+                    # the sum feeds only the 3x3 convolution: written straight as that kernel's split operand (ops.SplitActivations)
+                    for b in range(B):
+                        ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d), split_into=yy, image=b)
+                else:
+                    ups = [ops.resample_bilinear_nhwc(prev[b].view(ph, pw, d), (h, w), add=cur[b].view(h, w, d))
+                           for b in range(B)]                                                  # :357-358 fused sum
+                    yy = ups[0][None] if B == 1 else torch.stack(ups)
             planes = self._cached(ly, "_rba_conv_" + ops.SPLIT_MODE, lambda: ops.conv3x3_weight(ly.weight.detach()))    # per arithmetic form
-            z = ops.conv3x3_nhwc(yy, planes, None, out_features=d)
-            prev = ops.group_norm_nhwc(z.view(B, h * w, d), 32, ly.norm.weight, ly.norm.bias, ly.norm.eps, relu=True)
+            prev = ops.conv3x3_nhwc(yy, planes, None, out_features=d).view(B, h * w, d)   # raw: its GroupNorm + ReLU is folded into the next consumer
+            prev_norm = (ops.group_norm_nhwc_stats(prev, 32, ly.norm.eps) if fold else None, ly.norm)
             ph, pw = h, w
+        if prev_norm is not None:                              # the last level feeds the mask-feature projection: normalised here
+            prev = ops.group_norm_nhwc(prev, 32, prev_norm[1].weight, prev_norm[1].bias, prev_norm[1].eps, relu=True)
         mfw = self.mask_features.weight
         planes = self._cached(self.mask_features, "_rba_mf_planes_" + ops.SPLIT_MODE,           # per arithmetic form (f16x3 since round 3)
                               lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous()))

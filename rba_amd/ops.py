@@ -843,6 +843,67 @@ def resample_bilinear_nhwc(x, size, add=None, split_into=None, image=0):
     return out
 
 
+def _gn_nhwc_ok(C, num_groups):
+    return C % num_groups == 0 and (C // num_groups) % 4 == 0 and C <= 1024 and 256 % (C // 4) == 0
+
+
+@_hip_op
+def group_norm_nhwc_stats(x, num_groups, eps=1e-5):
+    """(mean, rstd) per image and group of channels-last x [B, P, C] (or [B, H, W, C]) -> [B, G, 2]: the statistics half of group_norm_nhwc, for a
+    consumer that folds the normalisation into its own loads (resample_bilinear_nhwc_gn)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    if x.dim() not in (3, 4):
+        raise RbaHipError("x must be [B,P,C] or [B,H,W,C]")
+    B, C = x.shape[0], x.shape[-1]
+    P = x.numel() // (B * C) if B * C else 0
+    if not _gn_nhwc_ok(C, num_groups):
+        raise RbaHipError("group_norm_nhwc_stats needs C % G == 0, (C/G) % 4 == 0, C <= 1024 and 256 % (C/4) == 0")
+    nbytes = lib.rba_group_norm_nhwc_workspace_bytes(B, P, C, num_groups)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    mr = torch.empty((B, num_groups, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_group_norm_nhwc_stats_f32(_p(x), _p(mr), _p(ws), B, P, C, num_groups, float(eps), _stream()), "rba_group_norm_nhwc_stats_f32")
+    return mr
+
+
+@_hip_op
+def resample_bilinear_nhwc_gn(x, size, add, num_groups, x_norm=None, add_norm=None, split_into=None, image=0):
+    """The FPN top-down step `GroupNorm(add) + F.interpolate(ReLU(GroupNorm(x)))` with the normalisations folded into the loads: x [h, w, C] and
+    add [H, W, C] are the RAW convolution outputs; ``x_norm`` = (mr [G, 2], weight, bias, relu) or None (x is used as it is), ``add_norm`` =
+    (mr, weight, bias) or None.  The arithmetic of group_norm_nhwc + resample_bilinear_nhwc(add=...) (equal up to fma contraction: one ulp).  ``split_into`` / ``image`` as there."""
+    lib = _lib.load()
+    _chk(x, "x", dim=3)
+    _chk(add, "add", dim=3)
+    h, w, C = x.shape
+    H, W = int(size[0]), int(size[1])
+    if tuple(add.shape) != (H, W, C) or not _gn_nhwc_ok(C, num_groups):
+        raise RbaHipError("resample_bilinear_nhwc_gn: add must be [H, W, C]; C % G == 0, (C/G) % 4 == 0")
+
+    def unpack(n, with_relu):
+        if n is None:
+            return 0, 0, 0, 0
+        mr, wgt, b = n[0], n[1], n[2]
+        _chk(mr, "mr")
+        _chk(wgt, "weight", dim=1)
+        _chk(b, "bias", dim=1)
+        if mr.numel() != 2 * num_groups or wgt.numel() != C or b.numel() != C:
+            raise RbaHipError("norm = (mr [G, 2], weight [C], bias [C])")
+        return _p(mr), _p(wgt), _p(b), (int(bool(n[3])) if with_relu and len(n) > 3 else 0)
+    xm, xg, xb, xr = unpack(x_norm, True)
+    am, ag, ab, _ = unpack(add_norm, False)
+    if split_into is not None:
+        if (not isinstance(split_into, SplitActivations) or len(split_into.shape) != 4 or tuple(split_into.shape[1:]) != (H, W, C) or C % 32
+                or not 0 <= image < split_into.shape[0]):
+            raise RbaHipError("split_into must be SplitActivations of shape [B, H, W, C] (C % 32 == 0) with 0 <= image < B")
+        _lib.check(lib.rba_resample_bilinear_nhwc_gn_f32(_p(x), xm, xg, xb, xr, _p(add), am, ag, ab, _p(split_into.data), 1, C, num_groups, h, w, H, W,
+                                                         image * H * W, _stream()), "rba_resample_bilinear_nhwc_gn_f32")
+        return split_into
+    out = torch.empty((H, W, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_resample_bilinear_nhwc_gn_f32(_p(x), xm, xg, xb, xr, _p(add), am, ag, ab, _p(out), 0, C, num_groups, h, w, H, W, 0, _stream()),
+               "rba_resample_bilinear_nhwc_gn_f32")
+    return out
+
+
 @_hip_op
 def bn_relu_conv1x1(x, scale, shift, weight, bias=None):
     """conv1x1(relu(x * scale[c] + shift[c])) for x [B,C,...] -> [B,O,...] (O = weight.shape[0] in {1,2,4}): the DenseHybrid

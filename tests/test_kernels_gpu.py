@@ -880,3 +880,36 @@ def test_msda_fused_equals_prepare_plus_forward(ops, N, Lq, L, edge):
     from oracle import ref_ops
     want = ref_ops.ms_deform_attn(value.double(), shapes, loc.cpu().double(), w.cpu().double())
     assert maxerr(fused, want) < 1e-4            # fp32 sample positions (y H - 0.5 at H = 92..160) against the float64 restatement
+
+
+@pytest.mark.parametrize("h,w,H,W,C,split", [(8, 16, 16, 32, 256, False), (23, 40, 46, 80, 128, False), (64, 128, 128, 256, 256, True), (7, 9, 14, 18, 128, True)])
+def test_resample_nhwc_with_folded_group_norms(ops, h, w, H, W, C, split):
+    """round 3: the FPN top-down step with GroupNorm(lateral) and ReLU(GroupNorm(previous conv)) folded into the resample kernel's loads agrees with
+    group_norm_nhwc + resample_bilinear_nhwc to an ulp (fp32 rows and the split image), and the statistics entry returns what the
+    full GroupNorm uses"""
+    g = torch.Generator().manual_seed(h * w + C)
+    x = dev(torch.randn(1, h * w, C, generator=g) * 2 + 0.5)
+    add = dev(torch.randn(1, H * W, C, generator=g))
+    gx, bx, ga, ba = (dev(torch.randn(C, generator=g)) for _ in range(4))
+    xn = ops.group_norm_nhwc(x, 32, gx, bx, 1e-5, relu=True)
+    an = ops.group_norm_nhwc(add, 32, ga, ba, 1e-5)
+    mx, ma = ops.group_norm_nhwc_stats(x, 32, 1e-5), ops.group_norm_nhwc_stats(add, 32, 1e-5)
+    xd = x[0].double().view(h * w, 32, C // 32)
+    assert maxerr(mx[0, :, 0], xd.mean((0, 2))) < 1e-5
+    assert maxerr(mx[0, :, 1], (xd.var((0, 2), unbiased=False) + 1e-5).rsqrt()) < 1e-4
+    want = ops.resample_bilinear_nhwc(xn[0].view(h, w, C), (H, W), add=an[0].view(H, W, C))
+    got = ops.resample_bilinear_nhwc_gn(x[0].view(h, w, C), (H, W), add[0].view(H, W, C), 32, x_norm=(mx[0], gx, bx, True), add_norm=(ma[0], ga, ba))
+    # the same operations per element; the compiler is free to contract a different multiply of `l0 v00 + l1 v01` into the fma in the
+    # two instantiations, so the results agree to an ulp of the interpolated value rather than bit for bit
+    tol = 4e-7 * float(want.abs().max())
+    assert maxerr(got, want.double()) <= tol
+    half = ops.resample_bilinear_nhwc_gn(xn[0].view(h, w, C), (H, W), add[0].view(H, W, C), 32, x_norm=None, add_norm=(ma[0], ga, ba))
+    assert maxerr(half, want.double()) <= tol
+    if split:
+        s_want = ops.SplitActivations.empty((1, H, W, C), x.device)
+        s_got = ops.SplitActivations.empty((1, H, W, C), x.device)
+        s_want.data.zero_(); s_got.data.zero_()
+        ops.resample_bilinear_nhwc(xn[0].view(h, w, C), (H, W), add=an[0].view(H, W, C), split_into=s_want)
+        ops.resample_bilinear_nhwc_gn(x[0].view(h, w, C), (H, W), add[0].view(H, W, C), 32, x_norm=(mx[0], gx, bx, True), add_norm=(ma[0], ga, ba),
+                                      split_into=s_got)
+        assert maxerr(s_got.unpack(), s_want.unpack().double()) <= 2 * tol
