@@ -8,6 +8,9 @@
 #include "common.h"
 #include "../../include/rba_hip.h"
 
+// tools / tests only: 1 = always the round 1-2 decomposition (one workgroup per 16 columns, all row tiles), 2 = always the per-row-tile one
+extern "C" __attribute__((visibility("default"))) int rba_skinny_variant = 0;
+
 namespace {
 
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
@@ -62,6 +65,59 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_kernel(const float* __r
   }
 }
 
+// Round 3: one workgroup per (16 output columns, 16-row tile) instead of per 16 columns with all row tiles.  The 9-layer decoder of BASELINE C5
+// spends 1.2 ms per image in 112 of these launches (profiles/r03_c5_kernel_trace.md): with every row tile in one workgroup a wave walks its k
+// blocks in a rolled loop of 16 loads + 56 MFMAs per trip and pays the memory latency once per trip -- the FFN's second Linear (K = 2048, N = 256:
+// 16 workgroups on a 256-CU chip, 8 trips per wave) took 44 us.  Here a wave's trip is 4 loads + 8 MFMAs, four trips are requested at once, and
+// the launch has M/16 times the workgroups.  k blocks are assigned to waves and reduced through LDS exactly as above: bit-identical results.
+__global__ __launch_bounds__(64 * SW) void skinny_linear_tile_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                     const float* __restrict__ bias, float* __restrict__ out, int M, int N, int K,
+                                                                     int relu) {
+  __shared__ __attribute__((aligned(16))) float red[SW * 16 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int nrow = n0 + l15 < N ? n0 + l15 : N - 1;
+  const int mrow = m0 + l15 < M ? m0 + l15 : M - 1;
+  const float* wrow = W + (int64_t)nrow * K + kk * 8;
+  const float* xrow = x + (int64_t)mrow * K + kk * 8;
+  f32x4_s acc = {0.f, 0.f, 0.f, 0.f};
+  const int kblocks = K / 32;
+  constexpr int U = 4;
+  for (int kb = wave; kb < kblocks; kb += SW * U) {
+    float4 a[U][2], b[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = kb + u * SW < kblocks ? kb + u * SW : kb;                      // clamped re-read, skipped below
+      a[u][0] = *reinterpret_cast<const float4*>(wrow + k * 32);
+      a[u][1] = *reinterpret_cast<const float4*>(wrow + k * 32 + 4);
+      b[u][0] = *reinterpret_cast<const float4*>(xrow + k * 32);
+      b[u][1] = *reinterpret_cast<const float4*>(xrow + k * 32 + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kb + u * SW < kblocks) {                                                 // wave-uniform
+        const float av[8] = {a[u][0].x, a[u][0].y, a[u][0].z, a[u][0].w, a[u][1].x, a[u][1].y, a[u][1].z, a[u][1].w};
+        const float bv[8] = {b[u][0].x, b[u][0].y, b[u][0].z, b[u][0].w, b[u][1].x, b[u][1].y, b[u][1].z, b[u][1].w};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], bv[s_], acc, 0, 0, 0);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4_s*>(red + (wave * 16 + l15) * 16 + kk * 4) = acc;
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < SW; ++w) sum += red[(w * 16 + m) * 16 + n];
+    if (m0 + m < M && n0 + n < N) {
+      if (bias) sum += bias[n0 + n];
+      if (relu) sum = fmaxf(sum, 0.f);
+      out[(int64_t)(m0 + m) * N + n0 + n] = sum;
+    }
+  }
+}
+
 template <int MT>
 int launch(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int relu, hipStream_t st) {
   const size_t shm = (size_t)SW * MT * 16 * 16 * sizeof(float);
@@ -79,6 +135,12 @@ extern "C" int rba_skinny_linear_f32(const float* x, const float* weight, const 
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const int mt = (M + 15) / 16;
+  // the per-row-tile form where a wave of the column-block form would LOOP over k blocks (K > 256: the FFN's second Linear, 32 -> 20 us per call,
+  // C5 +2 % images/s, +6 % single stream); with one k block per wave the column-block form's fewer, fatter workgroups launch faster
+  if (rba_skinny_variant == 0 ? K > 32 * SW : rba_skinny_variant == 2) {
+    hipLaunchKernelGGL(skinny_linear_tile_kernel, dim3((N + 15) / 16, mt), dim3(64 * SW), 0, st, x, weight, bias, out, M, N, K, relu);
+    return rba_launch_status();
+  }
   switch (mt) {
     case 1: return launch<1>(x, weight, bias, out, M, N, K, relu, st);
     case 2: return launch<2>(x, weight, bias, out, M, N, K, relu, st);

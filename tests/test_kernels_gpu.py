@@ -335,6 +335,18 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
     assert out.shape == (M, N) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
     out3 = ops.skinny_linear(dev(x.view(1, M, K)), dev(w), dev(b) if has_bias else None, relu)
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
+    # round 3: the per-row-tile decomposition (default) assigns and reduces the k blocks exactly as the round 1-2 kernel: bit-identical
+    import ctypes
+    from rba_amd import _lib
+    var = ctypes.c_int.in_dll(_lib.load(), "rba_skinny_variant")
+    try:
+        var.value = 1
+        old = ops.skinny_linear(dev(x), dev(w), dev(b) if has_bias else None, relu)
+        var.value = 2
+        new = ops.skinny_linear(dev(x), dev(w), dev(b) if has_bias else None, relu)
+    finally:
+        var.value = 0
+    assert torch.equal(old, out) and torch.equal(new, out)
 
 
 # ----------------------------------------------------------------------------------- bf16x6 (split-bf16) linear
