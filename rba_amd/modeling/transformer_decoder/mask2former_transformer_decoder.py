@@ -68,8 +68,9 @@ class CrossAttentionLayer(nn.Module):
         self.multihead_attn = _MHAParams(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
 
-    def forward(self, tgt, memory, mask_logits, pos, query_pos):
-        t2 = self.multihead_attn(tgt + query_pos, memory + pos, memory, mask_logits)
+    def forward(self, tgt, memory, mask_logits, pos, query_pos, memory_pos=None):
+        """``memory_pos`` = memory + pos when the caller has it (it is the same tensor for every layer that attends to a level)"""
+        t2 = self.multihead_attn(tgt + query_pos, memory + pos if memory_pos is None else memory_pos, memory, mask_logits)
         return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
                                   self.multihead_attn.out_proj.bias)[1]     # forward_post :106-118
 
@@ -190,7 +191,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 gathered[lvl] = mask_features.flatten(2).index_select(2, plan.reshape(-1)).contiguous()   # [B,C,4hw]
             cols = gathered[lvl]
             v = ops.mask_logits(mask_embed, cols).view(B, -1, 4, plan.shape[1])
-            attn_logits = 0.5 * (0.5 * v[:, :, 0] + 0.5 * v[:, :, 1]) + 0.5 * (0.5 * v[:, :, 2] + 0.5 * v[:, :, 3])
+            # = 0.5 * (0.5 * v0 + 0.5 * v1) + 0.5 * (0.5 * v2 + 0.5 * v3), the bilinear sample at the centre of a 2 x 2 cell: scaling by a power
+            # of two is exact, so the factors can be collected without changing a bit -- three launches instead of nine
+            attn_logits = ((v[:, :, 0] + v[:, :, 1]) + (v[:, :, 2] + v[:, :, 3])) * 0.25
             return outputs_class, None, attn_logits.contiguous()
         outputs_mask = ops.mask_logits(mask_embed, mask_features)
         attn_logits = None
@@ -218,9 +221,11 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                                                               need_masks=self.num_layers == 0, gathered=gathered)
         predictions_class.append(cls)
         predictions_mask.append(msk)
+        # memory + pos is the key input of every cross-attention layer of a level: one add per level instead of one per layer
+        kin = [src[l] + pos[l] for l in range(min(self.num_feature_levels, self.num_layers))]
         for i in range(self.num_layers):
             li = i % self.num_feature_levels
-            output = self.transformer_cross_attention_layers[i](output, src[li], attn_logits, pos[li], query_embed)
+            output = self.transformer_cross_attention_layers[i](output, src[li], attn_logits, pos[li], query_embed, memory_pos=kin[li])
             output = self.transformer_self_attention_layers[i](output, query_embed)
             output = self.transformer_ffn_layers[i](output)
             last = i == self.num_layers - 1
