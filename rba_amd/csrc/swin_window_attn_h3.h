@@ -185,15 +185,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       }
       S[c] = a0;
     }
+    // three sweeps over the key tiles instead of three dependent MFMAs per tile: consecutive MFMAs then write DIFFERENT accumulators (no
+    // dependent-issue stalls), every accumulator still receives its products in the order kh.qh, kh.ql, kl.qh (bit-identical)
+    {
+      k5h_f16x8 kf[NT];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      const k5h_f16x8 kh = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + c * 1024 + kfrag));
-      const k5h_f16x8 kl = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + PL + c * 1024 + kfrag));
-      f32x4_t a0 = S[c];
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, a0, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, a0, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, a0, 0, 0, 0);
-      S[c] = a0;
+      for (int c = 0; c < NT; ++c) kf[c] = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + c * 1024 + kfrag));
+#pragma unroll
+      for (int c = 0; c < NT; ++c) S[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[c], qh, S[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) S[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[c], ql, S[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) kf[c] = __builtin_bit_cast(k5h_f16x8, *reinterpret_cast<const k5h_u32x4*>(Kh + PL + c * 1024 + kfrag));
+#pragma unroll
+      for (int c = 0; c < NT; ++c) S[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[c], qh, S[c], 0, 0, 0);
     }
     // ---- shift mask, padding keys; row max
     float m = -INFINITY;
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
         ph[2] = ph[3] = pl[2] = pl[3] = 0u;
       }
       const k5h_f16x8 pa = __builtin_bit_cast(k5h_f16x8, ph), pb = __builtin_bit_cast(k5h_f16x8, pl);
+      k5h_f16x8 vh[2], vl[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int half = (dt ^ (kk & 1)) * 32;
@@ -267,14 +273,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
         const k5h_h4 r3 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) k5h_h4*)(v1 + PL));
         const uint2 u0 = __builtin_bit_cast(uint2, r0), u1 = __builtin_bit_cast(uint2, r1);
         const uint2 u2 = __builtin_bit_cast(uint2, r2), u3 = __builtin_bit_cast(uint2, r3);
-        const k5h_f16x8 vh = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u0.x, u0.y, u1.x, u1.y});
-        const k5h_f16x8 vl = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u2.x, u2.y, u3.x, u3.y});
-        // O^T = V^T P^T (V as the A operand, P as B: the same register contents, swapped): the lane ends up with four consecutive
-        // head-dim channels of ONE query instead of one channel of four queries -- 16-byte stores, and the pairing the split output needs
-        Om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pa, Om[dt], 0, 0, 0);
-        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, pa, Ol[dt], 0, 0, 0);
-        Ol[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pb, Ol[dt], 0, 0, 0);
+        vh[dt] = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u0.x, u0.y, u1.x, u1.y});
+        vl[dt] = __builtin_bit_cast(k5h_f16x8, (k5h_u32x4){u2.x, u2.y, u3.x, u3.y});
       }
+      // O^T = V^T P^T (V as the A operand, P as B: the same register contents, swapped): the lane ends up with four consecutive
+      // head-dim channels of ONE query instead of one channel of four queries -- 16-byte stores, and the pairing the split output needs.
+      // Issue order alternates the two head-dim halves so no MFMA waits on the one before it; per accumulator the order of the
+      // products is unchanged (vh.ph | vl.ph, vh.pl)
+      Om[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[0], pa, Om[0], 0, 0, 0);
+      Om[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[1], pa, Om[1], 0, 0, 0);
+      Ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[0], pa, Ol[0], 0, 0, 0);
+      Ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[1], pa, Ol[1], 0, 0, 0);
+      Ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[0], pb, Ol[0], 0, 0, 0);
+      Ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[1], pb, Ol[1], 0, 0, 0);
     }
     // ---- scatter: lane holds O[query = strip*16 + l15][d = 16 dt + 4 kk + r]
     const float inv = 1.0f / lsum;
