@@ -23,6 +23,7 @@
  *   rba_masked_xattn_f32        <- nn.MultiheadAttention core with bool attn_mask
  *                                  (mask2former_transformer_decoder.py:106-118, 433, 483-487)
  *   rba_mask_logits_f32         <- torch.einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479)
+ *   rba_mask_logits_f16x3_f32   <- the same call site, f16x3 arithmetic
  *   rba_swin_window_attn_f32    <- WindowAttention core + window_partition/reverse + roll + pad
  *                                  (backbone/swin.py:44-71, 131-171, 251-284)
  *   rba_skinny_linear_f32       <- nn.Linear / in_proj / MLP on the decoder's [100, B, 256] query tensors
@@ -111,6 +112,10 @@ int rba_masked_xattn_f32(const float* q, const float* k, const float* v, const f
 /* K4.  Mask logits: out[b,q,n] = sum_c embed[b,q,c] * feat[b,c,n]   (embed [B,Q,C], feat [B,C,N], out [B,Q,N]). */
 int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,
                         void* stream);
+/* The same contraction in f16x3 arithmetic (three f16 matrix-pipe products per fp32 product, main + low accumulators; |x| < 65504, NaN
+ * beyond): the form the model uses in its default arithmetic mode.  Shapes outside Q <= 112, C % 32 == 0, C <= 256 run rba_mask_logits_f32. */
+int rba_mask_logits_f16x3_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,
+                              void* stream);
 
 /* K5.  Swin (shifted-)window attention core over a token map, fusing zero-pad to a multiple of the window,
  * cyclic shift, window partition, q*scale @ k^T + relative-position bias (+ shift mask), softmax, @ v,

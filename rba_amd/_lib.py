@@ -29,6 +29,7 @@ SIGNATURES = {
     "rba_masked_xattn_workspace_bytes": [_i, _i, _i, _i],
     "rba_masked_xattn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_mask_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],
+    "rba_mask_logits_f16x3_f32": [_vp, _vp, _vp, _i, _i, _i, _i64, _vp],
     "rba_swin_window_attn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_window_attn_split_out_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_bias_fragments_elems": [_i, _i],

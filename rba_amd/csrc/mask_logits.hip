@@ -195,6 +195,167 @@ int launch_mfma(const float* embed, const float* feat, float* out, int B, int Q,
   return rba_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// f16x3 version (round 3; Q <= 112, C % 32 == 0, C <= 256).  The exact-fp32 MFMA above is bound by that instruction's rate (7.5 GFLOP padded
+// at 157 TFLOP/s = 48 us of the 80 us it takes at 256 x 512 columns; HBM needs 23 us for the 186 MB).  Here every fp32 value is
+// h + 2^-11 l with two f16 numbers (common.h: rba_split_f16x2, the arithmetic of split_linear_h3.h) and the product takes three
+// v_mfma_f32_16x16x32_f16 -- h.h into a MAIN accumulator, h.l and l.h into a LOW one added with weight 2^-11 -- at 16x the fp32 MFMA rate.
+// M = queries in 7 tiles of 16 (the A operand: the embedding matrix, split ONCE per workgroup into an LDS image in fragment order,
+// [k-step of 32 channels][query tile][h | l][lane] x 16 B, read back with lane-linear ds_read_b128), N = pixel columns (the B operand: a lane
+// (j = lane % 16, kb = lane / 16) loads channels 32 s + 8 kb .. + 7 of its CT consecutive columns -- 16 CT bytes per lane, 16 lanes
+// contiguous per channel row -- and splits them in registers: the CT column tiles are the columns {n0 + CT j + i}).  Eight waves per workgroup
+// (56 CT accumulator registers each, 256-register budget: everything stays in VGPRs), one persistent workgroup per CU (the 112 KB image is
+// built once), F loads PF k-steps ahead.
+typedef _Float16 k4_f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t k4_u32x4 __attribute__((ext_vector_type(4)));
+template <int CT> struct K4Vec;
+template <> struct K4Vec<4> { using type = f32x4; };
+template <> struct K4Vec<2> { using type = f32x2; };
+template <> struct K4Vec<1> { using type = float; };
+template <int CT>
+__device__ __forceinline__ float k4_get(const typename K4Vec<CT>::type& v, int i) {
+  if constexpr (CT == 1) return v; else return v[i];
+}
+
+template <int CT, int PF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void mask_logits_h3_kernel(
+    const float* __restrict__ embed, const float* __restrict__ feat, float* __restrict__ out, int Q, int C, int64_t N, int wave_tiles) {
+  constexpr int QT = 7;
+  using V = typename K4Vec<CT>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char k4lds[];   // [C / 32][QT][2][64] x 16 B
+  const int b = blockIdx.y;
+  const float* eb = embed + (int64_t)b * Q * C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kb = lane >> 4;
+  const int steps = C / 32;
+  // one thread = one 16-byte slot of the image: 8 consecutive channels of one query row, consecutive threads -> consecutive slots
+  // (conflict-free writes; the four lane groups of a slot block read the four 32-byte pieces of 16 rows' 128-byte lines); all of a
+  // thread's loads are in flight before the first is split -- the fill is a chain of L2 round trips otherwise
+  constexpr int FB = WAVES == 8 ? 4 : 7;                               // slots per thread and batch: two batches at C = 256
+  for (int base = 0; base < steps * QT * 64; base += 64 * WAVES * FB) {
+    f32x4 x0[FB], x1[FB];
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int e = base + i * 64 * WAVES + threadIdx.x;
+      const int blk = e >> 6, li = e & 63, s = blk / QT, t = blk - s * QT;
+      const int q = 16 * t + (li & 15), c = 32 * s + 8 * (li >> 4);
+      x0[i] = x1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (q < Q && s < steps) {
+        x0[i] = *reinterpret_cast<const f32x4*>(eb + (int64_t)q * C + c);
+        x1[i] = *reinterpret_cast<const f32x4*>(eb + (int64_t)q * C + c + 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int e = base + i * 64 * WAVES + threadIdx.x;
+      k4_u32x4 h, l;
+      uint32_t hh, ll;
+      rba_split_f16x2(x0[i].x, x0[i].y, hh, ll); h.x = hh; l.x = ll;
+      rba_split_f16x2(x0[i].z, x0[i].w, hh, ll); h.y = hh; l.y = ll;
+      rba_split_f16x2(x1[i].x, x1[i].y, hh, ll); h.z = hh; l.z = ll;
+      rba_split_f16x2(x1[i].z, x1[i].w, hh, ll); h.w = hh; l.w = ll;
+      if (e < steps * QT * 64) {
+        unsigned char* dst = k4lds + (size_t)(e >> 6) * 2048 + (e & 63) * 16;
+        *reinterpret_cast<k4_u32x4*>(dst) = h;
+        *reinterpret_cast<k4_u32x4*>(dst + 1024) = l;
+      }
+    }
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x * WAVES + wave; tile < wave_tiles; tile += gridDim.x * WAVES) {
+    const int64_t ncol = (int64_t)tile * (16 * CT) + CT * j;          // this lane's CT columns (N % CT == 0)
+    const bool cvalid = ncol < N;
+    const float* fb = feat + (int64_t)b * C * N + (cvalid ? ncol : 0) + (int64_t)(8 * kb) * N;
+    f32x4 accm[QT][CT], accl[QT][CT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int i = 0; i < CT; ++i) accm[t][i] = accl[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    V fbuf[PF][8];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) fbuf[u][r] = *reinterpret_cast<const V*>(fb + (int64_t)((u < steps ? u : steps - 1) * 32 + r) * N);
+    for (int s0 = 0; s0 < steps; s0 += PF) {                            // steps % PF == 0 (launch_h3)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int s = s0 + u;
+        {
+          k4_f16x8 bh[CT], bl[CT];
+#pragma unroll
+          for (int i = 0; i < CT; ++i) {
+            k4_u32x4 h, l;
+            uint32_t hh, ll;
+            rba_split_f16x2(k4_get<CT>(fbuf[u][0], i), k4_get<CT>(fbuf[u][1], i), hh, ll); h.x = hh; l.x = ll;
+            rba_split_f16x2(k4_get<CT>(fbuf[u][2], i), k4_get<CT>(fbuf[u][3], i), hh, ll); h.y = hh; l.y = ll;
+            rba_split_f16x2(k4_get<CT>(fbuf[u][4], i), k4_get<CT>(fbuf[u][5], i), hh, ll); h.z = hh; l.z = ll;
+            rba_split_f16x2(k4_get<CT>(fbuf[u][6], i), k4_get<CT>(fbuf[u][7], i), hh, ll); h.w = hh; l.w = ll;
+            bh[i] = __builtin_bit_cast(k4_f16x8, h);
+            bl[i] = __builtin_bit_cast(k4_f16x8, l);
+          }
+          const int sn = s + PF < steps ? s + PF : steps - 1;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) fbuf[u][r] = *reinterpret_cast<const V*>(fb + (int64_t)(sn * 32 + r) * N);
+          const unsigned char* ea = k4lds + (size_t)s * QT * 2048 + lane * 16;
+#pragma unroll
+          for (int t = 0; t < QT; ++t) {
+            const k4_f16x8 ah = __builtin_bit_cast(k4_f16x8, *reinterpret_cast<const k4_u32x4*>(ea + t * 2048));
+            const k4_f16x8 al = __builtin_bit_cast(k4_f16x8, *reinterpret_cast<const k4_u32x4*>(ea + t * 2048 + 1024));
+            // consecutive MFMAs write different accumulators; per accumulator the order is h.h | h.l, l.h
+#pragma unroll
+            for (int i = 0; i < CT; ++i) accm[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[i], accm[t][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CT; ++i) accl[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[i], accl[t][i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < CT; ++i) accl[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[i], accl[t][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lane holds out[q = 16 t + 4 kb + r][n = ncol + i] in acc[t][i][r]
+    if (cvalid) {
+      float* ob = out + (int64_t)b * Q * N + ncol;
+      asm volatile("" : "+v"(ob));                                      // keeps the 28 row addresses out of the k loop's registers
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * t + 4 * kb + r;
+          if (q < Q) {
+            V o;
+            if constexpr (CT == 1) o = fmaf(accl[t][0][r], 0.00048828125f, accm[t][0][r]);
+            else {
+#pragma unroll
+              for (int i = 0; i < CT; ++i) o[i] = fmaf(accl[t][i][r], 0.00048828125f, accm[t][i][r]);
+            }
+            *reinterpret_cast<V*>(ob + (int64_t)q * N) = o;
+          }
+        }
+    }
+  }
+}
+
+template <int CT, int PF, int WAVES>
+int launch_h3(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N, hipStream_t st) {
+  const size_t shm = (size_t)(C / 32) * 7 * 2048;
+  auto kern = mask_logits_h3_kernel<CT, PF, WAVES>;
+  static size_t shm_enabled[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+  if (shm > 64 * 1024 && shm > shm_enabled[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return (int)e;
+    shm_enabled[dev] = shm;
+  }
+  const int64_t wave_tiles = (N + 16 * CT - 1) / (16 * CT);
+  if (wave_tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  int64_t wgs = (wave_tiles + WAVES - 1) / WAVES;
+  const int64_t cap = B >= 256 ? 1 : 256 / B;                       // one workgroup per CU (LDS): persistent beyond that
+  if (wgs > cap) { const int64_t rounds = (wgs + cap - 1) / cap; wgs = (wgs + rounds - 1) / rounds; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs, B), dim3(64 * WAVES), shm, st, embed, feat, out, Q, C, N, (int)wave_tiles);
+  return rba_launch_status();
+}
+
 }  // namespace
 
 extern "C" int rba_mask_logits_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,
@@ -212,4 +373,33 @@ extern "C" int rba_mask_logits_f32(const float* embed, const float* feat, float*
   const bool vec2 = (N % 2 == 0) && ((((uintptr_t)feat | (uintptr_t)out) & 7) == 0);
   if (vec2) return launch<52, 2>(embed, feat, out, B, Q, C, N, st);
   return launch<52, 1>(embed, feat, out, B, Q, C, N, st);
+}
+
+// tools / tests only: 0 = columns per lane chosen from N, 1 / 2 = forced; waves per workgroup 8 (product) or 4
+extern "C" __attribute__((visibility("default"))) int rba_k4_variant = 0;
+extern "C" __attribute__((visibility("default"))) int rba_k4_waves = 8;
+
+// The same contraction in f16x3 arithmetic (domain |x| < 65504 like every f16x3 entry point; beyond it the result is NaN, never a wrong number).
+// Shapes outside Q <= 112, C % 32 == 0, C <= 256 take the exact-fp32 path above.
+extern "C" int rba_mask_logits_f16x3_f32(const float* embed, const float* feat, float* out, int B, int Q, int C, int64_t N,
+                                         void* stream) {
+  RBA_CHECK_ARG(B >= 0 && Q >= 0 && C >= 1 && N >= 0 && B <= 65535);
+  if (B == 0 || Q == 0 || N == 0) return 0;
+  RBA_CHECK_ARG(embed && feat && out);
+  const bool a16 = ((((uintptr_t)feat | (uintptr_t)out | (uintptr_t)embed) & 15) == 0);
+  if (!(Q <= 112 && C % 32 == 0 && C <= 256 && a16)) return rba_mask_logits_f32(embed, feat, out, B, Q, C, N, stream);
+  rba_begin();
+  hipStream_t st = (hipStream_t)stream;
+  // two columns per lane (8-byte loads) once that still leaves every SIMD of the chip a wave tile; measured (tools/k4_sweep.py, 256 x 512 / 180 x 320
+  // / 4 x 32 x 64 columns): 66 -> 41 us, 43 -> 22 us, 37 -> 11 us against the exact-fp32 kernel.  Four columns per lane need 224 accumulator
+  // registers, which the compiler splits between VGPRs and AGPRs with two copies per MFMA (64 us): not built.
+  int ct = (N % 2 == 0 && N * B >= 32768) ? 2 : 1;
+  if (rba_k4_variant == 1) ct = 1;
+  if (rba_k4_variant == 2 && N % 2 == 0) ct = 2;
+  const bool even = (C / 32) % 2 == 0;                               // prefetch depth 2 needs an even number of 32-channel steps
+#define RBA_K4(CTV, W) (even ? launch_h3<CTV, 2, W>(embed, feat, out, B, Q, C, N, st) : launch_h3<CTV, 1, W>(embed, feat, out, B, Q, C, N, st))
+  const bool w8 = rba_k4_waves == 8;
+  if (ct == 2) return w8 ? RBA_K4(2, 8) : RBA_K4(2, 4);
+  return w8 ? RBA_K4(1, 8) : RBA_K4(1, 4);
+#undef RBA_K4
 }

@@ -217,8 +217,9 @@ def masked_xattn(q, k, v, mask_logits=None, split_keys=None):
 
 
 @_hip_op
-def mask_logits(embed, feat):
-    """K4.  einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479): embed [B,Q,C], feat [B,C,h,w]."""
+def mask_logits(embed, feat, mode=None):
+    """K4.  einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479): embed [B,Q,C], feat [B,C,h,w].  `mode` (default: SPLIT_MODE)
+    "f16x3" = three f16 matrix-pipe products per fp32 product (|x| < 65504), anything else = the exact-fp32 MFMA kernel."""
     lib = _lib.load()
     _chk(embed, "embed", dim=3)
     _chk(feat, "feat")
@@ -232,7 +233,10 @@ def mask_logits(embed, feat):
     for s in sp:
         N *= int(s)
     out = torch.empty((B, Q) + sp, dtype=torch.float32, device=embed.device)
-    _lib.check(lib.rba_mask_logits_f32(_p(embed), _p(feat), _p(out), B, Q, C, N, _stream()), "rba_mask_logits_f32")
+    if (SPLIT_MODE if mode is None else mode) == "f16x3":
+        _lib.check(lib.rba_mask_logits_f16x3_f32(_p(embed), _p(feat), _p(out), B, Q, C, N, _stream()), "rba_mask_logits_f16x3_f32")
+    else:
+        _lib.check(lib.rba_mask_logits_f32(_p(embed), _p(feat), _p(out), B, Q, C, N, _stream()), "rba_mask_logits_f32")
     return out
 
 

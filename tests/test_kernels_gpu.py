@@ -214,14 +214,43 @@ def test_k3_masked_xattn(ops, B, Q, S, nH, split):
 
 
 # ----------------------------------------------------------------------------------- K4
-@pytest.mark.parametrize("B,Q,C,h,w", [(1, 100, 256, 32, 64), (2, 16, 64, 15, 23), (1, 100, 256, 7, 9), (1, 3, 8, 1, 1)])
-def test_k4_mask_logits(ops, B, Q, C, h, w):
+@pytest.mark.parametrize("mode", ["fp32", "f16x3"])
+@pytest.mark.parametrize("B,Q,C,h,w", [(1, 100, 256, 32, 64), (2, 16, 64, 15, 23), (1, 100, 256, 7, 9), (1, 3, 8, 1, 1), (1, 100, 256, 128, 512),
+                                       (2, 112, 96, 24, 46), (1, 100, 256, 1, 14720)])
+def test_k4_mask_logits(ops, B, Q, C, h, w, mode):
     g = torch.Generator().manual_seed(Q + C)
     e = torch.randn(B, Q, C, generator=g)
     f = torch.randn(B, C, h, w, generator=g)
     ref = torch.einsum("bqc,bchw->bqhw", e.double(), f.double())
-    out = ops.mask_logits(dev(e), dev(f))
+    out = ops.mask_logits(dev(e), dev(f), mode=mode)
     assert out.shape == (B, Q, h, w) and maxerr(out, ref) < 2e-4 * (C / 256) ** 0.5 + 1e-5
+
+
+def test_k4_f16x3_column_tiles_and_range(ops):
+    """both column-tile widths of the f16x3 kernel give the same bits (the per-element arithmetic does not depend on it), the result is as close
+    to fp64 as the exact-fp32 kernel's, and an out-of-range input is NaN, never a wrong number"""
+    import ctypes
+    from rba_amd import _lib
+    knob = ctypes.c_int.in_dll(_lib.load(), "rba_k4_variant")
+    g = torch.Generator().manual_seed(5)
+    e = dev(torch.randn(1, 100, 256, generator=g) * 3)
+    f = dev(torch.randn(1, 256, 4 * 37 * 16, generator=g) * 10)
+    ref = torch.einsum("bqc,bcn->bqn", e.double(), f.double())
+    outs = []
+    try:
+        for v in (1, 2):
+            knob.value = v
+            outs.append(ops.mask_logits(e, f, mode="f16x3"))
+    finally:
+        knob.value = 0
+    assert torch.equal(outs[0], outs[1])
+    exact = ops.mask_logits(e, f, mode="fp32")
+    assert (outs[0].double() - ref).abs().max() <= 1.5 * (exact.double() - ref).abs().max() + 1e-6
+    f2 = f.clone()
+    f2[0, 3, 5] = 7e4
+    bad = ops.mask_logits(e, f2, mode="f16x3")
+    assert torch.isnan(bad[0, :, 5]).all() and torch.isfinite(bad[0, :, 6]).all()
+    assert torch.isfinite(ops.mask_logits(e, f2, mode="fp32")).all()
 
 
 # ----------------------------------------------------------------------------------- K5
