@@ -721,4 +721,161 @@ int launch_reduce_mf(const float* mask, const float* prob, float* rba, int Q, in
 }
 
 
+// ------------------------------------------------------------------------------------------------------------
+// K1 with the class contraction on the matrix pipe and NO transposition ("m4", round 3): v_mfma_f32_4x4x4_16B_f16 is sixteen independent
+// 4 x 4 x 4 products, block b = lane / 4.  Its B operand wants, in lane (b, j), the four k values of column j of block b -- with k = four
+// consecutive query planes and "column" = the lane's OWN pixel that is exactly what a lane has after loading 16 B of each of four planes
+// (the VALU kernel's load pattern: one wave instruction = 1 KiB of one plane).  The A operand (class probabilities, rows = four classes,
+// k = the same four queries) is the same in every block: lane (b, i) reads row i of a small LDS table.  D lands as
+// acc[class tile][pixel][r] = sem[4 tile + r][the lane's pixel]: every lane ends up with all K classes of its four pixels, the layout of the
+// VALU kernel, so the epilogue (tanh-sum / sem_seg / argmax) is shared.  K accumulators per pixel as before (80 registers for K <= 20):
+// occupancy stays at four workgroups per CU, which the 32 x 32 / 16 x 16 MFMA forms of rounds 1-2 could not keep (r02_k1_matrix_pipe.txt).
+// Arithmetic: sigma = h + l and P = h + l with f16 pairs, l = f16(x - h) UNSCALED (both lie in [0, 1]: |l| <= 2^-12 is an f16 subnormal
+// or small normal, absolute error <= 2^-25 -- the matrix pipe does not flush subnormal inputs), three products h.h + h.l + l.h into ONE
+// fp32 accumulator; max |d sem| vs the fp32 fma chain ~1e-6 (tests pin the score to the oracle at the 1e-4 budget like every K1 form).
+// VALU work per lane and four planes: 16 sigmoids + 24 split instructions instead of + 152 packed FMAs.
+// RESULT (tools/k1_sweep.py 121,400-405, profiles/r03_k1_m4.txt): correct (max |d rba| 5.7e-6) and SLOWER, 184-194 us against 158-164: the
+// 4 x 4 x 4 MFMA does not run beside the VALU work of the SIMD's other waves -- tools/micro/mfma4_overlap.hip: 4.5 ns per instruction and
+// the times of matrix waves and vector waves ADD (0.57 + 0.44 -> 0.86 ms), unlike the 32 x 32 / 16 x 16 forms -- so its 60 instructions per
+// four planes cost more VALU-pipe time (~540 cycles) than the 76 packed FMAs they replace (365).  Without the MFMAs the kernel takes
+// 150 us, without the sigmoids 155.  Built only into librba_tune.so.
+typedef _Float16 k1_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 k1_f16x2 __attribute__((ext_vector_type(2)));
+
+// {h(a), h(b)} and {l(a), l(b)} with l = f16(x - h): v_cvt_pk_f16_f32 + two v_fma_mix (x - f32(h) is exact in fp32)
+__device__ __forceinline__ void k1_split_pair(float a, float b, uint32_t& h, uint32_t& l) {
+  const k1_f16x2 hh = {(_Float16)a, (_Float16)b};
+  const uint32_t ap = __builtin_bit_cast(uint32_t, hh);
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(ap), "v"(-1.0f), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(ap), "v"(-1.0f), "v"(b));
+  h = ap;
+  l = r;
+}
+
+template <int K, bool SEM, bool ARG, int WPS, bool DYN, int ABL>
+__global__ __launch_bounds__(256, WPS) void rba_reduce_m4_kernel(const float* __restrict__ mask, const float* __restrict__ prob,
+                                                                float* __restrict__ rba, float* __restrict__ sem,
+                                                                int32_t* __restrict__ argmax, int Q, int64_t HW, int tiles, int mode,
+                                                                unsigned int* __restrict__ counters) {
+  constexpr int MT = (K + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char k1lds[];   // [ceil(Q / 4)][MT][4] x {h01, h23, l01, l23}
+  __shared__ unsigned int sh_tile;
+  const int QS = (Q + 3) >> 2;
+  for (int e = threadIdx.x; e < QS * MT * 4; e += 256) {
+    const int i = e & 3, mt = (e >> 2) % MT, ks = (e >> 2) / MT;
+    const int c = 4 * mt + i;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (4 * ks + k < Q && c < K) ? prob[(4 * ks + k) * K + c] : 0.f;
+    rba_u32x4 t;
+    uint32_t h, l;
+    k1_split_pair(v[0], v[1], h, l); t.x = h; t.z = l;
+    k1_split_pair(v[2], v[3], h, l); t.y = h; t.w = l;
+    *reinterpret_cast<rba_u32x4*>(k1lds + (size_t)e * 16) = t;
+  }
+  __syncthreads();
+  const int li = threadIdx.x & 3;
+  auto next_tile = [&](int prev) -> int {
+    if (!DYN) return prev < 0 ? (int)blockIdx.x : prev + (int)gridDim.x;
+    __syncthreads();
+    if (threadIdx.x == 0) sh_tile = atomicAdd(counters, 1u);
+    __syncthreads();
+    return (int)sh_tile;
+  };
+  for (int tile = next_tile(-1); tile < tiles; tile = next_tile(tile)) {
+    const int64_t p0 = ((int64_t)tile * 256 + threadIdx.x) * 4;
+    if (p0 < HW) {
+      f32x4 acc4[MT][4];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc4[t][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* mp = mask + p0;
+      f32x4 buf[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)(u < Q ? u : Q - 1) * HW));
+      for (int ks = 0; ks < QS; ++ks) {
+        f32x4 sg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ABL == 2) { sg[u] = buf[u]; }
+          else {
+            const f32x2 s01 = rba_sigmoid2((f32x2){buf[u].x, buf[u].y});
+            const f32x2 s23 = rba_sigmoid2((f32x2){buf[u].z, buf[u].w});
+            sg[u] = (f32x4){s01.x, s01.y, s23.x, s23.y};
+          }
+          const int qn = 4 * ks + 4 + u < Q ? 4 * ks + 4 + u : Q - 1;   // planes beyond Q meet zero probabilities in the table
+          buf[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mp + (int64_t)qn * HW));
+        }
+        k1_f16x4 bh[4], bl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          uint32_t h0, l0, h1, l1;
+          k1_split_pair(sg[0][p], sg[1][p], h0, l0);
+          k1_split_pair(sg[2][p], sg[3][p], h1, l1);
+          bh[p] = __builtin_bit_cast(k1_f16x4, (uint2){h0, h1});
+          bl[p] = __builtin_bit_cast(k1_f16x4, (uint2){l0, l1});
+        }
+        if (ABL != 1) {
+          const unsigned char* tp = k1lds + ((size_t)ks * MT * 4 + li) * 16;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const rba_u32x4 a = *reinterpret_cast<const rba_u32x4*>(tp + t * 64);
+            const k1_f16x4 ah = __builtin_bit_cast(k1_f16x4, (uint2){a.x, a.y}), al = __builtin_bit_cast(k1_f16x4, (uint2){a.z, a.w});
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc4[t][p] = __builtin_amdgcn_mfma_f32_4x4x4f16(ah, bh[p], acc4[t][p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc4[t][p] = __builtin_amdgcn_mfma_f32_4x4x4f16(ah, bl[p], acc4[t][p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc4[t][p] = __builtin_amdgcn_mfma_f32_4x4x4f16(al, bh[p], acc4[t][p], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc4[0][p][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint2, bh[p]).x ^ __builtin_bit_cast(uint2, bl[p]).y);
+        }
+      }
+      float acc[K][4];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[k][p] = acc4[k >> 2][p][k & 3];
+      rba_epilogue<K, 4, SEM, ARG>(acc, K, mode, rba, sem, argmax, p0, HW);
+    }
+  }
+  if (DYN && threadIdx.x == 0) {
+    const unsigned int done = atomicAdd(counters + 1, 1u);
+    if (done == gridDim.x - 1) {
+      atomicExch(counters, 0u);
+      atomicExch(counters + 1, 0u);
+    }
+  }
+}
+
+template <int K, int WPS, int ABL = 0>
+int launch_reduce_m4(const float* mask, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int64_t HW, int mode,
+                     unsigned int* counters, hipStream_t st) {
+  const int64_t tiles = (HW + 1023) / 1024;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const size_t shm = (size_t)((Q + 3) / 4) * ((K + 3) / 4) * 64;
+  if (shm > 32 * 1024) return (int)hipErrorInvalidValue;
+  const int64_t cap = 256 * WPS;
+  int64_t grid = tiles;
+  if (tiles <= cap) counters = nullptr;                             // one tile per workgroup: the static split (see launch_reduce_pk)
+  if (tiles > cap) {
+    const int64_t rounds = (tiles + cap - 1) / cap;
+    grid = counters ? cap : (tiles + rounds - 1) / rounds;
+  }
+#define RBA_L(S, A, D) \
+  hipLaunchKernelGGL((rba_reduce_m4_kernel<K, S, A, WPS, D, ABL>), dim3((unsigned)grid), dim3(256), shm, st, mask, prob, rba, sem, argmax, Q, HW, (int)tiles, mode, counters)
+  if (counters) {
+    if (sem && argmax) RBA_L(true, true, true); else if (sem) RBA_L(true, false, true); else if (argmax) RBA_L(false, true, true); else RBA_L(false, false, true);
+  } else {
+    if (sem && argmax) RBA_L(true, true, false); else if (sem) RBA_L(true, false, false); else if (argmax) RBA_L(false, true, false); else RBA_L(false, false, false);
+  }
+#undef RBA_L
+  return rba_launch_status();
+}
+
+
 }  // namespace rba_k1

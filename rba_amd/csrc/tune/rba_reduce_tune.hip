@@ -790,6 +790,18 @@ extern "C" int rba_reduce_f32_tune(const float* mask, const float* cls_prob, flo
       return variant == 200 ? launch_reduce_mx<2>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st)
                             : launch_reduce_mx<3>(mask, cls_prob, rba, Q, 19, HW, 0, ctr, st);
     }
+    case 400: case 401: case 402: case 403: case 404: case 405: {   // m4: 4x4x4-block f16 MFMAs, no transposition (4 / 3 workgroups per CU, static / dynamic tiles, ablations)
+      unsigned int* ctr = nullptr;
+      if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;
+      static bool zeroed4 = false;
+      if (!zeroed4) { hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned int), st); zeroed4 = true; }
+      if (variant == 400) return launch_reduce_m4<19, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, ctr, st);
+      if (variant == 401) return launch_reduce_m4<19, 3>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, ctr, st);
+      if (variant == 402) return launch_reduce_m4<19, 4>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, nullptr, st);
+      if (variant == 403) return launch_reduce_m4<19, 4, 1>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, ctr, st);   // no MFMAs
+      if (variant == 404) return launch_reduce_m4<19, 4, 2>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, ctr, st);   // no sigmoids
+      return launch_reduce_m4<19, 5>(mask, cls_prob, rba, nullptr, nullptr, Q, HW, 0, ctr, st);
+    }
     case 121: {   // the product kernel: packed, dynamic tile assignment through a (here: static device) workspace
       unsigned int* ctr = nullptr;
       if (hipGetSymbolAddress((void**)&ctr, HIP_SYMBOL(k1_tile_counter)) != hipSuccess) return (int)hipErrorInvalidValue;

@@ -24,4 +24,13 @@ cd $R
 bash tools/pmc_k2.sh fused; python tools/pmc_k2_parse.py fused > $O/k2_pmc_final.txt; rm -rf gpurun_out/k2pmc_*
 python tools/k2_ab.py > $O/k2_ab.txt 2>&1
 python tools/k5_sweep.py > $O/k5_sweep.txt 2>&1
-python tools/k6_h3q_ab.py swin_b 30 > $O/k6_ab_swin_b.txt 2>&1
+for S in swin_b swin_l c5; do echo "== $S"; python tools/k6_h3q_ab.py $S 30 2>&1 | grep -v amdgpu.ids; done > $O/k6_h3q.txt
+python tools/k4_sweep.py 2>&1 | grep -v amdgpu.ids > $O/k4_sweep.txt
+python tools/skinny_ab.py 2>&1 | grep -v amdgpu.ids > $O/skinny_ab.txt
+python tools/k1_up4_ab.py 2>&1 | grep -v amdgpu.ids > $O/k1_up4_ab.txt
+python tools/mask_features_ab.py 2>&1 | grep -v amdgpu.ids > $O/mask_features_ab.txt
+python tools/evaluator_bench.py > $O/evaluator.json 2> $O/evaluator.err
+cd /tmp; rm -rf /tmp/pc5
+rocprofv3 --kernel-trace --stats -d /tmp/pc5 -o bench -- python $R/bench.py --arch swin_b_9dl --height 720 --width 1280 --no-cpu-baseline --streams 1 --steps 10 --warmup 3 > $O/prof_c5.log 2>&1
+python $R/tools/prof_summary.py $(find /tmp/pc5 -name "*.db" | head -1) > $O/c5_kernel_trace.md
+rm -rf /tmp/pc5
