@@ -29,7 +29,7 @@ python tools/k4_sweep.py 2>&1 | grep -v amdgpu.ids > $O/k4_sweep.txt
 python tools/skinny_ab.py 2>&1 | grep -v amdgpu.ids > $O/skinny_ab.txt
 python tools/k1_up4_ab.py 2>&1 | grep -v amdgpu.ids > $O/k1_up4_ab.txt
 python tools/mask_features_ab.py 2>&1 | grep -v amdgpu.ids > $O/mask_features_ab.txt
-python tools/evaluator_bench.py > $O/evaluator.json 2> $O/evaluator.err
+python tools/evaluator_bench.py 96 > $O/evaluator.json 2> $O/evaluator.err
 cd /tmp; rm -rf /tmp/pc5
 rocprofv3 --kernel-trace --stats -d /tmp/pc5 -o bench -- python $R/bench.py --arch swin_b_9dl --height 720 --width 1280 --no-cpu-baseline --streams 1 --steps 10 --warmup 3 > $O/prof_c5.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/pc5 -name "*.db" | head -1) > $O/c5_kernel_trace.md
