@@ -10,6 +10,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rba_amd import ops
 
+busy = torch.randn(8192, 8192, device="cuda")
 stages = [(256, 512, 4), (128, 256, 8), (64, 128, 16), (32, 64, 32)]
 ws = 12
 tot = 0.0
@@ -24,13 +25,16 @@ for (H, W, nH), reps, weight in zip(stages, (5, 5, 10, 10), (2, 2, 18, 2)):
     for shift in (0, 6):
         ts = []
         for i in range(reps + 2):
+            # ten launches queued behind a long kernel: the events bracket GPU time, not the host's launch latency (round 3)
+            busy @ busy
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift, bias_frag=frag)
+            for _ in range(10):
+                out = ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift, bias_frag=frag)
             e1.record()
             torch.cuda.synchronize()
             if i >= 2:
-                ts.append(e0.elapsed_time(e1) * 1e3)
+                ts.append(e0.elapsed_time(e1) * 1e2)
         ts.sort()
         line.append(f"{H}x{W}/s{shift}: {ts[len(ts) // 2]:6.1f}us")
         tot += ts[len(ts) // 2] * weight / 2
