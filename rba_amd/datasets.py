@@ -94,26 +94,79 @@ def prefetch(dataset, indices, num_threads=4, depth=None, pin=False, label_dtype
         # pinned host memory (PyTorch's caching host allocator re-uses the blocks): the H2D copy is then truly asynchronous
         return tuple(t.pin_memory() for t in item) if pin else item
 
-    if num_threads <= 0 or len(indices) <= 1:
-        for i in indices:
-            yield get(i)
+    yield from _ahead(get, indices, num_threads, depth)
+
+
+def _ahead(fn, keys, num_threads, depth=None):
+    """fn(key) for key in keys, in order, evaluated by `num_threads` threads at most `depth` items ahead of the consumer"""
+    keys = list(keys)
+    if num_threads <= 0 or len(keys) <= 1:
+        for k in keys:
+            yield fn(k)
         return
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     depth = depth or 2 * num_threads
     with ThreadPoolExecutor(max_workers=num_threads, thread_name_prefix="rba-decode") as ex:
         pending = deque()
-        it = iter(indices)
-        for i in it:
-            pending.append(ex.submit(get, i))
+        it = iter(keys)
+        for k in it:
+            pending.append(ex.submit(fn, k))
             if len(pending) >= depth:
                 break
         while pending:
             item = pending.popleft().result()
-            for i in it:
-                pending.append(ex.submit(get, i))
+            for k in it:
+                pending.append(ex.submit(fn, k))
                 break
             yield item
+
+
+def threaded(loader, max_threads=12):
+    """The batches of `loader` -- a map-style ``torch.utils.data.DataLoader`` with worker PROCESSES, e.g. the reference's
+    ``DataLoader(dataset, shuffle=False, batch_size=1, num_workers=15)`` (evaluate_ood.py:210-211) -- produced in the same order, through the
+    same sampler and collate function, by decode THREADS of this process; anything else is returned unchanged.  Why: with worker processes
+    forked from a process that holds a HIP context, GPU work submitted while they run crawls -- the unmodified reference loop scored 17-20
+    images/s with the 15-process loader however fast the model was (every host -> device copy or graph launch waits 50-190 ms;
+    tools/refloop_probe.py), against 80 with threads.  ``OODEvaluator.compute_anomaly_scores`` passes its loader through here, so the
+    reference's loop needs no change.  Set RBA_LOADER_PROCESSES=1 to keep the processes (a `worker_init_fn` keeps them too)."""
+    import os
+    try:
+        from torch.utils.data import DataLoader
+    except Exception:       # pragma: no cover
+        return loader
+    if (not isinstance(loader, DataLoader) or loader.num_workers <= 0 or loader.batch_sampler is None or loader.worker_init_fn is not None
+            or not hasattr(loader.dataset, "__getitem__") or os.environ.get("RBA_LOADER_PROCESSES") == "1"):
+        return loader
+    return _ThreadedView(loader, min(int(loader.num_workers), max_threads))
+
+
+class _ThreadedView:
+    def __init__(self, loader, num_threads):
+        self.loader, self.num_threads = loader, num_threads
+        self.dataset = loader.dataset
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        ds, collate = self.loader.dataset, self.loader.collate_fn
+        pin = torch.cuda.is_available()
+
+        def pinned(b):
+            if torch.is_tensor(b):
+                return b.pin_memory()
+            if isinstance(b, (list, tuple)):
+                return type(b)(pinned(v) for v in b)
+            if isinstance(b, dict):
+                return {k: pinned(v) for k, v in b.items()}
+            return b
+
+        def get(batch_indices):
+            b = collate([ds[i] for i in batch_indices])
+            return pinned(b) if pin else b
+
+        yield from _ahead(get, self.loader.batch_sampler, self.num_threads)
 
 
 class ThreadLoader:

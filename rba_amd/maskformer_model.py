@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .h2d import to_device
 from .arch import backbone_name as _backbone_name, complete
 from .modeling.backbone import resnet as _resnet  # noqa: F401  (registers build_resnet_backbone)
 from .modeling.backbone import swin as _swin  # noqa: F401  (registers D2SwinTransformer)
@@ -47,7 +48,7 @@ class MaskFormer(nn.Module):
 
     # ------------------------------------------------------------------ pre-processing (:255-257)
     def preprocess(self, batched_inputs):
-        images = [(x["image"].to(self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        images = [(to_device(x["image"], self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
         sizes = [tuple(int(v) for v in im.shape[-2:]) for im in images]
         d = self.size_divisibility
         H = (max(s[0] for s in sizes) + d - 1) // d * d
@@ -65,7 +66,7 @@ class MaskFormer(nn.Module):
                 and all(x["image"].dim() == 3 and x["image"].shape[0] == 3 and x["image"].dtype in (torch.uint8, torch.float32)
                         for x in batched_inputs)):
             # normalisation + ImageList padding + patch im2col in one kernel, the projection on K6 (backbone/swin.py PatchEmbed.forward_images)
-            images = [x["image"].to(self.device).contiguous() for x in batched_inputs]
+            images = [to_device(x["image"], self.device).contiguous() for x in batched_inputs]
             sizes = [tuple(int(v) for v in im.shape[-2:]) for im in images]
             d = self.size_divisibility
             H = (max(s[0] for s in sizes) + d - 1) // d * d
@@ -275,7 +276,7 @@ class MaskFormer(nn.Module):
             image = batched_inputs[0]["image"]
             if torch.is_tensor(image) and image.dim() == 3 and image.dtype in (torch.uint8, torch.float32) \
                     and set(batched_inputs[0]) <= {"image"}:
-                image = image.to(self.device, non_blocking=True).contiguous()
+                image = to_device(image, self.device).contiguous()
                 r = self._graphed_scores(image, return_argmax, score)
                 if r is not None:
                     return [r]

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .h2d import to_device
 from .metrics import ood_metrics, select_labelled
 
 
@@ -97,6 +98,9 @@ class OODEvaluator:
         kernels before anything reaches the rank statistics (FloatingPointError if that is not finite either)."""
         anomaly_score, ood_gts, predictions = [], [], []
         on_gpu = torch.device(device).type == "cuda"
+        if on_gpu:
+            from .datasets import threaded
+            loader = threaded(loader)                                           # worker processes -> decode threads, same batches (datasets.threaded)
         ring = _HostRing(4) if on_gpu else None
         mode = getattr(self.anomaly_score_func, "rba_score_mode", None)         # set on rba_amd.evaluate_ood's score functions
         CHUNK = 16
@@ -152,7 +156,7 @@ class OODEvaluator:
         for jj, (x, y) in enumerate(loader):
             if jj >= upper_limit:
                 break
-            x = x.to(device, non_blocking=True)
+            x = to_device(x, device)                                             # never a DMA from a DataLoader worker's shared-memory pages (h2d.py)
             ood_gts.append(np.asarray(y.cpu()))
             score, preds = score_one(x)
             store(anomaly_score, jj, score)

@@ -78,3 +78,38 @@ def test_thread_loader_matches_the_dataset_order(tmp_path):
             assert x.shape == (1, 3, 24, 40) and y.shape == (1, 24, 40)
             assert torch.equal(x[0], ds[i][0]) and torch.equal(y[0], ds[i][1])
     assert len(list(ThreadLoader(ds, 2, upper_limit=3, pin=False))) == 3
+
+
+def test_threaded_view_of_a_process_dataloader_yields_the_same_batches(monkeypatch):
+    """datasets.threaded: the reference's DataLoader(dataset, batch_size=1, num_workers=15) is iterated with threads -- same order, same sampler,
+    same collate function; loaders without workers, with a worker_init_fn, or with RBA_LOADER_PROCESSES=1 are left alone"""
+    import torch
+    from torch.utils.data import DataLoader, Dataset, Subset
+    from rba_amd.datasets import threaded
+
+    class DS(Dataset):
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            return torch.full((3, 4, 5), i, dtype=torch.uint8), torch.full((4, 5), i % 3, dtype=torch.int64)
+
+    ds = DS()
+    ref = list(DataLoader(ds, shuffle=False, batch_size=1, num_workers=0))
+    view = threaded(DataLoader(ds, shuffle=False, batch_size=1, num_workers=15))
+    assert type(view).__name__ == "_ThreadedView" and len(view) == 11 and view.dataset is ds
+    got = list(view)
+    assert len(got) == len(ref) and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got, ref))
+    # batches of 4 over a subset, custom collate
+    sub = Subset(ds, [9, 2, 5, 7, 1])
+    coll = lambda items: {"x": torch.stack([it[0] for it in items]), "n": len(items)}
+    got = list(threaded(DataLoader(sub, batch_size=4, num_workers=2, collate_fn=coll)))
+    assert [g["n"] for g in got] == [4, 1] and got[0]["x"][:, 0, 0, 0].tolist() == [9, 2, 5, 7]
+    plain = DataLoader(ds, batch_size=1, num_workers=0)
+    assert threaded(plain) is plain
+    keep = DataLoader(ds, batch_size=1, num_workers=2, worker_init_fn=lambda i: None)
+    assert threaded(keep) is keep
+    assert threaded([1, 2, 3]) == [1, 2, 3]
+    monkeypatch.setenv("RBA_LOADER_PROCESSES", "1")
+    procs = DataLoader(ds, batch_size=1, num_workers=2)
+    assert threaded(procs) is procs

@@ -352,3 +352,10 @@ def test_checkpoint_pickle_with_torch_tensors_is_refused_with_a_hint(tmp_path):
     with pytest.raises(pickle.UnpicklingError, match="RBA_TRUSTED_CHECKPOINT=1"):
         read_state_dict(str(pth))
     assert torch.equal(read_state_dict(str(pth), trusted=True)["w"], torch.ones(2, 2))
+
+
+def test_to_device_is_a_plain_move_without_a_hip_device():
+    from rba_amd.h2d import to_device
+    x = torch.arange(6).view(2, 3)
+    assert to_device(x, "cpu") is x or torch.equal(to_device(x, "cpu"), x)
+    assert to_device(None, "cpu") is None

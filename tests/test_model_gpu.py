@@ -663,3 +663,22 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
         assert np.array_equal(s_, w_.cpu().numpy())
     r = ev.evaluate_ood(scores, gts, verbose=False)
     assert all(np.isfinite(v) for v in r.values())
+
+
+@pytest.mark.gpu
+def test_to_device_stages_shared_memory_tensors():
+    """rba_amd.h2d.to_device: a DataLoader worker's item (shared-memory tensor) reaches the device through a page-locked staging buffer --
+    same values, ring reuse safe across more items than slots, page-locked and device tensors pass through"""
+    from rba_amd.h2d import to_device
+    g = torch.Generator().manual_seed(3)
+    items = [torch.randint(0, 256, (1, 3, 64 + 8 * i, 96), dtype=torch.uint8, generator=g).share_memory_() for i in range(7)]
+    outs = [to_device(x, "cuda") for x in items]
+    torch.cuda.synchronize()
+    for x, o in zip(items, outs):
+        assert o.is_cuda and o.shape == x.shape and o.dtype == x.dtype and torch.equal(o.cpu(), x)
+    y = torch.arange(10, dtype=torch.float32).pin_memory()
+    assert torch.equal(to_device(y, "cuda").cpu(), y)
+    z = outs[0]
+    assert to_device(z, "cuda") is z
+    nc = torch.arange(24, dtype=torch.int64).view(4, 6).t()                      # non-contiguous
+    assert torch.equal(to_device(nc, torch.device("cuda", 0)).cpu(), nc)
