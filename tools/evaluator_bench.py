@@ -2,7 +2,7 @@
 Fishyscapes-LostAndFound-shaped set (1024x2048 PNG images + label PNGs), Swin-B 1dl with seeded weights saved as model_final.pth.
 Reports images/s of the scoring loop (decode threads -> H2D -> forward -> K1 -> labelled-pixel selection) for
 the pipelined loop and for the reference-like serial loop (--num_workers 0 --streams 1).
-    python tools/evaluator_bench.py [n_images] [workdir]"""
+    python tools/evaluator_bench.py [n_images] [workdir] [case,case,...]"""
 import json
 import os
 import pickle
@@ -54,6 +54,7 @@ def main():
     a = A.complete(A.ARCHS["swin_b_1dl"])
     torch.save({"model": A.seeded_weights(a, 0)}, os.path.join(mdir, "model_final.pth"))
     res = {"n_images": n, "image": "1024x2048 PNG", "dataset_write_s": round(t_data, 1)}
+    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None          # optional: run just these cases
     for tag, extra in (("default_graph_8workers_3streams", []),
                        ("graph_16workers_3streams", ["--num_workers", "16"]),
                        ("graph_12workers_2streams", ["--num_workers", "12", "--streams", "2"]),
@@ -61,7 +62,12 @@ def main():
                        ("eager_8workers_3streams", ["--graph", "0"]),
                        ("eager_4workers_3streams", ["--graph", "0", "--num_workers", "4"]),
                        ("eager_16workers_3streams", ["--graph", "0", "--num_workers", "16"]),
+                       ("graph_10workers_3streams", ["--num_workers", "10"]),
+                       ("graph_12workers_3streams", ["--num_workers", "12"]),
+                       ("graph_6workers_3streams", ["--num_workers", "6"]),
                        ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1", "--graph", "0"])):
+        if only is not None and tag not in only:
+            continue
         out = os.path.join(work, "results_" + tag)
         timing = {}
         args = E.build_parser().parse_args(["--models_folder", os.path.join(work, "ckpts"), "--datasets_folder", os.path.join(work, "data"),
@@ -92,6 +98,8 @@ def main():
                                      ("reference_loop_dataloader_15_workers_no_graph", lambda: DataLoader(ds, shuffle=False, batch_size=1, num_workers=15, timeout=300), False),
                                      ("reference_loop_thread_loader_8", lambda: thread_loader(8), True),
                                      ("reference_loop_no_workers", lambda: DataLoader(ds, shuffle=False, batch_size=1, num_workers=0), True)):
+        if only is not None and tag not in only:
+            continue
         try:
             model = E.get_model(os.path.join(mdir, "config.yaml"), os.path.join(mdir, "model_final.pth"))
             model.graph_replay = replay
