@@ -590,6 +590,168 @@ int launch_up4_pk(const float* low, const float* prob, float* rba, float* sem, i
   return rba_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The fused kernel with the class contraction on the matrix pipe ("up4 mx", end of round 3; score only).  Unlike the HBM form of K1 this
+// kernel reads 52 MB that sit in L2 / Infinity Cache -- no load pattern to protect -- so a lane is free to take the queries the MFMA B operand
+// wants: v_mfma_f32_32x32x16_f16 with M = classes (K <= 32), N = 32 pixels, k = 16 queries; lane (n = lane % 32, kb = lane / 32) holds
+// queries 16 s + 8 kb .. + 7 of ITS OWN pixel.  A lane still interpolates four neighbouring output pixels per query from 3 x 2 taps (the
+// packed-fp32 arithmetic of rba_reduce_up4_pk_kernel, ATen's order), which makes four column tiles (tile r = pixels 4 n + r) and 64
+// accumulator registers; the two lane halves work on different queries of the same 128 pixels.  sigma and P are split h + l with UNSCALED f16
+// l (both in [0, 1]; see the note at rba_reduce_m4_kernel in tune/rba_reduce_experiments.h: absolute error 2^-25), three products into one
+// fp32 accumulator.  Per pixel and query the vector work drops from 13.5 packed + 2 transcendental to 5.5 + 2; the 19 x 4 FMAs per query
+// become 12 MFMAs per 16 queries.  Class probabilities: split once per workgroup into LDS in A-fragment order ([16-query step][h | l][lane] x 16 B).
+typedef _Float16 up4_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 up4_f16x2 __attribute__((ext_vector_type(2)));
+typedef float up4_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void up4_split_pair(float a, float b, uint32_t& h, uint32_t& l) {   // l = f16(x - h): v_cvt_pk + two v_fma_mix
+  const up4_f16x2 hh = {(_Float16)a, (_Float16)b};
+  const uint32_t ap = __builtin_bit_cast(uint32_t, hh);
+  uint32_t r;
+  // one asm statement, fenced by one wait state on either side: the inputs are often fresh v_rcp_f32 results (gfx940-class parts need a wait
+  // state between a transcendental and a vector instruction that reads it, and the compiler does not look inside asm), and the consumer of the
+  // half-written destination may follow immediately; early clobber: %0 is written before %4 is read
+  asm("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+      : "=&v"(r) : "v"(ap), "v"(-1.0f), "v"(a), "v"(b));
+  h = ap;
+  l = r;
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 3) void rba_reduce_up4_mx_kernel(const float* __restrict__ low, const float* __restrict__ prob,
+                                                                   float* __restrict__ rba, int Q, int h, int w, int crop_h, int crop_w,
+                                                                   int xtiles, int tiles, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char up4lds[];       // [ceil(Q / 16)][2][64] x 16 B
+  const int QS = (Q + 15) >> 4;
+  for (int e = threadIdx.x; e < QS * 64; e += 256) {
+    const int ln = e & 63, ks = e >> 6, m = ln & 31, q0 = 16 * ks + 8 * (ln >> 5);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (m < K && q0 + i < Q) ? prob[(q0 + i) * K + m] : 0.f;
+    rba_u32x4 th, tl;
+    uint32_t a, b;
+    up4_split_pair(v[0], v[1], a, b); th.x = a; tl.x = b;
+    up4_split_pair(v[2], v[3], a, b); th.y = a; tl.y = b;
+    up4_split_pair(v[4], v[5], a, b); th.z = a; tl.z = b;
+    up4_split_pair(v[6], v[7], a, b); th.w = a; tl.w = b;
+    *reinterpret_cast<rba_u32x4*>(up4lds + (size_t)ks * 2048 + ln * 16) = th;
+    *reinterpret_cast<rba_u32x4*>(up4lds + (size_t)ks * 2048 + 1024 + ln * 16) = tl;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, kb = lane >> 5;
+  const int tile = blockIdx.x * 4 + wave;                                       // one wave = 128 output pixels of one row
+  if (tile >= tiles) return;
+  const int y = tile / xtiles, xt = tile - y * xtiles;
+  const int j = 32 * xt + n;                                                    // this lane's low-res column = its four output columns / 4
+  const BilinearTap ty = bilinear_tap(y, 0.25f, h);
+  BilinearTap tx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tx[r] = bilinear_tap(4 * j + r, 0.25f, w);
+  const int jl = j < w ? j : w - 1;
+  const int jm = jl > 0 ? jl - 1 : 0, jc = jl, jp = jl < w - 1 ? jl + 1 : w - 1;
+  const f32x2 l0a = {tx[0].l0, tx[1].l0}, l1a = {tx[0].l1, tx[1].l1}, l0b = {tx[2].l0, tx[3].l0}, l1b = {tx[2].l1, tx[3].l1};
+  const int plane = h * w;                                                      // Q * h * w < 2^29 (launcher): byte offsets fit 32 bits
+  // Addressing: query u = 16 s + i of lane half 0 and u + 8 of half 1 are read in ONE instruction = wave-uniform base (low + u * plane, scalar
+  // arithmetic) + a per-lane byte offset (row, column, and the half's 8 planes clamped to Q - 1: three vector instructions per query).
+  // (A variant that skipped the clamp behind a wave-uniform "not the tail" branch was 0 % faster and produced intermittently wrong tiles --
+  // loads into the same registers on both sides of the branch; not pursued.)
+  uint32_t off[6];
+  {
+    const int r0 = ty.i0 * w, r1 = ty.i1 * w;
+    const int c[6] = {r0 + jm, r0 + jc, r0 + jp, r1 + jm, r1 + jc, r1 + jp};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) off[k] = (uint32_t)c[k] * 4u;
+  }
+  auto taps = [&](int qq, float (&d)[6]) {
+    const int u = 16 * (qq >> 3) + (qq & 7);                                    // wave-uniform
+    const int uc = u < Q ? u : Q - 1;
+    const char* base = reinterpret_cast<const char*>(low + (int64_t)uc * plane);
+    int qc = u + 8 * kb;
+    qc = qc < Q ? qc : Q - 1;
+    const uint32_t extra = (uint32_t)(qc - uc) * (uint32_t)plane * 4u;           // padded queries meet zero probabilities
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[k] = *reinterpret_cast<const float*>(base + (off[k] + extra));
+  };
+  up4_f32x16 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+  float t[4][6];                                                                 // ring: query i of a step lives in t[i % 4]; four queries in flight
+#pragma unroll
+  for (int i = 0; i < 4; ++i) taps(i, t[i]);
+  for (int ks = 0; ks < QS; ++ks) {
+    f32x2 s01[8], s23[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float d0 = t[i & 3][0], d1 = t[i & 3][1], d2 = t[i & 3][2], d3 = t[i & 3][3], d4 = t[i & 3][4], d5 = t[i & 3][5];
+      taps(8 * ks + i + 4, t[i & 3]);                                           // beyond the last step: clamped to Q - 1, never used
+      // ATen: l0h * (l0w * v00 + l1w * v01) + l1h * (l0w * v10 + l1w * v11); columns r < 2 -> (j-1, j), r >= 2 -> (j, j+1)
+      const f32x2 topa = l0a * d0 + l1a * d1, bota = l0a * d3 + l1a * d4;
+      const f32x2 topb = l0b * d1 + l1b * d2, botb = l0b * d4 + l1b * d5;
+      s01[i] = rba_sigmoid2(topa * ty.l0 + bota * ty.l1);
+      s23[i] = rba_sigmoid2(topb * ty.l0 + botb * ty.l1);
+    }
+    const up4_f16x8 ah = __builtin_bit_cast(up4_f16x8, *reinterpret_cast<const rba_u32x4*>(up4lds + (size_t)ks * 2048 + lane * 16));
+    const up4_f16x8 al = __builtin_bit_cast(up4_f16x8, *reinterpret_cast<const rba_u32x4*>(up4lds + (size_t)ks * 2048 + 1024 + lane * 16));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rba_u32x4 bh, bl;
+      uint32_t a, b;
+#define RBA_SG(i) (r == 0 ? s01[i].x : (r == 1 ? s01[i].y : (r == 2 ? s23[i].x : s23[i].y)))
+      up4_split_pair(RBA_SG(0), RBA_SG(1), a, b); bh.x = a; bl.x = b;
+      up4_split_pair(RBA_SG(2), RBA_SG(3), a, b); bh.y = a; bl.y = b;
+      up4_split_pair(RBA_SG(4), RBA_SG(5), a, b); bh.z = a; bl.z = b;
+      up4_split_pair(RBA_SG(6), RBA_SG(7), a, b); bh.w = a; bl.w = b;
+#undef RBA_SG
+      const up4_f16x8 vbh = __builtin_bit_cast(up4_f16x8, bh), vbl = __builtin_bit_cast(up4_f16x8, bl);
+      acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vbh, acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vbl, acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, vbh, acc[r], 0, 0, 0);
+    }
+  }
+  // acc[r][i] = sem[class 8 (i / 4) + 4 kb + i % 4][pixel 4 j + r]: score over this half's classes, then across the two lane halves
+  float out[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float part = 0.f, mx = -INFINITY;
+    if (mode == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int cls = 8 * (i >> 2) + 4 * kb + (i & 3);
+        if (8 * (i >> 2) + (i & 3) < K && cls < K) mx = fmaxf(mx, acc[r][i]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, RBA_WAVE));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int cls = 8 * (i >> 2) + 4 * kb + (i & 3);
+      if (8 * (i >> 2) + (i & 3) < K) {                                          // compile-time prune of rows no half can use
+        const float v = acc[r][i];
+        const float term = mode == 0 ? rba_tanh(v) : (mode == 2 ? v : expf(v - mx));
+        part += cls < K ? term : 0.f;
+      }
+    }
+    part += __shfl_xor(part, 32, RBA_WAVE);
+    out[r] = mode == 1 ? -(mx + logf(part)) : -part;
+  }
+  if (kb == 0 && 4 * j < crop_w)
+    *reinterpret_cast<f32x4*>(rba + (int64_t)y * crop_w + 4 * j) = (f32x4){out[0], out[1], out[2], out[3]};   // crop_w % 4 == 0 (launcher)
+}
+
+template <int K>
+int launch_up4_mx(const float* low, const float* prob, float* rba, int Q, int h, int w, int crop_h, int crop_w, hipStream_t st, int mode) {
+  const int wq = crop_w / 4;
+  const int xtiles = (wq + 31) / 32;
+  const int64_t tiles = (int64_t)xtiles * crop_h;
+  if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const size_t shm = (size_t)((Q + 15) / 16) * 2048;
+  if (shm > 64 * 1024 || (int64_t)(Q + 8) * h * w >= (1LL << 29)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((rba_reduce_up4_mx_kernel<K>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), shm, st, low, prob, rba, Q, h, w, crop_h, crop_w,
+                     xtiles, (int)tiles, mode);
+  return rba_launch_status();
+}
+
 template <int KMAX>
 int launch_up4(const float* low, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int K, int h, int w,
                int crop_h, int crop_w, hipStream_t st, int mode) {

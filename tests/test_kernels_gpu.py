@@ -125,6 +125,54 @@ def test_k1_up4_shapes(ops, h, w, ch, cw):
     assert argmax_ok(arg, sem_r)[0] == 0
 
 
+@pytest.mark.parametrize("Q,K,h,w,ch,cw", [(100, 19, 8, 16, 32, 64), (100, 20, 6, 9, 21, 36), (12, 19, 184, 320, 720, 1280), (5, 19, 3, 40, 12, 160),
+                                          (33, 19, 7, 33, 26, 132), (100, 19, 1, 1, 4, 4)])
+def test_k1_up4_matrix_pipe_form(ops, Q, K, h, w, ch, cw):
+    """score-only rba_reduce_up4 runs the class contraction on the matrix pipe (f16 h + l pairs, three products): against the oracle at the K1
+    budget, and against the packed VALU kernel (same taps, same interpolation: only the contraction's rounding differs); all three score modes"""
+    import ctypes
+    from rba_amd import _lib
+    var = ctypes.c_int.in_dll(_lib.load(), "rba_k1_up4_variant")
+    g = torch.Generator().manual_seed(Q + h + w)
+    low = torch.randn(Q, h, w, generator=g) * 5
+    prob = F.softmax(torch.randn(Q, K + 1, generator=g) * 3, -1)[:, :-1].contiguous()
+    up = ref_ops.upsample_bilinear(low[None], (4 * h, 4 * w))[0]
+    sem_r, _, _ = ref_ops.rba_reduce_ordered(up, prob)
+    sem_r = sem_r[:, :ch, :cw]
+    want = {"rba": -sem_r.tanh().sum(0), "energy": -torch.logsumexp(sem_r, dim=0), "neg_logit_sum": -sem_r.sum(0)}
+    for score in want:
+        got, _, _ = ops.rba_reduce_up4(dev(low), dev(prob), (ch, cw), score=score)
+        try:
+            var.value = 2
+            pk, _, _ = ops.rba_reduce_up4(dev(low), dev(prob), (ch, cw), score=score)
+        finally:
+            var.value = 0
+        assert got.shape == (ch, cw) and torch.isfinite(got).all()
+        tol = 6e-5 if score == "neg_logit_sum" else 2e-5                        # a plain sum of K values of magnitude ~3: fp32 round-off of the sum itself
+        assert maxerr(got, want[score]) < tol, score
+        assert maxerr(got, pk.cpu()) < tol, score
+
+
+def test_k1_up4_matrix_pipe_form_full_size_is_stable(ops):
+    """BASELINE C2's map: every pixel within the K1 budget of the packed VALU kernel, and two launches give the same bits (an earlier build of
+    this kernel produced intermittently wrong 32-pixel tiles -- only visible at a size that keeps every CU busy with several workgroups)"""
+    import ctypes
+    from rba_amd import _lib
+    var = ctypes.c_int.in_dll(_lib.load(), "rba_k1_up4_variant")
+    g = torch.Generator().manual_seed(0)
+    low = dev(torch.randn(100, 256, 512, generator=g) * 5)
+    prob = dev(F.softmax(torch.randn(100, 20, generator=g) * 3, -1)[:, :-1].contiguous())
+    try:
+        var.value = 2
+        pk = ops.rba_reduce_up4(low, prob, (1024, 2048))[0]
+    finally:
+        var.value = 0
+    a = ops.rba_reduce_up4(low, prob, (1024, 2048))[0]
+    b = ops.rba_reduce_up4(low, prob, (1024, 2048))[0]
+    assert torch.equal(a, b)
+    assert float((a - pk).abs().max()) < 2e-5
+
+
 # ----------------------------------------------------------------------------------- resample
 @pytest.mark.parametrize("C,h,w,H,W", [(100, 8, 16, 32, 64), (3, 23, 40, 46, 80), (5, 64, 128, 8, 16), (2, 184, 320, 23, 40),
                                         (4, 7, 9, 13, 30), (1, 1, 1, 5, 3), (6, 45, 80, 90, 160), (3, 30, 45, 32, 48)])

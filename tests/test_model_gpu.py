@@ -659,8 +659,8 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
     gt[:, 10:40, 10:60] = 1
     scores, gts = ev.compute_anomaly_scores([(im[None], gt) for im in imgs], device=torch.device("cuda"))
     assert np.isfinite(scores).all() and ev.bf16x6_rescored_images == [0, 1, 2]
-    for s_, w_ in zip(scores, want):
-        assert np.array_equal(s_, w_.cpu().numpy())
+    for k_, (s_, w_) in enumerate(zip(scores, want)):
+        assert np.array_equal(s_, w_.cpu().numpy()), (k_, float(np.abs(s_ - w_.cpu().numpy()).max()), int((s_ != w_.cpu().numpy()).sum()))
     r = ev.evaluate_ood(scores, gts, verbose=False)
     assert all(np.isfinite(v) for v in r.values())
 
