@@ -67,7 +67,7 @@ SIGNATURES = {
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
 }
 
-EXPECTED_ABI = 180        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 181        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 
