@@ -582,12 +582,13 @@ def main():
             print(f"[bench] single-stream probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
 
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "k1_pmc.json")
-    if args.k1 == "fullres" and os.path.exists(pmc):
+    import glob
+    pmc_file = None
+    for pmc in sorted(glob.glob(os.path.join(REPO, "profiles", "k1_pmc*.json"))) if args.k1 == "fullres" else []:
         with open(pmc) as f:
             pj = json.load(f)
         if pj.get("algorithmic_bytes_per_launch") == alg_bytes:        # same kernel, same shape
-            traffic = pj["traffic_bytes_per_launch"]
+            traffic, pmc_file = pj["traffic_bytes_per_launch"], os.path.basename(pmc)
 
     if rank == 0:
         res = {
@@ -611,7 +612,7 @@ def main():
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/k1_pmc.json)",
+                         "traffic": traffic, "traffic_unit": f"bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_file or 'k1_pmc*.json'})",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_avg_ms,
                          "min_launch_ms": k1_ms[0], "launches_timed": len(k1_ms)},
         }
