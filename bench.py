@@ -52,10 +52,22 @@ def parse():
                          "streams have joined (their HIP events are the `roofline` object: uncontended launches inside the timed region); the other "
                          "images' upsample + K1 are part of their stream's graph and overlap the other streams' forwards.  Round 2 ran all of them alone "
                          "(--k1-alone = --streams): 0.3 ms per image during which only an HBM-bound kernel ran")
+    ap.add_argument("--images-per-gpu", type=int, default=0,
+                    help="images every GPU scores per step (= --streams: each image of a step runs on its own HIP stream).  BASELINE.json configs[2] "
+                         "(batch 16 x 1024x2048 sharded over 8 GPUs) is exactly `--gpus 8 --images-per-gpu 2`")
+    ap.add_argument("--sustain", type=float, default=5.0,
+                    help="seconds of the SAME step loop run after the K timed steps (not part of `value`): the `sustained` object of the line -- images/s "
+                         "and the mean shader clock once the chip has settled at its sustained MFMA clock; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
+                    help="quick (default, <= ~15 s): ONE full-size forward of the oracle at the pre-chosen thread count + the isolated reduction; "
+                         "full: BASELINE.md section 3's protocol with the thread sweep, C1's size and one-thread legs (~50 s; also tools/cpu_baseline_sweep.py)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="thread count of the quick cpu_baseline (16 = the sweep's best on 2 x EPYC 9575F)")
     ap.add_argument("--cpu-budget", type=float, default=1.0, help="scale of the wall-time bounds of the cpu_baseline legs")
     ap.add_argument("--n-images", type=int, default=4, help="distinct resident synthetic images cycled through")
     args = ap.parse_args()
+    if args.images_per_gpu > 0:
+        args.streams = args.images_per_gpu
     if args.graph < 0:
         args.graph = 1 if args.streams > 1 else 0
     if args.k1_alone < 0:
@@ -90,14 +102,105 @@ def exchange_inputs(rank, h, w, device):
     return lab, valid
 
 
-def baseline_config(arch, h, w):
+def baseline_config(arch, h, w, world=1, per_gpu=1):
     """which BASELINE.json config a run corresponds to (the label in `config.workload`)"""
-    return {("swin_b_1dl", 1024, 2048): "BASELINE.json configs[1]; per GPU also configs[2]'s shard",
+    if (arch, h, w) == ("swin_b_1dl", 1024, 2048) and world == 8 and per_gpu == 2:
+        return "BASELINE.json configs[2]: batch 16 x 1024x2048 sharded over 8 GPUs, 2 images per GPU per step"
+    return {("swin_b_1dl", 1024, 2048): "BASELINE.json configs[1]; per GPU also configs[2]'s shard (configs[2] exactly = --gpus 8 --images-per-gpu 2)",
             ("swin_l_1dl", 1024, 2048): "BASELINE.json configs[3]",
             ("swin_b_9dl", 720, 1280): "BASELINE.json configs[4]"}.get((arch, h, w), "not a BASELINE.json configuration")
 
 
-def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0):
+class ClockSampler:
+    """Shader clock / busy % of this process's GPU sampled from a thread while the sustained leg runs: amdsmi if it answers, else `rocm-smi`'s
+    text, else nothing (the fields stay null and `source` says why)."""
+
+    def __init__(self, index=0, period=0.25):
+        import threading
+        self.index, self.period = index, period
+        self.sclk, self.busy, self.source, self.err = [], [], None, None
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _amdsmi(self):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        h = hs[min(self.index, len(hs) - 1)]
+
+        def read():
+            clk = busy = None
+            try:
+                m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                cs = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+                clk = sum(cs) / len(cs) if cs else (m.get("current_gfxclk") if isinstance(m.get("current_gfxclk"), (int, float)) else None)
+                busy = m.get("average_gfx_activity") if isinstance(m.get("average_gfx_activity"), (int, float)) else None
+            except Exception:                                                 # noqa: BLE001
+                pass
+            if clk is None:
+                ci = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                clk = ci.get("clk") if isinstance(ci.get("clk"), (int, float)) else ci.get("cur_clk")
+            if busy is None:
+                try:
+                    busy = amdsmi.amdsmi_get_gpu_activity(h).get("gfx_activity")
+                except Exception:                                             # noqa: BLE001
+                    busy = None
+            return clk, busy
+        read()
+        return read
+
+    def _rocm_smi(self):
+        import re
+        import subprocess
+
+        def read():
+            out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showuse"], capture_output=True, text=True, timeout=5).stdout
+            m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out) or re.search(r"sclk.*?\((\d+)Mhz\)", out)
+            b = re.search(r"GPU use \(%\): (\d+)", out)
+            return (float(m.group(1)) if m else None), (float(b.group(1)) if b else None)
+        read()
+        return read
+
+    def _run(self):
+        read = None
+        for name, mk in (("amdsmi", self._amdsmi), ("rocm-smi", self._rocm_smi)):
+            try:
+                read = mk()
+                self.source = name
+                break
+            except Exception as e:                                            # noqa: BLE001
+                self.err = f"{name}: {type(e).__name__}: {e}"
+        while read is not None and not self._stop.is_set():
+            try:
+                c, b = read()
+                if isinstance(c, (int, float)):
+                    self.sclk.append(float(c))
+                if isinstance(b, (int, float)):
+                    self.busy.append(float(b))
+            except Exception as e:                                            # noqa: BLE001
+                self.err = f"{type(e).__name__}: {e}"
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=10)
+
+    def summary(self):
+        r = {"source": self.source, "samples": len(self.sclk)}
+        if self.sclk:
+            r.update(sclk_mhz_mean=sum(self.sclk) / len(self.sclk), sclk_mhz_min=min(self.sclk), sclk_mhz_max=max(self.sclk))
+        else:
+            r.update(sclk_mhz_mean=None, error=self.err)
+        if self.busy:
+            r["gfx_busy_pct_mean"] = sum(self.busy) / len(self.busy)
+        return r
+
+
+def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0, mode="quick", threads=16):
     """the oracle (oracle/ref_model.py + oracle/ref_ops.py = CPU restatement of the reference path,
     pinned by tests/golden) timed on this box's host cores, fp32, no_grad, batch 1, after a warm-up, median of repeated runs:
       (1) full forward + RbA score at the bench size (C2) with the best thread count of a short sweep, and at C1's size
@@ -120,6 +223,43 @@ def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0):
         rec["cpu_model"] = names[0] if names else None
     except OSError:
         rec["cpu_model"] = None
+
+    if mode == "quick":
+        # ONE full-size forward at the pre-chosen thread count (the full protocol's sweep picks 16 on the driver's 2 x 64-core EPYC 9575F: 5.7 s;
+        # `--cpu-baseline full` / tools/cpu_baseline_sweep.py re-derive it) + the isolated reduction: ~10 s, so that the bench's wall time is the
+        # GPU's, not the baseline's
+        t = max(1, min(threads, ncpu))
+        torch.set_num_threads(t)
+        image = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+        ref_model.forward(torch.randint(0, 256, (3, 256, 512), generator=g, dtype=torch.uint8), sd, a)      # warm-up: thread pool, allocator
+        out = {}
+
+        def fwd():
+            out["o"] = ref_model.forward(image, sd, a)
+        full = _timed_runs(fwd, 1, 0)
+        assert out["o"]["rba"].shape == (h, w)
+        rec.update(value=1.0 / full[0], cores=t, runs_s=full, protocol="quick",
+                   sample=f"1 run of 1 image 3x{h}x{w}, full forward + RbA score, torch CPU fp32, {t} threads (pre-chosen: best of the sweep in "
+                          f"tools/cpu_baseline_sweep.py on 2 x EPYC 9575F), {full[0]:.2f} s; warm-up = one 256x512 forward")
+        Q, K = a["num_queries"], a["num_classes"]
+        H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        g0 = torch.Generator().manual_seed(0)
+        low = torch.randn(Q, H // 4, W // 4, generator=g0) * 5.0
+        cls = torch.randn(Q, K + 1, generator=g0) * 3.0
+
+        def reduction():
+            up = ref_ops.upsample_bilinear(low[None], (H, W))[0]
+            sem = ref_ops.semantic_inference(cls, up)
+            return ref_ops.rba_score(sem), sem.argmax(0)
+        reduction()
+        red = _timed_runs(reduction, 3, 4.0 * budget_scale)
+        alg = 4 * Q * H * W + 4 * Q * K + 4 * H * W
+        rec["reduction"] = {"what": "x4 bilinear -> sigmoid -> einsum(qc,qhw->chw) -> -tanh.sum(0) + argmax on [Q=%d,%d,%d] logits" % (Q, H // 4, W // 4),
+                            "threads": t, "median_s": _med(red), "runs_s": red, "k1_algorithmic_GBps_cpu": alg / _med(red) / 1e9,
+                            "k1_gpu_ms": k1_gpu_ms, "gpu_over_cpu": (_med(red) * 1e3 / k1_gpu_ms) if k1_gpu_ms else None}
+        torch.set_num_threads(default_threads)
+        return rec
+    rec["protocol"] = "full"
 
     # ---- thread-count sweep on the C1-size forward, ascending, stopping at the first count that is slower: on a 2 x 64-core
     # EPYC the small-operator path is fastest at 16 threads (0.20 s) and collapses beyond the physical cores (128: 1.6 s,
@@ -474,6 +614,39 @@ def main():
     k1_avg_ms = sum(k1_ms) / len(k1_ms)
     achieved = alg_bytes / (k1_avg_ms * 1e-3) / 1e9
 
+    # ---- sustained leg: the SAME step loop for >= --sustain seconds, after the counted steps and outside `value`: what the chip
+    # delivers once it has settled at its sustained clock (the counted region is ~0.4 s), with the shader clock sampled beside it
+    sustained = None
+    if args.sustain > 0:
+        n_timed = len(k1_events)
+        out = out.clone()                                                 # the last counted step's map (pooled metric exchange below), not a graph's static output
+        with ClockSampler(local) as cs:
+            barrier()
+            t1 = time.perf_counter()
+            n_sus, i = 0, args.warmup + args.steps
+            while True:
+                for _ in range(10):
+                    step(i)
+                    i += 1
+                n_sus += 10
+                torch.cuda.synchronize()
+                if time.perf_counter() - t1 >= args.sustain:
+                    break
+            barrier()
+            sus_s = time.perf_counter() - t1
+        del k1_events[n_timed:]
+        ts = torch.tensor([sus_s, float(n_sus)], dtype=torch.float64, device=dev)
+        if dist is not None:                                              # slowest rank's time, every rank's images
+            tmax = ts.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            sus_s, n_all = float(tmax[0].item()), float(ts[1].item())
+        else:
+            n_all = float(n_sus)
+        sustained = {"images_per_s": n_all * S / sus_s, "seconds": sus_s, "steps": n_sus, **cs.summary(),
+                     "what": "the timed step loop continued for --sustain seconds after the K counted steps (same streams, graphs and K1 launches; "
+                             "whole job, slowest rank's clock); clock = rank 0's GPU"}
+
     # ---- pooled OoD metric exchange over RCCL, outside the timed region
     exch_ms = None
     if world > 1:
@@ -603,11 +776,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (f16x3 split-MFMA GEMMs, fp32 accumulate)" if ops.SPLIT_MODE == "f16x3" else "f32 (bf16x6 split-MFMA GEMMs, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per stream per step "
-                                   f"({baseline_config(args.arch, h, w)}); random-init seeded weights",
-                       "images_per_gpu_per_step": S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
+                                   f"= {world * S} image(s) per step ({baseline_config(args.arch, h, w, world, S)}); random-init seeded weights",
+                       "images_per_gpu_per_step": S, "global_batch_per_step": world * S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
                        "k1_launches_alone_on_main_stream_per_step": (sum(1 for g_ in part_graphs if not g_[3]) if part_graphs is not None else S),
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",
@@ -641,6 +814,8 @@ def main():
             res["single_stream_images_per_s"] = single["eager"] if "eager" in single else None
             res["single_stream"] = {"images_per_s": single, "what": "one image at a time on one stream through MaskFormer.rba_scores (fused x4 upsample + K1), "
                                     "the caller reads every score back before issuing the next image"}
+        if sustained is not None:
+            res["sustained"] = sustained
         res["n_ranks_seen"] = n_ranks_seen
         res["dist_backend"] = backend_seen
         if gemm is not None:
@@ -651,7 +826,7 @@ def main():
         t_gpu_done = time.perf_counter()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.arch, h, w, k1_gpu_ms=k1_avg_ms if args.k1 == "fullres" else None,
-                                               budget_scale=args.cpu_budget)
+                                               budget_scale=args.cpu_budget, mode=args.cpu_baseline, threads=args.cpu_threads)
         # where the command's wall time goes: the timed region is short by contract (K steps); the CPU baseline is most of the rest
         res["wall_time_s"] = {"command_total": time.perf_counter() - t_cmd0, "timed_region": elapsed,
                               "setup_warmup_probes_gpu_phase": t_gpu_done - t_cmd0 - elapsed, "cpu_baseline": time.perf_counter() - t_gpu_done,

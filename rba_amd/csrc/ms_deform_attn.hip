@@ -216,6 +216,7 @@ template <bool FUSED>
 static int launch_msda_lp(const float* value, const int64_t* shapes, const int64_t* lsi, const float* a, const float* b, float* out, int N, int S,
                           int M, int L, int Lq, int P, hipStream_t st) {
   if (P != 4 || (L != 1 && L != 3) || M > 65535 || N > 65535) return -1;
+  if ((int64_t)S * M * 128 >= ((int64_t)1 << 32)) return -1;     // the kernel's tap addresses are 32-bit byte offsets into one image's value [S, M, 32] fp32
   const dim3 grid((unsigned)((Lq + 31) / 32), (unsigned)M, (unsigned)N);
   if (L == 1) hipLaunchKernelGGL((msda_fwd_lp_kernel<1, 4, FUSED>), grid, dim3(256), 0, st, value, shapes, lsi, a, b, out, S, M, Lq);
   else hipLaunchKernelGGL((msda_fwd_lp_kernel<3, 4, FUSED>), grid, dim3(256), 0, st, value, shapes, lsi, a, b, out, S, M, Lq);
@@ -301,6 +302,7 @@ extern "C" int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spa
 extern "C" int rba_msda_fused_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* raw,
                                   const float* reference_points, float* out, int N, int S, int M, int D, int L, int Lq, int P, void* stream) {
   RBA_CHECK_ARG(N >= 0 && S >= 1 && M >= 1 && D == 32 && P == 4 && (L == 1 || L == 3) && Lq >= 0 && M <= 65535 && N <= 65535);
+  RBA_CHECK_ARG((int64_t)S * M * 128 < ((int64_t)1 << 32));      // 32-bit tap offsets (launch_msda_lp); callers fall back to prepare + the generic kernel
   if (N == 0 || Lq == 0) return 0;
   RBA_CHECK_ARG(value && spatial_shapes && level_start_index && raw && reference_points && out);
   RBA_CHECK_ARG((((uintptr_t)value | (uintptr_t)out | (uintptr_t)raw) & 15) == 0);

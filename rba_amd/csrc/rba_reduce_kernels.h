@@ -604,17 +604,28 @@ typedef _Float16 up4_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 up4_f16x2 __attribute__((ext_vector_type(2)));
 typedef float up4_f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void up4_split_pair(float a, float b, uint32_t& h, uint32_t& l) {   // l = f16(x - h): v_cvt_pk + two v_fma_mix
-  const up4_f16x2 hh = {(_Float16)a, (_Float16)b};
-  const uint32_t ap = __builtin_bit_cast(uint32_t, hh);
-  uint32_t r;
-  // one asm statement, fenced by one wait state on either side: the inputs are often fresh v_rcp_f32 results (gfx940-class parts need a wait
-  // state between a transcendental and a vector instruction that reads it, and the compiler does not look inside asm), and the consumer of the
-  // half-written destination may follow immediately; early clobber: %0 is written before %4 is read
-  asm("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
-      : "=&v"(r) : "v"(ap), "v"(-1.0f), "v"(a), "v"(b));
-  h = ap;
-  l = r;
+// Two pairs (a0, a1), (b0, b1) -> packed f16 h and packed f16 residual l = f16(x - h): v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16 reading h's
+// halves in place.  The four mix instructions are ONE asm statement in the order lo, lo, hi, hi because of three gfx950 wait-state rules the
+// compiler enforces for instructions it emits itself and cannot enforce inside asm (it does not decode asm text):
+//  * a VALU that reads a register written by a 16-bit-destination VALU (v_fma_mixlo_f16 writes half a register; v_fma_mixhi_f16 of the SAME
+//    register reads it to keep that half) needs one wait state in between -- round 3's form issued mixlo, mixhi of one register back to
+//    back (40 of 40 sites in the emitted ISA), which is the hazard hipcc itself separates with an s_nop when it emits the pair
+//    (tools/isa_hazards.py, profiles/r04_k1_mx_soak.txt); interleaving two registers gives every mixhi its wait state for free;
+//  * a VALU that reads a fresh transcendental result (the inputs are v_rcp_f32 results of the sigmoid) needs one wait state: leading s_nop;
+//  * the consumer of the last half-written register (an MFMA operand here) needs one as well: trailing s_nop.
+// tests/test_host_cpu.py::test_emitted_isa_has_no_unfenced_16bit_destination_hazards scans every code object of the built library for these.
+__device__ __forceinline__ void up4_split_quad(float a0, float a1, float b0, float b1, uint32_t& ha, uint32_t& la, uint32_t& hb, uint32_t& lb) {
+  const up4_f16x2 va = {(_Float16)a0, (_Float16)a1}, vb = {(_Float16)b0, (_Float16)b1};
+  const uint32_t pa = __builtin_bit_cast(uint32_t, va), pb = __builtin_bit_cast(uint32_t, vb);
+  uint32_t ra, rb;
+  asm("s_nop 0\n\t"
+      "v_fma_mixlo_f16 %0, %2, %4, %5 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %3, %4, %7 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %4, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %3, %4, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 0"
+      : "=&v"(ra), "=&v"(rb) : "v"(pa), "v"(pb), "v"(-1.0f), "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+  ha = pa; la = ra; hb = pb; lb = rb;
 }
 
 template <int K>
@@ -630,10 +641,9 @@ __global__ __launch_bounds__(256, 3) void rba_reduce_up4_mx_kernel(const float* 
     for (int i = 0; i < 8; ++i) v[i] = (m < K && q0 + i < Q) ? prob[(q0 + i) * K + m] : 0.f;
     rba_u32x4 th, tl;
     uint32_t a, b;
-    up4_split_pair(v[0], v[1], a, b); th.x = a; tl.x = b;
-    up4_split_pair(v[2], v[3], a, b); th.y = a; tl.y = b;
-    up4_split_pair(v[4], v[5], a, b); th.z = a; tl.z = b;
-    up4_split_pair(v[6], v[7], a, b); th.w = a; tl.w = b;
+    uint32_t c, d;
+    up4_split_quad(v[0], v[1], v[2], v[3], a, b, c, d); th.x = a; tl.x = b; th.y = c; tl.y = d;
+    up4_split_quad(v[4], v[5], v[6], v[7], a, b, c, d); th.z = a; tl.z = b; th.w = c; tl.w = d;
     *reinterpret_cast<rba_u32x4*>(up4lds + (size_t)ks * 2048 + ln * 16) = th;
     *reinterpret_cast<rba_u32x4*>(up4lds + (size_t)ks * 2048 + 1024 + ln * 16) = tl;
   }
@@ -697,12 +707,10 @@ __global__ __launch_bounds__(256, 3) void rba_reduce_up4_mx_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       rba_u32x4 bh, bl;
-      uint32_t a, b;
+      uint32_t a, b, c, d;
 #define RBA_SG(i) (r == 0 ? s01[i].x : (r == 1 ? s01[i].y : (r == 2 ? s23[i].x : s23[i].y)))
-      up4_split_pair(RBA_SG(0), RBA_SG(1), a, b); bh.x = a; bl.x = b;
-      up4_split_pair(RBA_SG(2), RBA_SG(3), a, b); bh.y = a; bl.y = b;
-      up4_split_pair(RBA_SG(4), RBA_SG(5), a, b); bh.z = a; bl.z = b;
-      up4_split_pair(RBA_SG(6), RBA_SG(7), a, b); bh.w = a; bl.w = b;
+      up4_split_quad(RBA_SG(0), RBA_SG(1), RBA_SG(2), RBA_SG(3), a, b, c, d); bh.x = a; bl.x = b; bh.y = c; bl.y = d;
+      up4_split_quad(RBA_SG(4), RBA_SG(5), RBA_SG(6), RBA_SG(7), a, b, c, d); bh.z = a; bl.z = b; bh.w = c; bl.w = d;
 #undef RBA_SG
       const up4_f16x8 vbh = __builtin_bit_cast(up4_f16x8, bh), vbl = __builtin_bit_cast(up4_f16x8, bl);
       acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vbh, acc[r], 0, 0, 0);

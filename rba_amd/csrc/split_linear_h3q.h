@@ -286,6 +286,8 @@ int launch_h3q(const void* xf, const u32x4_t* wp, const float* bias, const float
   const int NCH = (NT64 + NS - 1) / NS;
   const int64_t NWG = MT * NCH;
   if (NWG >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  // the deferred epilogue reads bias / residual and writes fp32 rows in 16-byte units (N % 32 == 0 keeps every unit inside its row)
+  if ((((uintptr_t)bias | (uintptr_t)res | (uintptr_t)out | (uintptr_t)xf) & 15) != 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3q_kernel<MODE, ACT, PROBE>), dim3((unsigned)NWG), dim3(256), 0, st, reinterpret_cast<const char*>(xf), wp, bias, out,
                      res, (int)M, N, K, NT64, NS, NCH, (int)NWG);
   return 0;

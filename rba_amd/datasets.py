@@ -122,21 +122,55 @@ def _ahead(fn, keys, num_threads, depth=None):
             yield item
 
 
-def threaded(loader, max_threads=12):
+_THREAD_SAFE_DATASETS = ()            # filled below: this module's own readers (stateless __getitem__: open, decode, close)
+_warned_foreign = set()
+
+
+def _thread_safe(dataset):
+    """True for datasets whose __getitem__ may be called from several threads at once: this module's readers, Subsets / ConcatDatasets of
+    them, and any dataset that says so itself (`thread_safe = True`)."""
+    from torch.utils.data import ConcatDataset, Subset
+    if getattr(dataset, "thread_safe", False) or isinstance(dataset, _THREAD_SAFE_DATASETS):
+        return True
+    if isinstance(dataset, Subset):
+        return _thread_safe(dataset.dataset)
+    if isinstance(dataset, ConcatDataset):
+        return all(_thread_safe(d) for d in dataset.datasets)
+    return False
+
+
+def threaded(loader, max_threads=12, force=None):
     """The batches of `loader` -- a map-style ``torch.utils.data.DataLoader`` with worker PROCESSES, e.g. the reference's
     ``DataLoader(dataset, shuffle=False, batch_size=1, num_workers=15)`` (evaluate_ood.py:210-211) -- produced in the same order, through the
-    same sampler and collate function, by decode THREADS of this process; anything else is returned unchanged.  Why: with worker processes
-    forked from a process that holds a HIP context, GPU work submitted while they run crawls -- the unmodified reference loop scored 17-20
-    images/s with the 15-process loader however fast the model was (every host -> device copy or graph launch waits 50-190 ms;
+    same batch sampler and collate function, by decode THREADS of this process; anything else is returned unchanged.  Why: with worker
+    processes forked from a process that holds a HIP context, GPU work submitted while they run crawls -- the unmodified reference loop
+    scored 17-20 images/s with the 15-process loader however fast the model was (every host -> device copy or graph launch waits 50-190 ms;
     tools/refloop_probe.py), against 80 with threads.  ``OODEvaluator.compute_anomaly_scores`` passes its loader through here, so the
-    reference's loop needs no change.  Set RBA_LOADER_PROCESSES=1 to keep the processes (a `worker_init_fn` keeps them too)."""
+    reference's loop needs no change.
+
+    The swap calls ``dataset[i]`` from up to `max_threads` threads at once, which a dataset written for worker PROCESSES need not survive
+    (a shared file handle, an h5py / LMDB reader, a global-RNG transform, `get_worker_info()`): it is therefore automatic ONLY for datasets
+    known to be thread-safe -- this module's readers, Subset / ConcatDataset of them, or a dataset that declares ``thread_safe = True``.
+    For any other dataset the loader is returned unchanged (worker processes, the slow path) with a one-time warning; ``force=True`` or
+    RBA_LOADER_THREADS=1 opts such a dataset in, RBA_LOADER_PROCESSES=1 / ``force=False`` / a `worker_init_fn` keep the processes for
+    every dataset.  The view ignores the loader's `prefetch_factor` and `timeout` (it decodes 2 x threads batches ahead) and page-locks
+    the batches itself."""
     import os
     try:
         from torch.utils.data import DataLoader
     except Exception:       # pragma: no cover
         return loader
     if (not isinstance(loader, DataLoader) or loader.num_workers <= 0 or loader.batch_sampler is None or loader.worker_init_fn is not None
-            or not hasattr(loader.dataset, "__getitem__") or os.environ.get("RBA_LOADER_PROCESSES") == "1"):
+            or not hasattr(loader.dataset, "__getitem__") or os.environ.get("RBA_LOADER_PROCESSES") == "1" or force is False):
+        return loader
+    if not (force or os.environ.get("RBA_LOADER_THREADS") == "1" or _thread_safe(loader.dataset)):
+        name = type(loader.dataset).__name__
+        if name not in _warned_foreign:
+            _warned_foreign.add(name)
+            import warnings
+            warnings.warn(f"rba_amd: DataLoader over {name} keeps its {loader.num_workers} worker processes (not known to be thread-safe). With a HIP "
+                          f"context in the parent this loop is 4x slower than decode threads; set `dataset.thread_safe = True` or "
+                          f"RBA_LOADER_THREADS=1 if {name}.__getitem__ may run in several threads at once.", RuntimeWarning, stacklevel=3)
         return loader
     return _ThreadedView(loader, min(int(loader.num_workers), max_threads))
 
@@ -187,3 +221,6 @@ class ThreadLoader:
     def __iter__(self):
         for item in prefetch(self.dataset, range(self.n), self.num_workers, pin=self.pin and self.num_workers > 0):
             yield tuple(t[None] for t in item[:2])
+
+
+_THREAD_SAFE_DATASETS = (RoadAnomaly, FishyscapesLAF)

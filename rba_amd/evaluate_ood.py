@@ -221,8 +221,8 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
             finally:
                 if prev is not None:
                     model.graph_replay = prev
-        if not bool(torch.isfinite(s2).all()):
-            raise FloatingPointError(f"{dataset_name}: image {k_img} has a non-finite anomaly score in the f16x3 AND the bf16x6 arithmetic")
+        if bool(torch.isnan(s2).any()):
+            raise FloatingPointError(f"{dataset_name}: image {k_img} has a NaN anomaly score in the f16x3 AND the bf16x6 arithmetic")
         fallbacks.append(k_img)
         print(f"[rba_amd] {dataset_name}: image {k_img}: non-finite score in f16x3 arithmetic, re-scored on the bf16x6 kernels", file=sys.stderr)
         return s2.reshape(-1)
@@ -234,11 +234,18 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
             for st_ in {p[2] for p in pending}:
                 if st_ is not main_stream:
                     main_stream.wait_stream(st_)
-        # one fused check per chunk: a NaN / inf score must never reach the sort of the rank statistics
-        finite = torch.stack([torch.isfinite(p[0]).all() for p in pending]).cpu()
-        for j in (~finite).nonzero().reshape(-1).tolist():
-            s_, y_, st_, x_, k_img = pending[j]
-            pending[j] = (rescored(k_img, x_), y_, main_stream, x_, k_img)
+        # one fused check per chunk: a NaN score must never reach the sort of the rank statistics.  NaN -- not +-inf -- is the f16x3 Linear's
+        # overflow answer (h = inf, l = NaN: the whole output row is NaN); an infinite score of a custom score function is passed on as
+        # the reference passes it on
+        nan = torch.stack([torch.isnan(p[0]).any() for p in pending]).cpu()
+        for j in nan.nonzero().reshape(-1).tolist():
+            s_, y_, st_, x_, k_img, shp_ = pending[j]
+            pending[j] = (rescored(k_img, x_), y_, main_stream, x_, k_img, shp_)
+        if args.store_anomaly_scores:                              # saved AFTER the check: the map the metrics use (a re-scored one included)
+            vis = os.path.join("anomaly_scores", model_name, dataset_name)
+            os.makedirs(vis, exist_ok=True)
+            for p in pending:
+                np.save(os.path.join(vis, f"score_{p[4]}.npy"), p[0].reshape(p[5]).cpu().numpy())
         ss, yy = select_labelled(torch.cat([p[0] for p in pending]), torch.cat([p[1] for p in pending]))
         if on_gpu:
             for p in pending:                                      # produced on a side stream, last used here on the main stream
@@ -280,15 +287,11 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
                 # is scored eagerly there
                 s = graphed[id(st)](x) if graphed is not None and not first_of_shape else score_func(model, x[None])
                 t_b = time.perf_counter()
-                if args.store_anomaly_scores:
-                    vis = os.path.join("anomaly_scores", model_name, dataset_name)
-                    os.makedirs(vis, exist_ok=True)
-                    np.save(os.path.join(vis, f"score_{i}.npy"), s.cpu().numpy())
                 # torch.nonzero waits for the GPU (its result has a data-dependent size): compacting every image would
                 # serialise host and GPU image by image -- the launches of image i + 1 could not be issued while image i runs
                 # (measured: 2-3 ms of waiting per image and no overlap between streams).  Park (score, label) maps instead and
                 # compact FLUSH images at a time: one wait per FLUSH images, at most FLUSH x 10 MB parked at 1024 x 2048.
-                pending.append((s.reshape(-1), y.reshape(-1), st, x, i))
+                pending.append((s.reshape(-1), y.reshape(-1), st, x, i, tuple(s.shape)))
                 host["score_calls_s"] += t_b - t_a
             if len(pending) >= FLUSH:
                 t_c = time.perf_counter()

@@ -46,5 +46,14 @@ class ShapeCache:
     def pinned(self):
         return len(self._pinned)
 
+    def unpin(self):
+        """Hand the pinned entries back to the bounded LRU part.  ONLY when every graph that read them is gone (MaskFormer.drop_graphs
+        (release_constants=True), i.e. after a device move, which invalidates every captured graph of the model anyway)."""
+        for k, v in self._pinned.items():
+            self._d[k] = v
+        self._pinned = {}
+        while len(self._d) > self.maxsize:
+            self._d.popitem(last=False)
+
     def __len__(self):
         return len(self._d) + len(self._pinned)

@@ -203,6 +203,7 @@ class MaskFormer(nn.Module):
 
     # ------------------------------------------------------------------ hipGraph replay of the scoring path
     GRAPH_MAX = 8            # live graphs per model (each keeps its own activation pool: ~1.5 GB at 1024 x 2048)
+    GRAPH_THRASH_MAX = 4     # never-replayed graphs evicted before the model gives up capturing new keys
 
     def _weights_version(self):
         v = 0
@@ -215,12 +216,38 @@ class MaskFormer(nn.Module):
                 self.fused_upsample, self.fused_front_end, ops.SPLIT_MODE, ops.SPLIT_ACTIVATIONS, ops.TILES_MIN, ops.MLP_FUSED_MIN_ROWS,
                 getattr(self.sem_seg_head.predictor, "sparse_intermediate_heads", None), self._weights_version())
 
-    def drop_graphs(self):
-        """Forget every captured graph (their pools are freed); the next calls run eagerly, then capture again."""
+    def drop_graphs(self, release_constants=False):
+        """Forget every captured graph (their pools are freed); the next calls run eagerly, then capture again.  release_constants: also
+        un-pin the per-shape constants captures have read (lru.ShapeCache) -- only safe when no graph captured OUTSIDE the model (bench.py,
+        evaluate_ood.GraphedScore) is still alive, e.g. after a device move."""
+        if release_constants:
+            from .lru import ShapeCache
+            for m_ in self.modules():
+                for v_ in vars(m_).values():
+                    if isinstance(v_, ShapeCache):
+                        v_.unpin()
         self.__dict__.pop("_graphs", None)
+        self.__dict__.pop("_graph_seen", None)
+        self.__dict__.pop("_graph_thrash", None)
+
+    def __getstate__(self):
+        st = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
+        for k in ("_graphs", "_graph_seen", "_graph_thrash"):       # hipGraphs cannot be copied or pickled; a copy captures its own
+            st.pop(k, None)
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_graphs", "_graph_seen", "_graph_thrash"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def _apply(self, fn, *args, **kwargs):
-        self.drop_graphs()                  # .to() / .cuda() / .float(): the captured graphs hold the old parameter addresses
+        self.drop_graphs(release_constants=True)   # .to() / .cuda() / .float(): every captured graph holds the old parameter addresses
         return super()._apply(fn, *args, **kwargs)
 
     def _graphed_scores(self, image, return_argmax, score):
@@ -231,13 +258,25 @@ class MaskFormer(nn.Module):
         second captures, later ones copy the image into the graph's input and replay it on the CURRENT stream; the result is a fresh
         tensor.  Returns None when the capture failed (the caller then runs eagerly; the failure is remembered for the key)."""
         graphs = self.__dict__.setdefault("_graphs", {})
+        seen = self.__dict__.setdefault("_graph_seen", {})        # keys met once, not captured yet: bounded on its own, never evicts a graph
         key = self._graph_key(image, return_argmax, score)
         entry = graphs.get(key)
         if entry is None:
-            graphs[key] = "seen"
-            while len(graphs) > self.GRAPH_MAX:                 # oldest first; a graph owns its pool, dropping it frees the memory
-                graphs.pop(next(iter(graphs)))
-            return None
+            if self.__dict__.get("_graph_thrash", 0) >= self.GRAPH_THRASH_MAX:
+                return None                                     # image shapes churn faster than graphs are replayed: stay eager (see below)
+            if key not in seen:
+                seen[key] = True
+                while len(seen) > 4 * self.GRAPH_MAX:
+                    seen.pop(next(iter(seen)))
+                return None
+            del seen[key]
+            entry = "seen"
+            while len(graphs) >= self.GRAPH_MAX:                # oldest first; a graph owns its pool, dropping it frees the memory
+                old = graphs.pop(next(iter(graphs)))            # (on ROCm destroying a graph synchronises the device)
+                if isinstance(old, tuple) and old[4][0] <= 1:             # 1 = only the replay that followed its capture
+                    # a graph that was never replayed is being evicted: with more live shapes than GRAPH_MAX every capture costs more than it
+                    # saves; after GRAPH_THRASH_MAX of these the model stops capturing new keys (drop_graphs() resets)
+                    self.__dict__["_graph_thrash"] = self.__dict__.get("_graph_thrash", 0) + 1
         if entry == "seen":
             try:
                 static_in = image.clone()
@@ -247,7 +286,7 @@ class MaskFormer(nn.Module):
                 with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
                     r = self._rba_scores_eager([{"image": static_in}], return_argmax, score)[0]
                 torch.cuda.current_stream(image.device).wait_stream(cap)
-                entry = graphs[key] = (g, static_in, r, cap)
+                entry = graphs[key] = (g, static_in, r, cap, [0])
             except Exception as e:                                   # noqa: BLE001 -- an optimisation only
                 import sys
                 print(f"[rba_amd] hipGraph capture failed for image shape {tuple(image.shape)} ({type(e).__name__}: {e}); eager launches",
@@ -257,7 +296,8 @@ class MaskFormer(nn.Module):
         if entry is False:
             return None
         graphs[key] = graphs.pop(key)                               # most recently used last
-        g, static_in, r, _ = entry
+        g, static_in, r, _, uses = entry
+        uses[0] += 1
         static_in.copy_(image, non_blocking=True)
         g.replay()
         return (r[0].clone(), r[1].clone()) if return_argmax else r.clone()

@@ -211,7 +211,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     yy = ups[0][None] if B == 1 else torch.stack(ups)
             planes = self._cached(ly, "_rba_conv_" + ops.SPLIT_MODE, lambda: ops.conv3x3_weight(ly.weight.detach()))    # per arithmetic form
             prev = ops.conv3x3_nhwc(yy, planes, None, out_features=d).view(B, h * w, d)   # raw: its GroupNorm + ReLU is folded into the next consumer
-            prev_norm = (ops.group_norm_nhwc_stats(prev, 32, ly.norm.eps) if fold else None, ly.norm)
+            last = idx == self.num_fpn_levels - 1                  # its GroupNorm is applied below by the full kernel: no separate stats pass
+            prev_norm = (ops.group_norm_nhwc_stats(prev, 32, ly.norm.eps) if fold and not last else None, ly.norm)
             ph, pw = h, w
         if prev_norm is not None:                              # the last level feeds the mask-feature projection: normalised here
             prev = ops.group_norm_nhwc(prev, 32, prev_norm[1].weight, prev_norm[1].bias, prev_norm[1].eps, relu=True)

@@ -60,7 +60,7 @@ class MSDeformAttn(nn.Module):
         # sampling_offsets and attention_weights as ONE Linear (rows [offsets | logits]), then one kernel for
         # loc = reference + offset / (W_l, H_l) and the softmax over the L*P logits (reference :95-115)
         raw = ops.linear(query, self._sampling_linear())
-        if ops.msda_fused_ok(self.d_model // M, L, P) and input_padding_mask is None:
+        if ops.msda_fused_ok(self.d_model // M, L, P, S, M) and input_padding_mask is None:
             # locations + softmax inside the gather kernel: one launch, no [N,Lq,M,L,P,3] round trip
             out = ops.msda_fused(value.contiguous(), input_spatial_shapes, input_level_start_index, raw.contiguous(),
                                  reference_points.contiguous(), M, L, P)

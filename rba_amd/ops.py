@@ -366,9 +366,10 @@ def msda_prepare(raw, reference_points, spatial_shapes, M, L, P):
     return loc, attw
 
 
-def msda_fused_ok(D, L, P):
-    """Geometries of the one-launch deformable attention core (head_dim 32, 4 points, 1 or 3 levels: every released configuration)."""
-    return D == 32 and P == 4 and L in (1, 3)
+def msda_fused_ok(D, L, P, S=None, M=None):
+    """Geometries of the one-launch deformable attention core (head_dim 32, 4 points, 1 or 3 levels: every released configuration); with
+    S positions and M heads given, also that one image's value [S, M, 32] fp32 stays below 4 GiB (the kernel's 32-bit tap offsets)."""
+    return D == 32 and P == 4 and L in (1, 3) and (S is None or M is None or S * M * 128 < (1 << 32))
 
 
 @_hip_op
@@ -384,7 +385,7 @@ def msda_fused(value, spatial_shapes, level_start_index, raw, reference_points, 
     _chk(reference_points, "reference_points", dim=4)
     N, S, M2, D = value.shape
     _, Lq, W3 = raw.shape
-    if (M2 != M or not msda_fused_ok(D, L, P) or W3 != 3 * M * L * P or raw.shape[0] != N or tuple(reference_points.shape) != (N, Lq, L, 2)
+    if (M2 != M or not msda_fused_ok(D, L, P, S, M) or W3 != 3 * M * L * P or raw.shape[0] != N or tuple(reference_points.shape) != (N, Lq, L, 2)
             or spatial_shapes.shape[0] != L or level_start_index.shape[0] != L):
         raise RbaHipError("msda_fused: shapes do not match (head_dim 32, P = 4, L in {1, 3})")
     out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
@@ -585,8 +586,9 @@ def _cached_planes(lin, w):
 
 @contextlib.contextmanager
 def split_mode(mode):
-    """Run a block with ops.SPLIT_MODE = mode ("f16x3" | "bf16x6"), e.g. to re-score an image whose f16x3 result is not finite
-    (an activation or weight beyond f16's range) on the full-range kernels."""
+    """Run a block with ops.SPLIT_MODE = mode ("f16x3" | "bf16x6"), e.g. to re-score an image whose f16x3 result is NaN
+    (an activation or weight beyond f16's range) on the full-range kernels.  NOT thread-safe: SPLIT_MODE is a process global that every
+    ops.linear() call reads -- no other thread of the process may issue forwards while a block runs (the evaluator loops are single-threaded)."""
     global SPLIT_MODE
     if mode not in ("f16x3", "bf16x6"):
         raise RbaHipError(f"unknown split mode {mode!r}")

@@ -93,9 +93,11 @@ class OODEvaluator:
         Device -> host: the reference's `.cpu()` per image (support.py:375, 390) stalls the stream once per image; here every map goes
         through a small ring of reusable pinned staging buffers (`_HostRing`: 4 slots, events) into its final pageable numpy array, so
         the launch thread never waits for the image it has just issued and page-locked memory stays at a few maps.
-        Non-finite scores: the f16x3 token Linears answer |value| >= 65504 with NaN (never a wrong number); once per CHUNK of images a
-        fused `isfinite` flag per image is read back, and an image whose score is not finite is scored again on the full-range bf16x6
-        kernels before anything reaches the rank statistics (FloatingPointError if that is not finite either)."""
+        NaN scores: the f16x3 token Linears answer |value| >= 65504 with NaN (never a wrong number, never +-inf); once per CHUNK of images a
+        fused `isnan` flag per image is read back, and an image whose score holds a NaN is scored again on the full-range bf16x6
+        kernels before anything reaches the rank statistics (FloatingPointError if that one holds a NaN too).  An INFINITE score of a custom
+        score function is passed on, as the reference passes it on.  The re-score flips ops.SPLIT_MODE, a process global: this loop, like
+        the reference's, is single-threaded -- do not score on other threads of the process meanwhile (ops.split_mode is not thread-safe)."""
         anomaly_score, ood_gts, predictions = [], [], []
         on_gpu = torch.device(device).type == "cuda"
         if on_gpu:
@@ -132,9 +134,9 @@ class OODEvaluator:
         def check_chunk():
             if not chunk:
                 return
-            finite = torch.stack([c[2] for c in chunk]).cpu()                   # one read-back per chunk
-            for (idx, x, _), ok in zip(chunk, finite.tolist()):
-                if ok:
+            has_nan = torch.stack([c[2] for c in chunk]).cpu()                  # one read-back per chunk
+            for (idx, x, _), bad in zip(chunk, has_nan.tolist()):
+                if not bad:
                     continue
                 prev = getattr(self.model, "graph_replay", None)
                 with ops.split_mode("bf16x6"):
@@ -145,8 +147,8 @@ class OODEvaluator:
                     finally:
                         if prev is not None:
                             self.model.graph_replay = prev
-                if not bool(torch.isfinite(score).all()):
-                    raise FloatingPointError(f"image {idx}: non-finite anomaly score in the f16x3 AND the bf16x6 arithmetic")
+                if bool(torch.isnan(score).any()):
+                    raise FloatingPointError(f"image {idx}: NaN anomaly score in the f16x3 AND the bf16x6 arithmetic")
                 self.bf16x6_rescored_images.append(idx)
                 store(anomaly_score, idx, score)
                 if return_preds:
@@ -163,11 +165,11 @@ class OODEvaluator:
             if return_preds:
                 store(predictions, jj, preds)
             if score.is_cuda:
-                chunk.append((jj, x, torch.isfinite(score).all()))
+                chunk.append((jj, x, torch.isnan(score).any()))
                 if len(chunk) >= CHUNK:
                     check_chunk()
-            elif not bool(torch.isfinite(score).all()):
-                raise FloatingPointError(f"image {jj}: non-finite anomaly score")
+            elif bool(torch.isnan(score).any()):
+                raise FloatingPointError(f"image {jj}: NaN anomaly score")
         check_chunk()
         if ring is not None:
             ring.drain()

@@ -82,7 +82,8 @@ def test_thread_loader_matches_the_dataset_order(tmp_path):
 
 def test_threaded_view_of_a_process_dataloader_yields_the_same_batches(monkeypatch):
     """datasets.threaded: the reference's DataLoader(dataset, batch_size=1, num_workers=15) is iterated with threads -- same order, same sampler,
-    same collate function; loaders without workers, with a worker_init_fn, or with RBA_LOADER_PROCESSES=1 are left alone"""
+    same collate function; loaders without workers, with a worker_init_fn, or with RBA_LOADER_PROCESSES=1 are left alone; a dataset that is not
+    known to be thread-safe keeps its worker processes unless it opts in"""
     import torch
     from torch.utils.data import DataLoader, Dataset, Subset
     from rba_amd.datasets import threaded
@@ -95,6 +96,11 @@ def test_threaded_view_of_a_process_dataloader_yields_the_same_batches(monkeypat
             return torch.full((3, 4, 5), i, dtype=torch.uint8), torch.full((4, 5), i % 3, dtype=torch.int64)
 
     ds = DS()
+    foreign = DataLoader(ds, shuffle=False, batch_size=1, num_workers=15)
+    with pytest.warns(RuntimeWarning, match="thread_safe"):
+        assert threaded(foreign) is foreign                           # unknown dataset: processes stay, one warning
+    assert type(threaded(foreign, force=True)).__name__ == "_ThreadedView"
+    DS.thread_safe = True                                             # the dataset opts in
     ref = list(DataLoader(ds, shuffle=False, batch_size=1, num_workers=0))
     view = threaded(DataLoader(ds, shuffle=False, batch_size=1, num_workers=15))
     assert type(view).__name__ == "_ThreadedView" and len(view) == 11 and view.dataset is ds

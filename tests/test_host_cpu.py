@@ -359,3 +359,28 @@ def test_to_device_is_a_plain_move_without_a_hip_device():
     x = torch.arange(6).view(2, 3)
     assert to_device(x, "cpu") is x or torch.equal(to_device(x, "cpu"), x)
     assert to_device(None, "cpu") is None
+
+
+def test_emitted_isa_has_no_unfenced_16bit_destination_hazards():
+    """hipcc separates a 16-bit-destination VALU (v_fma_mixlo/mixhi_f16 ...) and a transcendental from the next VALU that reads the register
+    when it emitted both; it cannot look inside `asm`.  Scan EVERY gfx950 code object of the built library for back-to-back pairs
+    (tools/isa_hazards.py): round 3's fused K1 (rba_reduce_up4_mx_kernel) shipped with 40 of them and was not bit-stable run to run."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import isa_hazards
+    from rba_amd import _lib
+    if not os.path.exists(os.path.join(isa_hazards.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    r = isa_hazards.scan_library(_lib.LIB_PATH)
+    assert r["code_objects"] >= 15 and r["mix"] > 3000, r["code_objects"]      # the scan saw the library's kernels (3 452 v_fma_mix* in round 4)
+    assert not r["D"], r["D"][:3]
+    assert not r["T"], r["T"][:3]
+    # the scanner itself: the round-3 pattern must be flagged, the fenced forms must pass
+    mk = lambda *ins: [("label", "k")] + [(i, "k") for i in ins]
+    lo, hi = "v_fma_mixlo_f16 v24, v20, v9, v11 op_sel_hi:[1,0,0]", "v_fma_mixhi_f16 v24, v20, v9, v14 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    assert len(isa_hazards.scan(mk(lo, hi))["D"]) == 1
+    assert not isa_hazards.scan(mk(lo, "s_nop 0", hi))["D"]
+    assert not isa_hazards.scan(mk(lo, lo.replace("v24", "v25"), hi))["D"]
+    assert len(isa_hazards.scan(mk(hi, "v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[24:27], v[0:15]"))["D"]) == 1
+    assert not isa_hazards.scan(mk(hi, "ds_write_b128 v2, v[24:27]"))["D"]        # not a VALU reader
+    assert len(isa_hazards.scan(mk("v_rcp_f32_e32 v4, v1", "v_mul_f32_e32 v5, v4, v4"))["T"]) == 1
+    assert not isa_hazards.scan(mk("v_rcp_f32_e32 v4, v1", "v_exp_f32_e32 v5, v4"))["T"]

@@ -173,6 +173,19 @@ def test_k1_up4_matrix_pipe_form_full_size_is_stable(ops):
     assert float((a - pk).abs().max()) < 2e-5
 
 
+def test_k1_up4_matrix_pipe_form_soak(ops):
+    """2 000 launches of the score-only fused K1 at C2's and C5's maps, round-robin from three streams while a fourth
+    stream runs a K6 GEMM loop; every output bit-equal to launch 0 of its map (tools/k1_soak.py reports the pixel pattern otherwise).
+    Round 3's build fails this test (tools/ab, profiles/r04_k1_mx_soak.txt): its v_fma_mixlo_f16 / v_fma_mixhi_f16 pairs were issued back
+    to back, without the wait state a 16-bit-destination write needs before the same register is read."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k1_soak
+    r = k1_soak.soak_kernel(2000)
+    assert r["launches"] == 2000 and r["mismatching_launches"] == 0, r
+
+
 # ----------------------------------------------------------------------------------- resample
 @pytest.mark.parametrize("C,h,w,H,W", [(100, 8, 16, 32, 64), (3, 23, 40, 46, 80), (5, 64, 128, 8, 16), (2, 184, 320, 23, 40),
                                         (4, 7, 9, 13, 30), (1, 1, 1, 5, 3), (6, 45, 80, 90, 160), (3, 30, 45, 32, 48)])

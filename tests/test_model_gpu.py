@@ -459,13 +459,16 @@ def test_bench_self_launch_two_ranks_share_device():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warm),
-                        "--streams", "1", "--n-images", str(nimg), "--height", str(h), "--width", str(w), "--no-cpu-baseline"],
+                        "--streams", "1", "--n-images", str(nimg), "--height", str(h), "--width", str(w), "--no-cpu-baseline",
+                        "--sustain", "0.5"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == steps and res["scaling"] == "weak"
+    assert res["dtype"].startswith("f32 (f16x3") and res["config"]["global_batch_per_step"] == 2
+    assert res["sustained"]["seconds"] >= 0.5 and res["sustained"]["images_per_s"] > 0
     assert res["metric_exchange_ms"] > 0 and res["value"] > 0 and res["roofline"]["frac"] > 0
     # single process: the last timed image of each rank (bench.py: image (warmup + steps - 1) % n_images, seed 1234 + 1000 rank + i)
     model, a, _ = build("swin_b_1dl", 0)
@@ -660,10 +663,9 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
     scores, gts = ev.compute_anomaly_scores([(im[None], gt) for im in imgs], device=torch.device("cuda"))
     assert np.isfinite(scores).all() and ev.bf16x6_rescored_images == [0, 1, 2]
     for k_, (s_, w_) in enumerate(zip(scores, want)):
-        # the same kernels on the same input: normally bit-equal; the bound is the K1 budget (one full-suite run in round 3 saw this comparison
-        # fail once and never again in isolation -- the tuple says by how much if it ever does)
-        d_ = np.abs(s_ - w_.cpu().numpy())
-        assert float(d_.max()) < 2e-5, (k_, float(d_.max()), int((d_ > 0).sum()))
+        # the same kernels on the same input: bit-equal.  (Round 3 relaxed this to 2e-5 after one unexplained failure; the cause was the fused
+        # K1's hand-written v_fma_mixlo/mixhi pair issued without the wait state gfx950 needs -- tools/isa_hazards.py, docs/kernels/K1.md.)
+        assert np.array_equal(s_, w_.cpu().numpy()), (k_, float(np.abs(s_ - w_.cpu().numpy()).max()), int((s_ != w_.cpu().numpy()).sum()))
     r = ev.evaluate_ood(scores, gts, verbose=False)
     assert all(np.isfinite(v) for v in r.values())
 
@@ -685,3 +687,14 @@ def test_to_device_stages_shared_memory_tensors():
     assert to_device(z, "cuda") is z
     nc = torch.arange(24, dtype=torch.int64).view(4, 6).t()                      # non-contiguous
     assert torch.equal(to_device(nc, torch.device("cuda", 0)).cpu(), nc)
+
+
+def test_rba_scores_soak_three_streams_graph_replay():
+    """the evaluator's default scorer must be bit-stable.  Swin-B 1dl at 1024 x 2048 through MaskFormer.rba_scores with graph
+    replay, 3 x 60 forwards alternating over three streams (three graphs replaying concurrently): every score map bit-equal to the first."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import k1_soak
+    r = k1_soak.soak_model(forwards=60)
+    assert r["live_graphs"] == 3 and r["mismatching_forwards"] == 0, r

@@ -26,7 +26,7 @@ tg = os.environ.get("TOGGLE", "")
 if "noh3q" in tg:
     ctypes.c_int.in_dll(_lib.load(), "rba_k6_variant").value = 1
 if "nomsda" in tg:
-    ops.msda_fused_ok = lambda D, L, P: False
+    ops.msda_fused_ok = lambda D, L, P, S=None, M=None: False
 if "nofront" in tg:
     m.fused_front_end = False
 if "noup4" in tg:
