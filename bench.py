@@ -706,6 +706,7 @@ def main():
     # on the launch stream, outside the timed region: score only (the line's `roofline`), + sem_seg materialised (the stock
     # get_RbA / get_logits read out[0]["sem_seg"], maskformer_model.py:381-386), + the int32 argmax map (support.py:385-388)
     k1_forms = None
+    k1_up4_forms = None
     single = None
     if rank == 0:
         try:
@@ -729,6 +730,25 @@ def main():
                     k1_forms[name] = {"algorithmic_bytes_per_launch": nb, "avg_launch_ms": ms, "achieved_GBps": nb / (ms * 1e-3) / 1e9,
                                       "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_timed": len(evs)}
                 del up
+                # the product's DEFAULT K1 path (MaskFormer.rba_scores / forward): the reduction fused with the x4 upsample and the crop, class
+                # contraction on the matrix pipe -- reads the LOW-resolution logits (L2-resident), so it is bound by its arithmetic, not by HBM
+                k1_up4_forms = {}
+                low_ = mask_pred[0].contiguous()
+                for name, (ws_, wa_), extra in (("score_only", (False, False), 0), ("with_sem_seg", (True, False), 4 * K * h * w),
+                                                ("with_sem_seg_and_argmax", (True, True), 4 * K * h * w + 4 * h * w)):
+                    for _ in range(2):
+                        ops.rba_reduce_up4(low_, prob, sizes[0], ws_, wa_)
+                    evs = []
+                    for _ in range(10):
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record(); ops.rba_reduce_up4(low_, prob, sizes[0], ws_, wa_); e1.record()
+                        evs.append((e0, e1))
+                    torch.cuda.synchronize()
+                    ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+                    nb = 4 * Q * (H // 4) * (W // 4) + 4 * Q * K + 4 * h * w + extra
+                    k1_up4_forms[name] = {"algorithmic_bytes_per_launch": nb, "avg_launch_ms": ms, "achieved_GBps": nb / (ms * 1e-3) / 1e9,
+                                          "bound": "valu + mfma (sigmoid, interpolation, f16x3 class contraction)", "launches_timed": len(evs),
+                                          "x_faster_than_upsample_plus_fullres_k1": None}
         except Exception as e:                                           # informational only
             print(f"[bench] K1 form probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
         # ---- the same step on ONE stream, one image at a time (what a caller that scores serially gets): eager launches, and the
@@ -810,6 +830,8 @@ def main():
             print(f"[bench] roofline_e2e skipped ({type(e).__name__}: {e})", file=sys.stderr)
         if k1_forms is not None:
             res["roofline_k1_forms"] = k1_forms
+        if k1_up4_forms:
+            res["k1_fused_upsample_forms"] = k1_up4_forms
         if single is not None:
             res["single_stream_images_per_s"] = single["eager"] if "eager" in single else None
             res["single_stream"] = {"images_per_s": single, "what": "one image at a time on one stream through MaskFormer.rba_scores (fused x4 upsample + K1), "

@@ -31,6 +31,8 @@
  *   rba_bn_relu_conv1x1_f32     <- BNReluConv(hidden_dim, 2, k=1) `ood_pred` head (mask2former_transformer_decoder.py:216-230, 467-468)
  *   rba_split_linear_f32        <- nn.Linear on the backbone's token tensors: qkv / proj / Mlp.fc1(+GELU) / Mlp.fc2 /
  *                                  PatchMerging.reduction (backbone/swin.py:44-71, 131-171, 319-343)
+ *   rba_token_linear_f32        <- nn.Linear on the encoder / decoder-memory token tensors (pixel_decoder/msdeformattn.py:101-140,
+ *                                  ops/modules/ms_deform_attn.py:95-121, mask2former_transformer_decoder.py:83-143) [+ residual + LayerNorm]
  *   rba_gaussian_blur_f32       <- transforms.GaussianBlur(7, sigma=1) on the anomaly map (support.py:366-383)
  *   rba_threshold_u8 / rba_morph3x3_u8 / rba_ccl4_roots_i32 <- the open-set branch of MaskFormer.panoptic_inference
  *                                  (maskformer_model.py:454-481: threshold, cv2.morphologyEx open/close, cv2.connectedComponents)
@@ -162,6 +164,12 @@ int rba_merge_layer_norm_f32(const float* x, const float* gamma, const float* be
  * (mask2former_transformer_decoder.py:25-212). */
 int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias, float* out, int M, int N, int K,
                           int relu, void* stream);
+/* The same with the query position embedding folded in: output columns n < add_cols (a multiple of 16) see x + x_add, the others x -- the
+ * q / k / v projections of a self-attention layer (q = k = W (tgt + query_pos), v = W tgt; mask2former_transformer_decoder.py:48-58) as ONE
+ * launch over the stacked in_proj weight [3E, E] with add_cols = 2E; x_add may be NULL.  seg_n > 0 (N % seg_n == 0) writes the result as
+ * N / seg_n contiguous [M, seg_n] blocks (q, k, v separately contiguous) instead of [M, N]. */
+int rba_skinny_linear_add_f32(const float* x, const float* x_add, int add_cols, const float* weight, const float* bias, float* out,
+                              int M, int N, int K, int relu, int seg_n, void* stream);
 
 /* fp32-accurate Linear on the bf16 matrix pipe: every fp32 value is the exact sum of three bf16 values, and six
  * bf16 x bf16 MFMAs (exact products, fp32 accumulation) reproduce the fp32 product to < 2^-24 relative.
@@ -285,6 +293,37 @@ int rba_ccl4_roots_i32(const uint8_t* mask, int32_t* roots, int H, int W, void* 
 int rba_bn_relu_conv1x1_f32(const float* x, const float* scale, const float* shift, const float* weight, const float* bias, float* out,
                             int B, int C, int O, int64_t P, void* stream);
 int rba_resample_bilinear_ac_f32(const float* x, float* out, int C, int h, int w, int H, int W, void* stream);
+
+/* Row-complete token Linear for the path's SMALL Linears (fewer than 64 tiles of 128 x 128: not served by rba_split_linear_*): the
+ * MSDeformAttn encoder's value / sampling / output projections and linear2 (pixel_decoder/msdeformattn.py:101-140,
+ * ops/modules/ms_deform_attn.py:95-121), the decoder's key / value projections of the memory
+ * (transformer_decoder/mask2former_transformer_decoder.py:83-143), the 1x1 input projection (msdeformattn.py:328-333).  f16x3 arithmetic
+ * (fp32-GEMM accuracy for |v| < 65504, NaN beyond).  One workgroup owns 16 rows and all N <= 256 columns:
+ * rba_token_linear_pack_f16x2: weight [N,K] fp32 -> `packed`, ceil(N/16) * (K/32) * 2048 bytes, [N/16][K/32][h | l][64 lanes][8 f16], lane
+ *                             (n = lane % 16, kb = lane / 16) holding W[16 nt + n][32 b + 8 kb + 0..7]; rows beyond N zero.  K % 32 == 0.
+ * rba_token_linear_f32:       out[m,:] = act((x[m,:] + x_add[m,:]) W^T + bias), act 0 none / 2 ReLU; with ln_weight != NULL instead
+ *                             out[m,:] = LayerNorm(residual[m,:] + (x W^T + bias)) * ln_weight + ln_bias (N % 16 == 0, act 0): the
+ *                             post-norm `src = norm(src + dropout(src2))` of msdeformattn.py:134-138 in the GEMM's epilogue.
+ *                             x_add, bias may be NULL; residual only with ln_weight.  out must not alias x.
+ * rba_token_linear_multi_f32: up to three Linears over the SAME rows x [M,K] in ONE launch, problem i:
+ *                             out_i[m * ld_out + n] = act((x[m,:] + x_add_i[m,:]) W_i^T + bias_i)[n], n < N_i (x_add, bias may be NULL; N % 4 == 0,
+ *                             ld_out >= N lets a problem fill a column slice of a wider tensor): value = value_proj(src) beside the
+ *                             sampling_offsets / attention_weights Linears of `src + pos` (ms_deform_attn.py:102-110), or k = k_proj(memory + pos)
+ *                             beside v = v_proj(memory) (mask2former_transformer_decoder.py:106-118). */
+typedef struct {
+  const float* x_add;  /* [M,K] or NULL */
+  const void* packed;  /* rba_token_linear_pack_f16x2 of the weight [N,K] */
+  const float* bias;   /* [N] or NULL */
+  float* out;
+  int N;
+  int ld_out;          /* row stride of out, in floats */
+  int act;             /* 0 none, 2 ReLU */
+} rba_token_linear_problem;
+int rba_token_linear_pack_f16x2(const float* weight, void* packed, int N, int K, void* stream);
+int rba_token_linear_f32(const float* x, const float* x_add, const void* packed, const float* bias, const float* residual,
+                         const float* ln_weight, const float* ln_bias, float ln_eps, float* out, int64_t M, int N, int K, int act,
+                         void* stream);
+int rba_token_linear_multi_f32(const float* x, const rba_token_linear_problem* problems, int n_problems, int64_t M, int K, void* stream);
 
 #ifdef __cplusplus
 }

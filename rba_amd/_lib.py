@@ -35,6 +35,7 @@ SIGNATURES = {
     "rba_swin_bias_fragments_elems": [_i, _i],
     "rba_swin_bias_fragments_f32": [_vp, _vp, _i, _i, _vp],
     "rba_skinny_linear_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "rba_skinny_linear_add_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_split_weight_bf16x3": [_vp, _vp, _i, _i, _vp],
     "rba_split_linear_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_weight_f16x2": [_vp, _vp, _i, _i, _vp],
@@ -65,9 +66,18 @@ SIGNATURES = {
     "rba_merge_layer_norm_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp],
     "rba_group_norm_workspace_bytes": [_i, _i, _i, _i],
     "rba_group_norm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp],
+    "rba_token_linear_pack_f16x2": [_vp, _vp, _i, _i, _vp],
+    "rba_token_linear_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _i64, _i, _i, _i, _vp],
+    "rba_token_linear_multi_f32": [_vp, _vp, _i, _i64, _i, _vp],
 }
 
-EXPECTED_ABI = 181        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+class TokenLinearProblem(ctypes.Structure):
+    """rba_token_linear_problem of include/rba_hip.h"""
+    _fields_ = [("x_add", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+EXPECTED_ABI = 182        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -14,7 +14,7 @@
 
 using namespace rba_k1;
 
-extern "C" int rba_hip_version(void) { return 181; }
+extern "C" int rba_hip_version(void) { return 182; }
 
 // tools / tests only: 1 = rba_reduce_up4_f32 runs the generic (round 1-2) kernel for K = 19 / 20 too, 2 = always the packed VALU kernel (no MFMA form)
 extern "C" __attribute__((visibility("default"))) int rba_k1_up4_variant = 0;
@@ -59,10 +59,12 @@ extern "C" int rba_reduce_up4_f32(const float* mask_lowres, const float* cls_pro
   hipStream_t st = (hipStream_t)stream;
   // vector stores need 16 B aligned rows; the kernel falls back to scalar stores when crop_w % 4 != 0
   RBA_CHECK_ARG((((uintptr_t)rba | (uintptr_t)sem_seg) & 15) == 0);
-  // score only, rows a multiple of four wide, at most 1 024 queries: the class contraction on the matrix pipe
-  const bool mx = rba_k1_up4_variant == 0 && !sem_seg && !argmax && (crop_w & 3) == 0 && Q <= 512 && (int64_t)(Q + 8) * h * w < (1LL << 29);
-  if (K == 19 && mx) return launch_up4_mx<19>(mask_lowres, cls_prob, rba, Q, h, w, crop_h, crop_w, st, score_mode);
-  if (K == 20 && mx) return launch_up4_mx<20>(mask_lowres, cls_prob, rba, Q, h, w, crop_h, crop_w, st, score_mode);
+  // rows a multiple of four wide, at most 512 queries: the class contraction on the matrix pipe (since round 4 also with sem_seg / argmax outputs;
+  // rba_k1_up4_variant = 3 (tools / tests): the matrix-pipe kernel for score-only calls only, the round-3 dispatch)
+  const bool mx = (rba_k1_up4_variant == 0 || (rba_k1_up4_variant == 3 && !sem_seg && !argmax)) && (crop_w & 3) == 0 && Q <= 512 &&
+                  (int64_t)(Q + 8) * h * w < (1LL << 29) && (((uintptr_t)argmax) & 15) == 0;
+  if (K == 19 && mx) return launch_up4_mx<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, h, w, crop_h, crop_w, st, score_mode);
+  if (K == 20 && mx) return launch_up4_mx<20>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, h, w, crop_h, crop_w, st, score_mode);
   if (K == 19 && rba_k1_up4_variant != 1) return launch_up4_pk<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, h, w, crop_h, crop_w, st, score_mode);
   if (K == 20 && rba_k1_up4_variant != 1) return launch_up4_pk<20>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, h, w, crop_h, crop_w, st, score_mode);
   if (K == 19) return launch_up4<19>(mask_lowres, cls_prob, rba, sem_seg, argmax, Q, K, h, w, crop_h, crop_w, st, score_mode);

@@ -605,15 +605,17 @@ typedef _Float16 up4_f16x2 __attribute__((ext_vector_type(2)));
 typedef float up4_f32x16 __attribute__((ext_vector_type(16)));
 
 // Two pairs (a0, a1), (b0, b1) -> packed f16 h and packed f16 residual l = f16(x - h): v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16 reading h's
-// halves in place.  The four mix instructions are ONE asm statement in the order lo, lo, hi, hi because of three gfx950 wait-state rules the
-// compiler enforces for instructions it emits itself and cannot enforce inside asm (it does not decode asm text):
+// halves in place.  The four mix instructions are ONE asm statement in the order lo, lo, hi, hi: hipcc enforces three gfx950 wait-state rules
+// for instructions it emits itself and cannot enforce inside asm (it does not decode asm text), so the statement satisfies them by construction:
 //  * a VALU that reads a register written by a 16-bit-destination VALU (v_fma_mixlo_f16 writes half a register; v_fma_mixhi_f16 of the SAME
-//    register reads it to keep that half) needs one wait state in between -- round 3's form issued mixlo, mixhi of one register back to
-//    back (40 of 40 sites in the emitted ISA), which is the hazard hipcc itself separates with an s_nop when it emits the pair
-//    (tools/isa_hazards.py, profiles/r04_k1_mx_soak.txt); interleaving two registers gives every mixhi its wait state for free;
+//    register reads it to keep that half) gets one wait state from hipcc -- round 3's form issued mixlo, mixhi of one register back to back
+//    (40 of 40 sites in the emitted ISA, tools/isa_hazards.py); interleaving two registers gives every mixhi its wait state for free;
 //  * a VALU that reads a fresh transcendental result (the inputs are v_rcp_f32 results of the sigmoid) needs one wait state: leading s_nop;
 //  * the consumer of the last half-written register (an MFMA operand here) needs one as well: trailing s_nop.
-// tests/test_host_cpu.py::test_emitted_isa_has_no_unfenced_16bit_destination_hazards scans every code object of the built library for these.
+// Measured (profiles/r04_k1_mx_soak.txt, profiles/r04_mix_hazard_probe.txt): the back-to-back form is NOT observably wrong on MI355X --
+// 2.3e10 pairs in tools/micro/mix_hazard.hip and 6 000 three-stream launches of round 3's build show no differing bit, same as this form --
+// so this is conformance with the compiler's own rule, not a demonstrated fix; the single run-to-run difference round 3 saw once was never
+// reproduced.  tests/test_host_cpu.py::test_emitted_isa_has_no_unfenced_16bit_destination_hazards keeps every code object of the library clean.
 __device__ __forceinline__ void up4_split_quad(float a0, float a1, float b0, float b1, uint32_t& ha, uint32_t& la, uint32_t& hb, uint32_t& lb) {
   const up4_f16x2 va = {(_Float16)a0, (_Float16)a1}, vb = {(_Float16)b0, (_Float16)b1};
   const uint32_t pa = __builtin_bit_cast(uint32_t, va), pb = __builtin_bit_cast(uint32_t, vb);
@@ -628,9 +630,14 @@ __device__ __forceinline__ void up4_split_quad(float a0, float a1, float b0, flo
   ha = pa; la = ra; hb = pb; lb = rb;
 }
 
-template <int K>
+// SEM / ARG (round 4): the accumulators hold sem[class][pixel] -- the evaluator's `return_preds=True` path (support.py:385-388) and the stock
+// get_RbA / get_logits on out[0]["sem_seg"] (evaluate_ood.py:143-150) get the same kernel: a lane stores its classes' four pixels as one
+// 16-byte piece per class (32 lanes = 512 contiguous bytes of a class row), the argmax is the first maximum in class order (torch.argmax /
+// the packed VALU kernel's rule), combined across the two lane halves with ties to the smaller class index.
+template <int K, bool SEM = false, bool ARG = false>
 __global__ __launch_bounds__(256, 3) void rba_reduce_up4_mx_kernel(const float* __restrict__ low, const float* __restrict__ prob,
-                                                                   float* __restrict__ rba, int Q, int h, int w, int crop_h, int crop_w,
+                                                                   float* __restrict__ rba, float* __restrict__ sem, int32_t* __restrict__ argmax,
+                                                                   int Q, int h, int w, int crop_h, int crop_w,
                                                                    int xtiles, int tiles, int mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char up4lds[];       // [ceil(Q / 16)][2][64] x 16 B
   const int QS = (Q + 15) >> 4;
@@ -743,20 +750,59 @@ __global__ __launch_bounds__(256, 3) void rba_reduce_up4_mx_kernel(const float* 
     part += __shfl_xor(part, 32, RBA_WAVE);
     out[r] = mode == 1 ? -(mx + logf(part)) : -part;
   }
+  const int64_t p0 = (int64_t)y * crop_w + 4 * j;
   if (kb == 0 && 4 * j < crop_w)
-    *reinterpret_cast<f32x4*>(rba + (int64_t)y * crop_w + 4 * j) = (f32x4){out[0], out[1], out[2], out[3]};   // crop_w % 4 == 0 (launcher)
+    *reinterpret_cast<f32x4*>(rba + p0) = (f32x4){out[0], out[1], out[2], out[3]};                           // crop_w % 4 == 0 (launcher)
+  if (SEM && 4 * j < crop_w) {
+    const int64_t oplane = (int64_t)crop_h * crop_w;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int cls = 8 * (i >> 2) + 4 * kb + (i & 3);
+      if (8 * (i >> 2) + (i & 3) < K && cls < K)
+        __builtin_nontemporal_store((f32x4){acc[0][i], acc[1][i], acc[2][i], acc[3][i]}, reinterpret_cast<f32x4*>(sem + (int64_t)cls * oplane + p0));
+    }
+  }
+  if (ARG) {
+    int best[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float bv = -INFINITY;
+      int b = 0x7fffffff;                                                          // a half without a valid class (K <= 4 kb) never wins
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                                               // increasing class order within this half
+        const int cls = 8 * (i >> 2) + 4 * kb + (i & 3);
+        if (8 * (i >> 2) + (i & 3) < K) {
+          const float v = acc[r][i];
+          const bool take = cls < K && (v > bv || b == 0x7fffffff);                // first valid class seeds the scan (also when it is -inf / NaN-free data)
+          bv = take ? v : bv;
+          b = take ? cls : b;
+        }
+      }
+      const float ov = __shfl_xor(bv, 32, RBA_WAVE);
+      const int ob = __shfl_xor(b, 32, RBA_WAVE);
+      best[r] = (ov > bv || (ov == bv && ob < b)) ? ob : b;
+    }
+    if (kb == 0 && 4 * j < crop_w) *reinterpret_cast<rba_u32x4*>(argmax + p0) = (rba_u32x4){(uint32_t)best[0], (uint32_t)best[1], (uint32_t)best[2], (uint32_t)best[3]};
+  }
 }
 
 template <int K>
-int launch_up4_mx(const float* low, const float* prob, float* rba, int Q, int h, int w, int crop_h, int crop_w, hipStream_t st, int mode) {
+int launch_up4_mx(const float* low, const float* prob, float* rba, float* sem, int32_t* argmax, int Q, int h, int w, int crop_h, int crop_w,
+                  hipStream_t st, int mode) {
   const int wq = crop_w / 4;
   const int xtiles = (wq + 31) / 32;
   const int64_t tiles = (int64_t)xtiles * crop_h;
   if (tiles > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   const size_t shm = (size_t)((Q + 15) / 16) * 2048;
   if (shm > 64 * 1024 || (int64_t)(Q + 8) * h * w >= (1LL << 29)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((rba_reduce_up4_mx_kernel<K>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), shm, st, low, prob, rba, Q, h, w, crop_h, crop_w,
-                     xtiles, (int)tiles, mode);
+#define RBA_L(S, A)                                                                                                                  \
+  hipLaunchKernelGGL((rba_reduce_up4_mx_kernel<K, S, A>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), shm, st, low, prob, rba, sem, argmax, Q, \
+                     h, w, crop_h, crop_w, xtiles, (int)tiles, mode)
+  if (sem && argmax) RBA_L(true, true);
+  else if (sem) RBA_L(true, false);
+  else if (argmax) RBA_L(false, true);
+  else RBA_L(false, false);
+#undef RBA_L
   return rba_launch_status();
 }
 

@@ -19,10 +19,12 @@ constexpr int SW = 8;                       // waves per workgroup = K splits
 template <int MT>
 __global__ __launch_bounds__(64 * SW) void skinny_linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ bias, float* __restrict__ out,
-                                                                int M, int N, int K, int relu) {
+                                                                int M, int N, int K, int relu, const float* __restrict__ x_add, int add_cols,
+                                                                int seg_n) {
   extern __shared__ __attribute__((aligned(16))) float red[];          // [SW][MT*16][16]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
   const int n0 = blockIdx.x * 16;
+  const bool addx = x_add != nullptr && n0 < add_cols;                  // workgroup-uniform: these 16 output columns see x + x_add
   const int nrow = n0 + l15 < N ? n0 + l15 : N - 1;                     // clamped (results of padded columns are dropped)
   const float* wrow = W + (int64_t)nrow * K + kk * 8;
   f32x4_s acc[MT];
@@ -39,6 +41,12 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_kernel(const float* __r
       const float* xr = x + (int64_t)m * K + kb * 32 + kk * 8;
       b0[t] = *reinterpret_cast<const float4*>(xr);
       b1[t] = *reinterpret_cast<const float4*>(xr + 4);
+      if (addx) {
+        const float* ar = x_add + (int64_t)m * K + kb * 32 + kk * 8;
+        const float4 c0 = *reinterpret_cast<const float4*>(ar), c1 = *reinterpret_cast<const float4*>(ar + 4);
+        b0[t] = make_float4(b0[t].x + c0.x, b0[t].y + c0.y, b0[t].z + c0.z, b0[t].w + c0.w);
+        b1[t] = make_float4(b1[t].x + c1.x, b1[t].y + c1.y, b1[t].z + c1.z, b1[t].w + c1.w);
+      }
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -60,7 +68,8 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_kernel(const float* __r
     if (m < M && n0 + n < N) {
       if (bias) sum += bias[n0 + n];
       if (relu) sum = fmaxf(sum, 0.f);
-      out[(int64_t)m * N + n0 + n] = sum;
+      const int nn = n0 + n;
+      out[seg_n ? ((int64_t)(nn / seg_n) * M + m) * seg_n + nn % seg_n : (int64_t)m * N + nn] = sum;
     }
   }
 }
@@ -72,14 +81,16 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_kernel(const float* __r
 // the launch has M/16 times the workgroups.  k blocks are assigned to waves and reduced through LDS exactly as above: bit-identical results.
 __global__ __launch_bounds__(64 * SW) void skinny_linear_tile_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                      const float* __restrict__ bias, float* __restrict__ out, int M, int N, int K,
-                                                                     int relu) {
+                                                                     int relu, const float* __restrict__ x_add, int add_cols, int seg_n) {
   __shared__ __attribute__((aligned(16))) float red[SW * 16 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kk = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const bool addx = x_add != nullptr && n0 < add_cols;
   const int nrow = n0 + l15 < N ? n0 + l15 : N - 1;
   const int mrow = m0 + l15 < M ? m0 + l15 : M - 1;
   const float* wrow = W + (int64_t)nrow * K + kk * 8;
   const float* xrow = x + (int64_t)mrow * K + kk * 8;
+  const float* arow = addx ? x_add + (int64_t)mrow * K + kk * 8 : nullptr;
   f32x4_s acc = {0.f, 0.f, 0.f, 0.f};
   const int kblocks = K / 32;
   constexpr int U = 4;
@@ -92,6 +103,11 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_tile_kernel(const float
       a[u][1] = *reinterpret_cast<const float4*>(wrow + k * 32 + 4);
       b[u][0] = *reinterpret_cast<const float4*>(xrow + k * 32);
       b[u][1] = *reinterpret_cast<const float4*>(xrow + k * 32 + 4);
+      if (addx) {
+        const float4 c0 = *reinterpret_cast<const float4*>(arow + k * 32), c1 = *reinterpret_cast<const float4*>(arow + k * 32 + 4);
+        b[u][0] = make_float4(b[u][0].x + c0.x, b[u][0].y + c0.y, b[u][0].z + c0.z, b[u][0].w + c0.w);
+        b[u][1] = make_float4(b[u][1].x + c1.x, b[u][1].y + c1.y, b[u][1].z + c1.z, b[u][1].w + c1.w);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -113,42 +129,57 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_tile_kernel(const float
     if (m0 + m < M && n0 + n < N) {
       if (bias) sum += bias[n0 + n];
       if (relu) sum = fmaxf(sum, 0.f);
-      out[(int64_t)(m0 + m) * N + n0 + n] = sum;
+      const int nn = n0 + n, mm = m0 + m;
+      out[seg_n ? ((int64_t)(nn / seg_n) * M + mm) * seg_n + nn % seg_n : (int64_t)mm * N + nn] = sum;
     }
   }
 }
 
 template <int MT>
-int launch(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int relu, hipStream_t st) {
+int launch(const float* x, const float* W, const float* bias, float* out, int M, int N, int K, int relu, hipStream_t st, const float* x_add,
+           int add_cols, int seg_n) {
   const size_t shm = (size_t)SW * MT * 16 * 16 * sizeof(float);
-  hipLaunchKernelGGL(skinny_linear_kernel<MT>, dim3((N + 15) / 16), dim3(64 * SW), shm, st, x, W, bias, out, M, N, K, relu);
+  hipLaunchKernelGGL(skinny_linear_kernel<MT>, dim3((N + 15) / 16), dim3(64 * SW), shm, st, x, W, bias, out, M, N, K, relu, x_add, add_cols, seg_n);
   return rba_launch_status();
 }
 
-}  // namespace
-
-extern "C" int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias, float* out, int M, int N, int K,
-                                     int relu, void* stream) {
+int skinny_impl(const float* x, const float* x_add, int add_cols, const float* weight, const float* bias, float* out, int M, int N, int K, int relu,
+                int seg_n, void* stream) {
   RBA_CHECK_ARG(M >= 0 && M <= 128 && N >= 0 && K >= 32 && K % 32 == 0);
   if (M == 0 || N == 0) return 0;
-  RBA_CHECK_ARG(x && weight && out && (((uintptr_t)x | (uintptr_t)weight) & 15) == 0);
+  RBA_CHECK_ARG(x && weight && out && (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)x_add) & 15) == 0);
+  RBA_CHECK_ARG(seg_n == 0 || (seg_n > 0 && N % seg_n == 0));
+  RBA_CHECK_ARG(!x_add || (add_cols >= 0 && add_cols % 16 == 0));
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
   const int mt = (M + 15) / 16;
   // the per-row-tile form where a wave of the column-block form would LOOP over k blocks (K > 256: the FFN's second Linear, 32 -> 20 us per call,
   // C5 +2 % images/s, +6 % single stream); with one k block per wave the column-block form's fewer, fatter workgroups launch faster
   if (rba_skinny_variant == 0 ? K > 32 * SW : rba_skinny_variant == 2) {
-    hipLaunchKernelGGL(skinny_linear_tile_kernel, dim3((N + 15) / 16, mt), dim3(64 * SW), 0, st, x, weight, bias, out, M, N, K, relu);
+    hipLaunchKernelGGL(skinny_linear_tile_kernel, dim3((N + 15) / 16, mt), dim3(64 * SW), 0, st, x, weight, bias, out, M, N, K, relu, x_add, add_cols,
+                       seg_n);
     return rba_launch_status();
   }
   switch (mt) {
-    case 1: return launch<1>(x, weight, bias, out, M, N, K, relu, st);
-    case 2: return launch<2>(x, weight, bias, out, M, N, K, relu, st);
-    case 3: return launch<3>(x, weight, bias, out, M, N, K, relu, st);
-    case 4: return launch<4>(x, weight, bias, out, M, N, K, relu, st);
-    case 5: return launch<5>(x, weight, bias, out, M, N, K, relu, st);
-    case 6: return launch<6>(x, weight, bias, out, M, N, K, relu, st);
-    case 7: return launch<7>(x, weight, bias, out, M, N, K, relu, st);
-    default: return launch<8>(x, weight, bias, out, M, N, K, relu, st);
+    case 1: return launch<1>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    case 2: return launch<2>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    case 3: return launch<3>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    case 4: return launch<4>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    case 5: return launch<5>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    case 6: return launch<6>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    case 7: return launch<7>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
+    default: return launch<8>(x, weight, bias, out, M, N, K, relu, st, x_add, add_cols, seg_n);
   }
+}
+
+}  // namespace
+
+extern "C" int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias, float* out, int M, int N, int K,
+                                     int relu, void* stream) {
+  return skinny_impl(x, nullptr, 0, weight, bias, out, M, N, K, relu, 0, stream);
+}
+
+extern "C" int rba_skinny_linear_add_f32(const float* x, const float* x_add, int add_cols, const float* weight, const float* bias, float* out,
+                                         int M, int N, int K, int relu, int seg_n, void* stream) {
+  return skinny_impl(x, x_add, add_cols, weight, bias, out, M, N, K, relu, seg_n, stream);
 }

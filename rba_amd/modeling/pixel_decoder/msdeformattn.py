@@ -50,10 +50,20 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index):
-        """msdeformattn.py:131-140 (dropout = identity)."""
-        src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index)
-        _, src = ops.add_layer_norm(src, self.norm1.weight, self.norm1.bias, self.norm1.eps, src2.contiguous())
-        src2 = ops.linear(ops.linear(src, self.linear1, relu=True), self.linear2, use_bias=False)   # bf16x6 (K6) when the level set is large
+        """msdeformattn.py:131-140 (dropout = identity).  Round 4: `src + pos`, value_proj and the sampling Linears are one launch, the output
+        projection carries `norm1(src + .)` and linear2 carries `norm2(src + .)` in their epilogues (csrc/token_linear.hip): 5 launches per
+        layer where round 3 had 9, none of them a library GEMM."""
+        src = self.self_attn(src, reference_points, src, spatial_shapes, level_start_index, query_pos=pos, post=(src, self.norm1))
+        hid = ops.linear(src, self.linear1, relu=True)                        # N = d_ffn: K6
+        N2, K2 = self.linear2.weight.shape
+        if ops.token_linear_pays(hid.numel() // K2, N2, K2):
+            if K2 <= 512:
+                return ops.token_linear(hid, self.linear2, residual=src, norm=self.norm2)
+            # long K: a workgroup that owned whole rows would stream the entire 1 MiB weight through one CU's L1 (20 us against 16 for the
+            # library path) -- column-split launch + the add-LayerNorm kernel (csrc/token_linear.hip, "column groups")
+            src2 = ops.token_linear(hid, self.linear2, use_bias=False)
+        else:
+            src2 = ops.linear(hid, self.linear2, use_bias=False)
         return ops.add_layer_norm(src, self.norm2.weight, self.norm2.bias, self.norm2.eps, src2, self.linear2.bias)[1]
 
 
@@ -81,21 +91,32 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             (d_model, dim_feedforward, num_feature_levels, nhead, enc_n_points), num_encoder_layers)
         self.level_embed = nn.Parameter(torch.zeros(num_feature_levels, d_model))
         self._ref_cache = ShapeCache(8)
+        self._pos_cache = ShapeCache(8)
 
-    def forward(self, srcs, pos_embeds):
-        """msdeformattn.py:70-98; returns (memory [B,S,C], shapes list, level_start list)."""
+    def forward(self, srcs, pos_embeds, tokens=None):
+        """msdeformattn.py:70-98; returns (memory [B,S,C], shapes list, level_start list).  tokens: the levels as [B, h*w, C] token tensors
+        when the caller has them (channels-last pixel decoder): no flatten / transpose copies."""
         dev = srcs[0].device
         shapes = [tuple(int(v) for v in s.shape[-2:]) for s in srcs]
-        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
-                         for l, p in enumerate(pos_embeds)], 1)
+        B = srcs[0].shape[0]
+        if tokens is not None:
+            src = tokens[0].contiguous() if len(tokens) == 1 else torch.cat(tokens, 1)
+        else:
+            src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+
+        def build_pos():                # pos + level_embed depends on the shapes and on one parameter: built once per (shapes, batch, version)
+            p_ = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
+            return p_.expand(B, -1, -1).contiguous()
+
+        le = self.level_embed
+        pos = self._pos_cache.get((tuple(shapes), B, dev, le.data_ptr(), le._version), build_pos)
+
         def build():
             sh_ = torch.as_tensor(shapes, dtype=torch.long, device=dev)
             lsi_ = torch.cat((sh_.new_zeros((1,)), sh_.prod(1).cumsum(0)[:-1]))
             return sh_, lsi_, MSDeformAttnTransformerEncoder.get_reference_points(shapes, dev)
 
         sh, lsi, ref = self._ref_cache.get((tuple(shapes), dev), build)
-        B = src.shape[0]
         if B > 1:
             ref = ref.expand(B, -1, -1, -1).contiguous()
         out = src
@@ -151,6 +172,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
     def _conv1x1(self, tok, mod, use_bias=True):
         """1x1 convolution of `mod` (weight [N,C,1,1]) on tokens [B,P,C] -> [B,P,N]."""
         lin = self._cached(mod, "_rba_lin", lambda: _LinearView(mod.weight.view(mod.weight.shape[0], -1), mod.bias))
+        N, K = lin.weight.shape
+        M = tok.numel() // K
+        if not ops.split_linear_pays(M, N, K) and ops.token_linear_pays(M, N, K) and tok.is_contiguous():
+            return ops.token_linear(tok, lin, use_bias=use_bias)              # the 2 048-token input projection of res5: was a library GEMM
         return ops.linear(tok, lin, use_bias=use_bias)
 
     def _channels_last_ok(self, features):
@@ -161,18 +186,20 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return all(self._tokens(features[f]) is not None and features[f].shape[1] % 32 == 0 for f in need)
 
     def _forward_features_channels_last(self, features):
-        srcs, pos = [], []
+        srcs, pos, tks = [], [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
             x = features[f]
             B, _, h, w = x.shape
             conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
             y = ops.group_norm_nhwc(self._conv1x1(self._tokens(x), conv), 32, gn.weight, gn.bias, gn.eps)
+            tks.append(y.view(B, h * w, -1))
             srcs.append(y.view(B, h, w, -1).permute(0, 3, 1, 2))
             pos.append(self.pe_layer(x))
-        y, shapes = self.transformer(srcs, pos)
+        y, shapes = self.transformer(srcs, pos, tokens=tks)
         B, d = y.shape[0], y.shape[2]
         toks = [z.contiguous() for z in torch.split(y, [h * w for h, w in shapes], dim=1)]
-        outs = [z.view(B, h, w, d).permute(0, 3, 1, 2).contiguous() for z, (h, w) in zip(toks, shapes)]
+        # multi-scale features for the masked decoder: channels-last VIEWS of the token tensors (the decoder reads them as tokens again)
+        outs = [z.view(B, h, w, d).permute(0, 3, 1, 2) for z, (h, w) in zip(toks, shapes)]
         prev, (ph, pw) = toks[-1], shapes[-1]
         prev_norm = None                                   # (mr [B, G, 2], module) once `prev` is a raw convolution output awaiting GroupNorm + ReLU
         fold = self.fold_group_norm

@@ -45,9 +45,56 @@ class MSDeformAttn(nn.Module):
             self._rba_sampling = cache
         return cache[1]
 
+    def _sampling_parts(self):
+        """the stacked sampling Linear cut into row chunks of <= 256 outputs for the row-complete token kernel: [(linear view, first column)]"""
+        lin = self._sampling_linear()
+        parts = getattr(lin, "parts", None)
+        if parts is None:
+            from types import SimpleNamespace
+            n = lin.weight.shape[0]
+            parts = lin.parts = [(SimpleNamespace(weight=lin.weight[c:c + 256], bias=lin.bias[c:c + 256]), c) for c in range(0, n, 256)]
+        return parts
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
-        """query [N,Lq,C]; reference_points [N,Lq,L,2] in [0,1]; input_flatten [N,S,C] -> [N,Lq,C]."""
+                input_padding_mask=None, query_pos=None, post=None):
+        """query [N,Lq,C]; reference_points [N,Lq,L,2] in [0,1]; input_flatten [N,S,C] -> [N,Lq,C].
+        query_pos: the attention runs on ``query + query_pos`` (the encoder's `self.with_pos_embed(src, pos)`, msdeformattn.py:133) -- handed
+        over separately so that the add happens inside the Linear that consumes it.  post = (residual, LayerNorm): return
+        ``norm(residual + output)`` (msdeformattn.py:134-135), in the output projection's epilogue where the row-complete kernel applies."""
+        N, Lq, _ = query.shape
+        S = input_flatten.shape[1]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        if reference_points.shape[-1] != 2:
+            raise ValueError(f"Last dim of reference_points must be 2 on this path, got {reference_points.shape[-1]}")
+        C = self.d_model
+        fused = ops.msda_fused_ok(C // M, L, P, S, M) and input_padding_mask is None
+        parts = self._sampling_parts()
+        tok = (fused and query is input_flatten and len(parts) <= 2 and query.is_contiguous() and ops.token_linear_pays(N * S, C, C)
+               and all(ops.token_linear_pays(N * Lq, pl.weight.shape[0], C) for pl, _ in parts)
+               and (query_pos is None or (query_pos.is_contiguous() and tuple(query_pos.shape) == tuple(query.shape))))
+        if tok:
+            # value = value_proj(src) and the sampling Linears of src + pos: ONE launch (was: an add and two GEMMs)
+            raw = torch.empty((N, Lq, M * L * P * 3), dtype=torch.float32, device=query.device)
+            outs = ops.token_linear_multi(query, [(self.value_proj, None, None, 0, False)] + [(pl, query_pos, raw, c0, False) for pl, c0 in parts])
+            out = ops.msda_fused(outs[0].view(N, S, M, C // M), input_spatial_shapes, input_level_start_index, raw, reference_points.contiguous(),
+                                 M, L, P)
+            if post is not None and ops.token_linear_pays(N * Lq, C, C):
+                return ops.token_linear(out, self.output_proj, residual=post[0].contiguous(), norm=post[1])
+            return self._finish(ops.linear(out, self.output_proj), post)
+        if query_pos is not None:
+            query = query + query_pos
+        return self._finish(self._forward_general(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                                                  input_padding_mask), post)
+
+    @staticmethod
+    def _finish(y, post):
+        if post is None:
+            return y
+        res, norm = post
+        return ops.add_layer_norm(res, norm.weight, norm.bias, norm.eps, y.contiguous())[1]
+
+    def _forward_general(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                         input_padding_mask=None):
         N, Lq, _ = query.shape
         S = input_flatten.shape[1]
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -55,8 +102,6 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, self.d_model // M)
-        if reference_points.shape[-1] != 2:
-            raise ValueError(f"Last dim of reference_points must be 2 on this path, got {reference_points.shape[-1]}")
         # sampling_offsets and attention_weights as ONE Linear (rows [offsets | logits]), then one kernel for
         # loc = reference + offset / (W_l, H_l) and the softmax over the L*P logits (reference :95-115)
         raw = ops.linear(query, self._sampling_linear())

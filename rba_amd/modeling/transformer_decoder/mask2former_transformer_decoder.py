@@ -16,11 +16,12 @@ from ...registry import TRANSFORMER_DECODER_REGISTRY
 from .position_encoding import PositionEmbeddingSine
 
 
-def _qlinear(x, weight, bias=None, relu=False):
-    """Linear layer on the query tensor [B, Q, C] (<= 128 rows): the skinny MFMA kernel; anything larger -> library GEMM."""
+def _qlinear(x, weight, bias=None, relu=False, x_add=None):
+    """Linear layer on the query tensor [B, Q, C] (<= 128 rows): the skinny MFMA kernel; anything larger -> library GEMM.
+    x_add: the Linear runs on x + x_add (the query position embedding), added inside the kernel."""
     if x.numel() // x.shape[-1] <= 128 and x.shape[-1] % 32 == 0:
-        return ops.skinny_linear(x.contiguous(), weight, bias, relu)
-    y = F.linear(x, weight, bias)
+        return ops.skinny_linear(x.contiguous(), weight, bias, relu, x_add=None if x_add is None else x_add.contiguous())
+    y = F.linear(x if x_add is None else x + x_add, weight, bias)
     return F.relu(y) if relu else y
 
 
@@ -34,13 +35,42 @@ class _MHAParams(nn.Module):
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
         self.out_proj = nn.Linear(d_model, d_model)
 
-    def forward(self, query, key, value, mask_logits=None):
-        """batch-first: query [B,Q,E], key/value [B,S,E]; mask_logits [B,Q,S] (blocked iff sigmoid < 0.5)."""
+    def _kv_views(self):
+        """the key / value rows of in_proj as Linear views (their packed weight images are cached on the views)"""
+        w, b = self.in_proj_weight, self.in_proj_bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        c = getattr(self, "_rba_kv", None)
+        if c is None or c[0] != key:
+            from types import SimpleNamespace
+            E = self.embed_dim
+            c = self._rba_kv = (key, SimpleNamespace(weight=w[E:2 * E], bias=b[E:2 * E]), SimpleNamespace(weight=w[2 * E:], bias=b[2 * E:]))
+        return c[1], c[2]
+
+    def forward(self, query, key, value, mask_logits=None, key_add=None, query_add=None):
+        """batch-first: query [B,Q,E], key/value [B,S,E]; mask_logits [B,Q,S] (blocked iff sigmoid < 0.5).  key_add / query_add: the keys /
+        queries are ``key + key_add`` / ``query + query_add`` (position embeddings, :48-58, :106-118), added inside the projections."""
         E, nH = self.embed_dim, self.num_heads
         B, Q, _ = query.shape
         S = key.shape[1]
         w, b = self.in_proj_weight, self.in_proj_bias
-        q = _qlinear(query, w[:E], b[:E]).view(B, Q, nH, E // nH)
+        if (query is key and key is value and key_add is query_add and B * Q <= 128 and E % 32 == 0 and E % 16 == 0
+                and w.is_contiguous() and query.is_contiguous()):
+            # self-attention: q = W_q (tgt + pos), k = W_k (tgt + pos), v = W_v tgt -- ONE launch over the stacked in_proj weight (was: an add
+            # and three launches); q, k, v come back separately contiguous
+            q, k, v = ops.skinny_linear(query, w, b, x_add=None if query_add is None else query_add.contiguous(), add_cols=2 * E, segments=3)
+            o = ops.masked_xattn(q.view(B, Q, nH, E // nH), k.view(B, S, nH, E // nH), v.view(B, S, nH, E // nH), mask_logits)
+            return _qlinear(o, self.out_proj.weight)
+        q = _qlinear(query, w[:E], b[:E], x_add=query_add).view(B, Q, nH, E // nH)
+        if (key is value and B * S > 128 and key.is_contiguous() and ops.token_linear_pays(B * S, E, E)
+                and (key_add is None or (key_add.is_contiguous() and tuple(key_add.shape) == tuple(key.shape)))):
+            # cross-attention: k = W_k (memory + pos) + b_k and v = W_v memory + b_v in ONE launch of the row-complete kernel (was: an add and two
+            # library GEMMs per layer)
+            lk, lv = self._kv_views()
+            k, v = ops.token_linear_multi(key, [(lk, key_add, None, 0, False), (lv, None, None, 0, False)])
+            o = ops.masked_xattn(q, k.view(B, S, nH, E // nH), v.view(B, S, nH, E // nH), mask_logits)
+            return _qlinear(o, self.out_proj.weight)
+        if key_add is not None:
+            key = key + key_add
         # self-attention: key / value are the (<= 128) queries themselves -> the skinny kernel too (hipBLASLt takes 33 us for
         # 100 x 256 x 256); cross-attention: thousands of memory tokens -> library GEMM
         k = _qlinear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
@@ -56,8 +86,8 @@ class SelfAttentionLayer(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, tgt, query_pos):
-        qk = tgt + query_pos
-        t2 = self.self_attn(qk, qk, tgt)
+        tgt = tgt.contiguous()
+        t2 = self.self_attn(tgt, tgt, tgt, key_add=query_pos, query_add=query_pos)      # q = k = tgt + query_pos, v = tgt
         return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
                                   self.self_attn.out_proj.bias)[1]          # forward_post :48-58
 
@@ -68,9 +98,8 @@ class CrossAttentionLayer(nn.Module):
         self.multihead_attn = _MHAParams(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
 
-    def forward(self, tgt, memory, mask_logits, pos, query_pos, memory_pos=None):
-        """``memory_pos`` = memory + pos when the caller has it (it is the same tensor for every layer that attends to a level)"""
-        t2 = self.multihead_attn(tgt + query_pos, memory + pos if memory_pos is None else memory_pos, memory, mask_logits)
+    def forward(self, tgt, memory, mask_logits, pos, query_pos):
+        t2 = self.multihead_attn(tgt, memory, memory, mask_logits, key_add=pos, query_add=query_pos)
         return ops.add_layer_norm(tgt.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps, t2,
                                   self.multihead_attn.out_proj.bias)[1]     # forward_post :106-118
 
@@ -201,17 +230,25 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             attn_logits = ops.resample_bilinear(outputs_mask, attn_mask_target_size).flatten(2)
         return outputs_class, outputs_mask, attn_logits
 
+    def _level_pos(self, x, B):
+        """sine position embedding of a level as tokens [B, S, C] (contiguous: it is the key projection's `x_add` operand), per (shape, batch)"""
+        cache = self.__dict__.setdefault("_pos_tok_cache", ShapeCache(8))
+        key = (tuple(x.shape[-2:]), B, x.device)
+        return cache.get(key, lambda: self.pe_layer(x).flatten(2).transpose(1, 2).expand(B, -1, -1).contiguous())
+
     def forward(self, x, mask_features, mask=None):
         """x: list of [B,C,h_l,w_l]; mask_features [B,md,H/4,W/4] -> dict(pred_logits, pred_masks, aux_outputs)
         (reference :398-470)."""
         assert len(x) == self.num_feature_levels
         del mask
         src, pos, size_list = [], [], []
+        B = x[0].shape[0]
         for i in range(self.num_feature_levels):
             size_list.append(tuple(int(v) for v in x[i].shape[-2:]))
-            pos.append(self.pe_layer(x[i]).flatten(2).transpose(1, 2))                      # [1,S,C]
-            src.append((x[i].flatten(2) + self.level_embed.weight[i][None, :, None]).transpose(1, 2).contiguous())
-        B = src[0].shape[0]
+            pos.append(self._level_pos(x[i], B))                                              # [B,S,C], cached per shape
+            t = x[i].permute(0, 2, 3, 1)                                                      # channels-last views (pixel decoder): tokens without a copy
+            tok = t.reshape(B, -1, x[i].shape[1]) if t.is_contiguous() else x[i].flatten(2).transpose(1, 2)
+            src.append(tok + self.level_embed.weight[i])                                      # [B,S,C] contiguous (:424-426)
         query_embed = self.query_embed.weight[None].expand(B, -1, -1)
         output = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
         mask_features = mask_features.contiguous()
@@ -221,11 +258,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                                                               need_masks=self.num_layers == 0, gathered=gathered)
         predictions_class.append(cls)
         predictions_mask.append(msk)
-        # memory + pos is the key input of every cross-attention layer of a level: one add per level instead of one per layer
-        kin = [src[l] + pos[l] for l in range(min(self.num_feature_levels, self.num_layers))]
         for i in range(self.num_layers):
             li = i % self.num_feature_levels
-            output = self.transformer_cross_attention_layers[i](output, src[li], attn_logits, pos[li], query_embed, memory_pos=kin[li])
+            output = self.transformer_cross_attention_layers[i](output, src[li], attn_logits, pos[li], query_embed)   # memory + pos: inside the key projection
             output = self.transformer_self_attention_layers[i](output, query_embed)
             output = self.transformer_ffn_layers[i](output)
             last = i == self.num_layers - 1

@@ -6,6 +6,7 @@ AT_ASSERTM on contiguity and device -> RuntimeError): a bad argument raises Runt
 no fallback path.
 """
 import contextlib
+import ctypes
 import functools
 import os
 
@@ -411,8 +412,11 @@ def merge_layer_norm(x, H, W, weight, bias, eps=1e-5):
 
 
 @_hip_op
-def skinny_linear(x, weight, bias=None, relu=False):
-    """F.linear(x, weight, bias) [+ ReLU] for x with at most 128 rows (the decoder's 100 queries): [..., K] -> [..., N]."""
+def skinny_linear(x, weight, bias=None, relu=False, x_add=None, add_cols=None, segments=1):
+    """F.linear(x, weight, bias) [+ ReLU] for x with at most 128 rows (the decoder's 100 queries): [..., K] -> [..., N].
+    x_add: output columns n < add_cols (default: all; a multiple of 16) are computed from ``x + x_add`` -- the query position embedding of
+    mask2former_transformer_decoder.py:48-58, 106-118 added inside the projection.  segments = s > 1: the N outputs are returned as s
+    separately contiguous tensors [..., N / s] (q, k, v of a stacked in_proj weight) written by the one launch."""
     lib = _lib.load()
     _chk(x, "x")
     _chk(weight, "weight", dim=2)
@@ -425,10 +429,26 @@ def skinny_linear(x, weight, bias=None, relu=False):
         _chk(bias, "bias", dim=1)
         if bias.numel() != N:
             raise RbaHipError("bias must have N elements")
-    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.rba_skinny_linear_f32(_p(x), _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), _stream()),
-               "rba_skinny_linear_f32")
-    return out
+    segments = int(segments)
+    if segments < 1 or N % segments:
+        raise RbaHipError("segments must divide N")
+    if x_add is None and segments == 1:
+        out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+        _lib.check(lib.rba_skinny_linear_f32(_p(x), _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), _stream()),
+                   "rba_skinny_linear_f32")
+        return out
+    if x_add is not None:
+        _chk(x_add, "x_add")
+        if tuple(x_add.shape) != tuple(x.shape):
+            raise RbaHipError("x_add must have x's shape")
+    add_cols = N if add_cols is None else int(add_cols)
+    if add_cols % 16 or not 0 <= add_cols <= N:
+        raise RbaHipError("add_cols must be a multiple of 16 in [0, N]")
+    seg_n = N // segments
+    out = torch.empty((segments,) + tuple(x.shape[:-1]) + (seg_n,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_skinny_linear_add_f32(_p(x), _p(x_add), add_cols, _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)),
+                                             seg_n if segments > 1 else 0, _stream()), "rba_skinny_linear_add_f32")
+    return out[0] if segments == 1 else tuple(out[i] for i in range(segments))
 
 
 class SplitActivations:
@@ -777,6 +797,115 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     fn, name = ((lib.rba_conv3x3_nhwc_f16x3_f32, "rba_conv3x3_nhwc_f16x3_f32") if f16 else (lib.rba_conv3x3_nhwc_f32, "rba_conv3x3_nhwc_f32"))
     _lib.check(fn(_p(x), _p(planes), _p(bias), _p(out), B, H, W, C, N, _stream()), name)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- small token Linears
+TOKEN_LINEAR = os.environ.get("RBA_TOKEN_LINEAR", "1") != "0"      # A/B switch (tools): 0 sends the small Linears back to hipBLASLt + separate kernels
+
+
+def token_linear_ok(N, K):
+    """Shapes the row-complete token Linear serves (csrc/token_linear.hip): N <= 256 outputs, K a multiple of 32; f16x3 arithmetic only
+    (ops.SPLIT_MODE == "bf16x6", the full-range fallback, keeps the library GEMM)."""
+    return TOKEN_LINEAR and SPLIT_MODE == "f16x3" and 1 <= N <= 256 and K >= 32 and K % 32 == 0
+
+
+TOKEN_MAX_ROWS = 8192      # beyond that a 128 x 128-tiled GEMM re-reads the weight far less often than one workgroup per 16 rows does
+
+
+def token_linear_pays(M, N, K):
+    """True when the row-complete kernel is the launch to use for an [M, K] x [N, K]^T Linear: the encoder / decoder-memory token counts of one
+    image (2 048 at C2, 4 830 at C5) -- its callers then also fold `+ pos`, sibling Linears and the post-norm residual step into the launch."""
+    return token_linear_ok(N, K) and N % 4 == 0 and 1 <= M <= TOKEN_MAX_ROWS
+
+
+def _token_planes(lin):
+    """fragment-ordered f16 (h, l) image of lin.weight, packed once per weight load and cached on the module"""
+    w = lin.weight
+    key = (w.data_ptr(), w._version, w.device)
+    cache = getattr(lin, "_rba_token_planes", None)
+    if cache is None or cache[0] != key:
+        lib = _lib.load()
+        w2 = w.detach().contiguous()
+        _chk(w2, "weight", dim=2)
+        N, K = w2.shape
+        packed = torch.empty((((N + 15) // 16) * (K // 32) * 128, 4), dtype=torch.int32, device=w.device)
+        _lib.check(lib.rba_token_linear_pack_f16x2(_p(w2), _p(packed), N, K, _stream()), "rba_token_linear_pack_f16x2")
+        cache = (key, packed)
+        try:
+            lin._rba_token_planes = cache
+        except AttributeError:                      # objects with __slots__ (none today): no caching
+            pass
+    return cache[1]
+
+
+@_hip_op
+def token_linear(x, lin, x_add=None, use_bias=True, relu=False, residual=None, norm=None):
+    """``F.linear(x + x_add, lin.weight, lin.bias)`` [+ ReLU] on a token tensor [..., K] with N <= 256 outputs, as one launch of the
+    row-complete kernel; with ``residual`` and ``norm`` (an nn.LayerNorm over N): ``norm(residual + F.linear(x, W, b))`` -- the post-norm
+    residual step of an encoder layer (msdeformattn.py:134-138) in the GEMM's epilogue.  Check token_linear_ok(N, K) first."""
+    lib = _lib.load()
+    _chk(x, "x")
+    N, K = lin.weight.shape
+    if x.shape[-1] != K or not token_linear_ok(N, K):
+        raise RbaHipError("token_linear: x [..., K] with K % 32 == 0, N <= 256 and the f16x3 mode (see token_linear_ok)")
+    M = x.numel() // K
+    if x_add is not None:
+        _chk(x_add, "x_add")
+        if tuple(x_add.shape) != tuple(x.shape):
+            raise RbaHipError("x_add must have x's shape")
+    bias = lin.bias if use_bias else None
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    if (residual is None) != (norm is None):
+        raise RbaHipError("token_linear: residual and norm come together")
+    if norm is not None:
+        _chk(residual, "residual")
+        if tuple(residual.shape) != tuple(out.shape) or N % 16 or relu or norm.weight.numel() != N:
+            raise RbaHipError("token_linear(norm=...): residual [..., N], N % 16 == 0, no activation")
+        _lib.check(lib.rba_token_linear_f32(_p(x), _p(x_add), _p(_token_planes(lin)), _p(bias), _p(residual), _p(norm.weight), _p(norm.bias),
+                                            float(norm.eps), _p(out), M, N, K, 0, _stream()), "rba_token_linear_f32")
+        return out
+    _lib.check(lib.rba_token_linear_f32(_p(x), _p(x_add), _p(_token_planes(lin)), _p(bias), None, None, None, 0.0, _p(out), M, N, K,
+                                        2 if relu else 0, _stream()), "rba_token_linear_f32")
+    return out
+
+
+@_hip_op
+def token_linear_multi(x, specs):
+    """Up to three Linears over the same rows in ONE launch.  specs: [(lin, x_add | None, out | None, col0, relu), ...]; problem i computes
+    F.linear(x + x_add_i, W_i, b_i) [ReLU] and writes it into out_i[..., col0 : col0 + N_i] (out_i = a fresh [..., N_i] tensor when None; several
+    problems may fill column slices of one wider tensor).  Returns the list of output tensors.  Check token_linear_ok(N_i, K) first."""
+    lib = _lib.load()
+    _chk(x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K if K else 0
+    if not 1 <= len(specs) <= 3:
+        raise RbaHipError("token_linear_multi: one to three problems")
+    arr = (_lib.TokenLinearProblem * len(specs))()
+    outs, keep = [], []
+    for i, (lin, x_add, out, col0, relu) in enumerate(specs):
+        N, K_ = lin.weight.shape
+        if K_ != K or not token_linear_ok(N, K) or N % 4:
+            raise RbaHipError("token_linear_multi: weights [N <= 256, N % 4 == 0, K] with x's K % 32 == 0 (see token_linear_ok)")
+        if x_add is not None:
+            _chk(x_add, "x_add")
+            if tuple(x_add.shape) != tuple(x.shape):
+                raise RbaHipError("x_add must have x's shape")
+        if out is None:
+            out, col0 = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device), 0
+        else:
+            _chk(out, "out")
+            if tuple(out.shape[:-1]) != tuple(x.shape[:-1]) or col0 % 4 or col0 + N > out.shape[-1] or out.shape[-1] % 4:
+                raise RbaHipError("token_linear_multi: out [..., ld] with ld % 4 == 0 and a column slice col0 % 4 == 0 inside it")
+        if lin.bias is not None:
+            _chk(lin.bias, "bias", dim=1)
+        planes = _token_planes(lin)
+        keep.append(planes)
+        arr[i] = _lib.TokenLinearProblem(_p(x_add) or None, _p(planes), _p(lin.bias) or None, out.data_ptr() + 4 * col0, N, out.shape[-1], 2 if relu else 0)
+        outs.append(out)
+    _lib.check(lib.rba_token_linear_multi_f32(_p(x), ctypes.byref(arr), len(specs), M, K, _stream()), "rba_token_linear_multi_f32")
+    return outs
 
 
 @_hip_op

@@ -151,6 +151,18 @@ def test_k1_up4_matrix_pipe_form(ops, Q, K, h, w, ch, cw):
         tol = 6e-5 if score == "neg_logit_sum" else 2e-5                        # a plain sum of K values of magnitude ~3: fp32 round-off of the sum itself
         assert maxerr(got, want[score]) < tol, score
         assert maxerr(got, pk.cpu()) < tol, score
+    # round 4: the same kernel with sem_seg and argmax outputs (the evaluator's return_preds path, the stock get_RbA on out["sem_seg"])
+    rba0 = ops.rba_reduce_up4(dev(low), dev(prob), (ch, cw))[0]
+    for ws_, wa_ in ((True, True), (True, False), (False, True)):
+        rba, sem, arg = ops.rba_reduce_up4(dev(low), dev(prob), (ch, cw), ws_, wa_)
+        assert torch.equal(rba, rba0)                                           # the score does not depend on which outputs are written
+        if ws_:
+            assert sem.shape == (K, ch, cw) and maxerr(sem, sem_r) < 1e-5
+            assert maxerr(-sem.tanh().sum(0), want["rba"]) < 2e-5               # the reference's get_RbA on the dict's sem_seg
+        if wa_:
+            assert arg.dtype == torch.int32 and argmax_ok(arg, sem_r)[0] == 0   # no flip outside the reference's own near-ties
+            if ws_:
+                assert torch.equal(sem.gather(0, arg.long()[None])[0], sem.max(0).values)     # a maximum of the kernel's own sem_seg
 
 
 def test_k1_up4_matrix_pipe_form_full_size_is_stable(ops):
@@ -176,8 +188,7 @@ def test_k1_up4_matrix_pipe_form_full_size_is_stable(ops):
 def test_k1_up4_matrix_pipe_form_soak(ops):
     """2 000 launches of the score-only fused K1 at C2's and C5's maps, round-robin from three streams while a fourth
     stream runs a K6 GEMM loop; every output bit-equal to launch 0 of its map (tools/k1_soak.py reports the pixel pattern otherwise).
-    Round 3's build fails this test (tools/ab, profiles/r04_k1_mx_soak.txt): its v_fma_mixlo_f16 / v_fma_mixhi_f16 pairs were issued back
-    to back, without the wait state a 16-bit-destination write needs before the same register is read."""
+    profiles/r04_k1_mx_soak.txt: 6 000 launches + 600 graph-replayed forwards, no differing bit (round 3's build included)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -439,6 +450,32 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
     assert torch.equal(old, out) and torch.equal(new, out)
 
 
+@pytest.mark.parametrize("M,E,K", [(100, 256, 256), (100, 64, 2048), (37, 32, 64), (128, 256, 256)])
+def test_skinny_linear_position_add_and_segments(ops, M, E, K):
+    """the q / k / v projections of a decoder self-attention layer as ONE launch over the stacked in_proj weight: columns < 2E see x + x_add,
+    the rest x; three separately contiguous outputs -- each bit-equal to its own launch on the separately added input (the add is the same
+    fp32 add, the k blocks are reduced in the same order), in both decompositions"""
+    import ctypes
+    from rba_amd import _lib
+    g = torch.Generator().manual_seed(M + E + K)
+    x, pos = dev(torch.randn(1, M, K, generator=g)), dev(torch.randn(1, M, K, generator=g))
+    w, b = dev(torch.randn(3 * E, K, generator=g) * K ** -0.5), dev(torch.randn(3 * E, generator=g))
+    var = ctypes.c_int.in_dll(_lib.load(), "rba_skinny_variant")
+    try:
+        for v_ in (0, 1, 2):
+            var.value = v_
+            q, k, v = ops.skinny_linear(x, w, b, x_add=pos, add_cols=2 * E, segments=3)
+            xp = x + pos
+            assert q.shape == (1, M, E) and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+            assert torch.equal(q, ops.skinny_linear(xp, w[:E].contiguous(), b[:E].contiguous()))
+            assert torch.equal(k, ops.skinny_linear(xp, w[E:2 * E].contiguous(), b[E:2 * E].contiguous()))
+            assert torch.equal(v, ops.skinny_linear(x, w[2 * E:].contiguous(), b[2 * E:].contiguous()))
+            assert torch.equal(ops.skinny_linear(x, w, b, x_add=pos), ops.skinny_linear(xp, w, b))              # every column, one output
+            assert torch.equal(ops.skinny_linear(x, w, b, relu=True, x_add=pos, add_cols=0), ops.skinny_linear(x, w, b, relu=True))
+    finally:
+        var.value = 0
+
+
 # ----------------------------------------------------------------------------------- bf16x6 (split-bf16) linear
 @pytest.mark.parametrize("M,N,K,gelu,has_bias", [(128, 128, 32, False, True), (1000, 256, 128, False, True), (777, 128, 256, True, True),
                                                  (4096, 384, 512, False, False), (130, 256, 1024, True, True), (1, 128, 64, False, True),
@@ -480,6 +517,83 @@ def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias, mode):
         assert maxerr(out, ref) < 2.0 * maxerr(fp32, ref) + 1e-6, "not worse than the fp32 GEMM it replaces"
     out3 = ops.split_linear(dev(x.view(1, M, K)), planes, dev(b) if has_bias else None, gelu=gelu, out_features=N)
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
+
+
+@pytest.mark.parametrize("M,N,K,relu,has_bias,has_add", [(2048, 256, 256, False, True, True), (2048, 96, 256, False, True, True), (2048, 256, 1024, False, True, False),
+                                                         (4830, 256, 256, True, True, False), (4830, 32, 256, False, False, True), (37, 192, 64, False, True, True),
+                                                         (1, 16, 32, False, True, False), (2048, 100, 96, True, True, False), (301, 256, 160, False, False, False)])
+def test_token_linear_vs_fp64(ops, M, N, K, relu, has_bias, has_add):
+    """Row-complete token Linear (csrc/token_linear.hip): act((x + x_add) W^T + b) against fp64 at the level of the fp32 GEMM it replaces,
+    ragged M (rows per workgroup = 16), N not a multiple of 16, odd block counts; x_add is added exactly as the separate torch add did."""
+    from types import SimpleNamespace
+    from rba_amd._lib import RbaHipError
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) if has_bias else None
+    xa = torch.randn(M, K, generator=g) if has_add else None
+    xin = x + xa if has_add else x
+    ref = F.linear(xin.double(), w.double(), b.double() if has_bias else None)
+    ref = F.relu(ref) if relu else ref
+    lin = SimpleNamespace(weight=dev(w), bias=dev(b) if has_bias else None)
+    assert ops.token_linear_ok(N, K) and ops.token_linear_pays(M, N, K)
+    out = ops.token_linear(dev(x), lin, x_add=dev(xa) if has_add else None, relu=relu)
+    fp32 = F.linear(dev(xin), dev(w), dev(b) if has_bias else None)
+    fp32 = F.relu(fp32) if relu else fp32
+    tol = 2e-5 * (K / 256) ** 0.5 + 2e-6
+    assert out.shape == (M, N) and maxerr(out, ref) < tol
+    assert maxerr(out, ref) < 2.0 * maxerr(fp32, ref) + 1e-6, "not worse than the fp32 GEMM it replaces"
+    assert torch.equal(ops.token_linear(dev(x).view(1, M, K), lin, x_add=dev(xa).view(1, M, K) if has_add else None, relu=relu)[0], out)
+    with pytest.raises(RbaHipError):
+        ops.token_linear(dev(x)[:, : K - 1], lin)                          # K mismatch / non-contiguous
+    with pytest.raises(RbaHipError):
+        ops.token_linear(dev(x), SimpleNamespace(weight=dev(torch.zeros(272, K)), bias=None))     # N > 256
+
+
+@pytest.mark.parametrize("M,C,K", [(2048, 256, 256), (2048, 256, 1024), (4830, 256, 256), (50, 64, 128), (999, 128, 96)])
+def test_token_linear_residual_layer_norm(ops, M, C, K):
+    """norm(residual + Linear(x)) in the Linear's epilogue (msdeformattn.py:134-138): against fp64, and against the unfused composition
+    (the same Linear, then rba_add_layer_norm_f32) at fp32 round-off"""
+    from types import SimpleNamespace
+    from rba_amd._lib import RbaHipError
+    g = torch.Generator().manual_seed(M + C + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(C, K, generator=g) * K ** -0.5, torch.randn(C, generator=g)
+    res = torch.randn(M, C, generator=g) * 3
+    norm = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(C, generator=g))
+    ref = F.layer_norm(res.double() + F.linear(x.double(), w.double(), b.double()), (C,), norm.weight.double(), norm.bias.double(), norm.eps)
+    lin = SimpleNamespace(weight=dev(w), bias=dev(b))
+    norm = norm.cuda()
+    out = ops.token_linear(dev(x), lin, residual=dev(res), norm=norm)
+    assert out.shape == (M, C) and maxerr(out, ref) < 3e-5 * (K / 256) ** 0.5
+    t2 = ops.token_linear(dev(x), lin, use_bias=False)
+    unf = ops.add_layer_norm(dev(res), norm.weight, norm.bias, norm.eps, t2, lin.bias)[1]
+    assert maxerr(out, unf.cpu()) < 5e-6
+    with pytest.raises(RbaHipError):
+        ops.token_linear(dev(x), lin, residual=dev(res))                    # residual without norm
+
+
+def test_token_linear_multi(ops):
+    """three Linears over the same rows in one launch, two of them filling column slices of one tensor (the sampling Linear of a 3-level
+    MSDeformAttn: 288 outputs = 256 + 32), each with its own x_add: bit-equal to the single-problem launches"""
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(11)
+    M, K = 4830, 256
+    x, pos = dev(torch.randn(M, K, generator=g)), dev(torch.randn(M, K, generator=g))
+    mk = lambda n: SimpleNamespace(weight=dev(torch.randn(n, K, generator=g) * K ** -0.5), bias=dev(torch.randn(n, generator=g)))
+    lv, ls = mk(256), mk(288)
+    parts = [(SimpleNamespace(weight=ls.weight[c:c + 256], bias=ls.bias[c:c + 256]), c) for c in (0, 256)]
+    raw = torch.full((M, 288), float("nan"), device="cuda")
+    outs = ops.token_linear_multi(x, [(lv, None, None, 0, False)] + [(pl, pos, raw, c0, False) for pl, c0 in parts])
+    assert outs[1] is raw and outs[2] is raw and torch.isfinite(raw).all()
+    assert torch.equal(outs[0], ops.token_linear(x, lv))
+    for pl, c0 in parts:
+        assert torch.equal(raw[:, c0:c0 + pl.weight.shape[0]], ops.token_linear(x, pl, x_add=pos))
+    ref = F.linear((x + pos).double().cpu(), ls.weight.double().cpu(), ls.bias.double().cpu())
+    assert maxerr(raw, ref) < 2.5e-5
+    k, v = ops.token_linear_multi(x, [(lv, pos, None, 0, True), (lv, None, None, 0, False)])      # ReLU on one problem only
+    assert torch.equal(k, ops.token_linear(x, lv, x_add=pos, relu=True)) and torch.equal(v, outs[0])
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (3000, 1100, 544), (32768, 256, 256), (1000, 128, 128), (2048, 1024, 4096),

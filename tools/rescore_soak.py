@@ -64,6 +64,7 @@ def wrap(fn, label):
     return inner
 
 
+_split_linear, _split_weight = ops.split_linear, ops.split_weight          # unwrapped: the GEMM thread beside the soak must not touch the recorder
 F.linear = wrap(F.linear, "F.linear")
 F.conv2d = wrap(F.conv2d, "F.conv2d")
 for k in dir(ops):
@@ -90,10 +91,11 @@ def soak(mode, poison):
         st = torch.cuda.Stream()
         x = torch.randn(8192, 512, device="cuda")
         lin = torch.nn.Linear(512, 2048).cuda()
-        with torch.cuda.stream(st), torch.no_grad(), ops.split_mode("f16x3"):
+        with torch.cuda.stream(st), torch.no_grad():
+            planes = _split_weight(lin.weight.detach(), "f16x3")
             while not stop.is_set():
                 for _ in range(4):
-                    ops.split_linear(x, ops.split_weight(lin.weight.detach(), "f16x3"), lin.bias, gelu=True)
+                    _split_linear(x, planes, lin.bias, gelu=True)
                 st.synchronize()
 
     bad_maps, nops = 0, 0

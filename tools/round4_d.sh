@@ -1,0 +1,16 @@
+set -x
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4d; mkdir -p $O
+cd $R
+python tools/token_linear_ab.py 2>&1 | grep -v amdgpu.ids > $O/token_linear_ab.txt; cat $O/token_linear_ab.txt
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "token_linear or k1_up4" > $O/tests_k.txt 2>&1; tail -8 $O/tests_k.txt
+timeout 1200 python -m pytest tests/test_model_gpu.py -q -x > $O/tests_model.txt 2>&1; tail -8 $O/tests_model.txt
+python tools/k1_up4_ab.py 2>&1 | grep -v amdgpu.ids > $O/k1_up4_ab.txt; cat $O/k1_up4_ab.txt
+python bench.py --streams 1 --no-cpu-baseline --sustain 0 > $O/bench_s1.json 2> $O/bench_s1.err
+python bench.py --no-cpu-baseline --sustain 0 > $O/bench_s3.json 2> $O/bench_s3.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("/root/repo/gpurun_out/r4d/bench_*.json")):
+    try:
+        d=json.load(open(f)); print(f.split("/")[-1], round(d["value"],1), d.get("single_stream",{}).get("images_per_s"), {k:round(v["avg_launch_ms"]*1e3,1) for k,v in (d.get("k1_fused_upsample_forms") or {}).items()})
+    except Exception as e: print(f, "ERR", e)
+PY
