@@ -61,9 +61,10 @@ __global__ void token_linear_pack_kernel(const float* __restrict__ w, rba_u32x4*
   }
 }
 
-// CTW: 16-column tiles per wave (N <= 64 CTW).  LN: residual + LayerNorm epilogue (single problem).
+// CTW: 16-column tiles per wave (N <= 16 CTW TLW).  LN: residual + LayerNorm epilogue (single problem).
+constexpr int TLW = 4;
 template <int CTW, bool LN>
-__global__ __launch_bounds__(256) void token_linear_kernel(const float* __restrict__ x, TlProblems ps, const float* __restrict__ residual,
+__global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __restrict__ x, TlProblems ps, const float* __restrict__ residual,
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K) {
   const TlProblem p = blockIdx.y == 0 ? ps.p[0] : (blockIdx.y == 1 ? ps.p[1] : ps.p[2]);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
   const int row0 = blockIdx.x * 16;
   const int row = min(row0 + t, M - 1);
   const int KB = K >> 5, NT = (p.N + 15) >> 4;
-  const int nt0 = (blockIdx.z * 4 + wave) * CTW;                                  // this wave's first column tile (blockIdx.z: column group)
+  const int nt0 = wave * CTW;                                                     // this wave's first column tile
   const float* xa = x + (int64_t)row * K + 8 * kb;
   const float* xb = p.x_add ? p.x_add + (int64_t)row * K + 8 * kb : nullptr;
   const bool has_add = xb != nullptr;                                             // workgroup-uniform
@@ -81,14 +82,19 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < CTW; ++i) accm[i] = accl[i] = (tl_f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // NS-deep register ring: the loads of block b + NS - 1 are issued before block b is consumed.  With one block of look-ahead (the first
-  // version) a workgroup walked K as a chain of L2 round trips -- 18 us for the K = 256 / 1 024 LayerNorm launches, 12 us for the two-problem
-  // launch (profiles/r04_token_linear.txt); a workgroup needs ~128 KB in flight to stream its weight at the CU's L1 fill rate.
+  // NS-deep register ring: the loads of block b + NS - 1 are issued before block b is consumed.  Every workgroup streams the whole packed
+  // weight (256 KiB at K = N = 256, 1 MiB at K = 1 024) and all workgroups walk the same lines at the same time.  Measured at 2 048 rows
+  // (profiles/r04_token_linear.txt; two-problem launch / K = 256 + LayerNorm / K = 1 024 + LayerNorm): one block of look-ahead 12 / 18 (mean of
+  // both LayerNorm forms) us; FOUR stages 10.6 / 9.6 / 20.4 us (the product); eight waves x six stages (192 KB in flight per workgroup)
+  // 11.3 / 9.6 / 25.6 us -- more bytes in flight do not help, so the launch is not latency-bound any more but bound by the L2 serving the
+  // same weight lines to 128 workgroups at once; cutting the columns into groups (4x the workgroups, a quarter of the weight each) is
+  // slower still (23 us at K = 1 024: three MFMAs per 2 KB of loads).  At K = 1 024 the library GEMM + LayerNorm pair it replaces took 16 us.
   constexpr int NS = 4;
   f32x4 a[NS][2], ad[NS][2];
   rba_u32x4 wf[NS][CTW][2];
   auto loads = [&](int b, int s) {
-    const int bc = b < KB ? b : KB - 1;                                             // beyond K: a valid re-load, never consumed
+    if (b >= KB) return;                                                            // wave-uniform
+    const int bc = b;
     a[s][0] = *reinterpret_cast<const f32x4*>(xa + 32 * bc);
     a[s][1] = *reinterpret_cast<const f32x4*>(xa + 32 * bc + 4);
     if (has_add) {
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
   }
   // ---- residual + LayerNorm over the complete row (N % 16 == 0): s = residual + (x W^T + bias), y = (s - mean) rstd g + b, the
   // statistics as in rba_add_layer_norm_f32 (mean first, then the centred sum of squares)
-  __shared__ float red[2][4][16];
+  __shared__ float red[2][TLW][16];
   float s1 = 0.f;
 #pragma unroll
   for (int i = 0; i < CTW; ++i) {
@@ -198,7 +204,10 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
   s1 += __shfl_xor(s1, 32, RBA_WAVE);
   if (kb == 0) red[0][wave][t] = s1;
   __syncthreads();
-  const float mean = (red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]) / (float)p.N;
+  float tot = 0.f;
+#pragma unroll
+  for (int w_ = 0; w_ < TLW; ++w_) tot += red[0][w_][t];
+  const float mean = tot / (float)p.N;
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CTW; ++i) {
@@ -214,7 +223,10 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
   s2 += __shfl_xor(s2, 32, RBA_WAVE);
   if (kb == 0) red[1][wave][t] = s2;
   __syncthreads();
-  const float var = (red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]) / (float)p.N;
+  tot = 0.f;
+#pragma unroll
+  for (int w_ = 0; w_ < TLW; ++w_) tot += red[1][w_][t];
+  const float var = tot / (float)p.N;
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
   for (int i = 0; i < CTW; ++i) {
@@ -229,19 +241,14 @@ __global__ __launch_bounds__(256) void token_linear_kernel(const float* __restri
   }
 }
 
-// Column groups (no LayerNorm): a workgroup that owns all N columns streams the whole packed weight -- 1 MiB at K = 1 024, N = 256, which one
-// CU's vector L1 takes ~8 us to pull in (profiles/r04_token_linear.txt: 20 us against 16 for the library GEMM + LayerNorm).  For long K the
-// columns are therefore cut into groups of 64 (one 16-column tile per wave), blockIdx.z = group: 4x the workgroups, a quarter of the bytes each.
 template <bool LN>
 int launch_token_linear(const float* x, const TlProblems& ps, int nprob, const float* residual, const float* ln_w, const float* ln_b, float eps,
                         int M, int K, hipStream_t st) {
   int nmax = 0;
   for (int i = 0; i < nprob; ++i) nmax = ps.p[i].N > nmax ? ps.p[i].N : nmax;
-  const int ntiles = (nmax + 15) >> 4;
-  const int groups = (!LN && K >= 512 && ntiles > 4) ? (ntiles + 3) / 4 : 1;
-  const int ctw = groups > 1 ? 1 : (ntiles + 3) >> 2;
-  const dim3 grid((unsigned)((M + 15) / 16), (unsigned)nprob, (unsigned)groups);
-#define RBA_TL(C) hipLaunchKernelGGL((token_linear_kernel<C, LN>), grid, dim3(256), 0, st, x, ps, residual, ln_w, ln_b, eps, M, K)
+  const int ctw = (((nmax + 15) >> 4) + TLW - 1) / TLW;
+  const dim3 grid((unsigned)((M + 15) / 16), (unsigned)nprob);
+#define RBA_TL(C) hipLaunchKernelGGL((token_linear_kernel<C, LN>), grid, dim3(64 * TLW), 0, st, x, ps, residual, ln_w, ln_b, eps, M, K)
   switch (ctw) {
     case 1: RBA_TL(1); break;
     case 2: RBA_TL(2); break;

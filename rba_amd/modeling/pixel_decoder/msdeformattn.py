@@ -57,13 +57,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         hid = ops.linear(src, self.linear1, relu=True)                        # N = d_ffn: K6
         N2, K2 = self.linear2.weight.shape
         if ops.token_linear_pays(hid.numel() // K2, N2, K2):
-            if K2 <= 512:
-                return ops.token_linear(hid, self.linear2, residual=src, norm=self.norm2)
-            # long K: a workgroup that owned whole rows would stream the entire 1 MiB weight through one CU's L1 (20 us against 16 for the
-            # library path) -- column-split launch + the add-LayerNorm kernel (csrc/token_linear.hip, "column groups")
-            src2 = ops.token_linear(hid, self.linear2, use_bias=False)
-        else:
-            src2 = ops.linear(hid, self.linear2, use_bias=False)
+            return ops.token_linear(hid, self.linear2, residual=src, norm=self.norm2)
+        src2 = ops.linear(hid, self.linear2, use_bias=False)
         return ops.add_layer_norm(src, self.norm2.weight, self.norm2.bias, self.norm2.eps, src2, self.linear2.bias)[1]
 
 

@@ -53,8 +53,6 @@ for M, L in ((2048, 1), (4830, 3)):
         t_new = timed(lambda: ops.token_linear(hid, l2, residual=res, norm=norm))
         t_old = timed(lambda: ops.add_layer_norm(res, norm.weight, norm.bias, norm.eps, F.linear(hid, l2.weight), l2.bias))
         print(f"M={M:5d}  linear2 + residual + LayerNorm (K = 1 024)      token kernel {t_new:6.1f} us   library GEMM + add_layer_norm {t_old:6.1f} us")
-        t_new2 = timed(lambda: ops.add_layer_norm(res, norm.weight, norm.bias, norm.eps, ops.token_linear(hid, l2, use_bias=False), l2.bias))
-        print(f"M={M:5d}  linear2 (column groups) + add_layer_norm           token kernels {t_new2:6.1f} us")
         t_new = timed(lambda: ops.token_linear_multi(x, [(lv, pos, None, 0, False), (lo, None, None, 0, False)]))
         t_old = timed(lambda: (F.linear(x + pos, lv.weight, lv.bias), F.linear(x, lo.weight, lo.bias)))
         print(f"M={M:5d}  decoder k = W_k (mem + pos), v = W_v mem         token kernel {t_new:6.1f} us   add + 2 library GEMMs {t_old:6.1f} us", flush=True)
