@@ -407,6 +407,10 @@ def main():
         import ctypes
         from rba_amd import _lib
         ctypes.c_int.in_dll(_lib.load(), "rba_k6_occ").value = int(os.environ["RBA_K6_OCC"])
+    if os.environ.get("RBA_K6_RS"):                           # tools: A/B of the 256 x 128 / 8-wave K6 form (0 = by tile count, 1 = never, 2 = always)
+        import ctypes
+        from rba_amd import _lib
+        ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs").value = int(os.environ["RBA_K6_RS"])
     if os.environ.get("RBA_K6_STAGGER"):                      # tools: late start of every CU's second K6 workgroup (100 MHz ticks)
         import ctypes
         from rba_amd import _lib

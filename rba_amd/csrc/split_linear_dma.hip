@@ -15,6 +15,7 @@
 extern "C" __attribute__((visibility("default"))) int rba_k6_variant = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_stagger = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_occ = 2;
+extern "C" __attribute__((visibility("default"))) int rba_k6_rs = 0;       // 256 x 128 / 8-wave form: 0 = by tile count (split_linear_h3.h), 1 = never, 2 = always
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {

@@ -541,9 +541,12 @@ __device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], co
 // CONVP (with PRE, two workgroups per CU): the 3 x 3 convolution as an implicit GEMM over the producer's split image of the NHWC input
 // (rows = pixels, K = 9 Cin, k = tap * Cin + channel): the four pieces of a lane's row for block (tap, channel block) are the pieces
 // of the NEIGHBOUR pixel's row (row + dy W + dx) -- 32 lanes still read one or two contiguous runs -- zeroed where the tap leaves the image.
+// RS = 2 (round 4, tune library only -- measured in profiles/r04_k6_rs2.txt): EIGHT waves, two per SIMD, as ONE workgroup of 256 x 128: waves 4-7 are
+// a second copy of waves 0-3 that owns the NEXT 128 rows and walks the same k blocks through the SAME weight ring (staged once by all 512 threads), so
+// the packed weight crosses the vector L1 once per 256 rows instead of once per 128: operand traffic per MFMA 42.7 -> 32 B/clk/CU at full matrix rate.
 template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false, int KS = 1,
-          bool CONVP = false>
-__global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
+          bool CONVP = false, int RS = 1>
+__global__ __launch_bounds__(256 * KS * RS, (KS == 2 || RS == 2) ? 1 : OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
                                                                  const float* R = nullptr, ConvShape cs = ConvShape{0, 0, 0}, int stagger = 0) {
@@ -559,20 +562,24 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_
   constexpr int SUBW = 4 * BN, BLK = 2 * SUBW, UPL = BLK / 256;
   __shared__ __attribute__((aligned(16))) u32x4_t lds_all[2 * BLK * KS];
 
+  static_assert(KS * RS <= 2, "K split and row split are alternatives");
   const int tid = threadIdx.x & 255, lane = tid & 63;
   const int ks = KS == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;     // which half of the k blocks
+  const int rs = RS == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;     // which 128 rows of the 256-row tile
+  const int wtid = RS == 2 ? (int)threadIdx.x : tid;                                  // weight staging: all threads that share the ring
+  constexpr int UPLW = UPL / RS;
   u32x4_t* const lds = lds_all + ks * 2 * BLK;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
   const int nb = MT * NT;
   if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
   const int mt = bid / NT, nt = bid - mt * NT;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = (mt * RS + rs) * BM, n0 = nt * BN;
   const int NB = (K >> 5) / KS, S16 = K >> 4;                                       // NB: blocks THIS wave set walks (K / 32 even when KS = 2)
   const int l31 = lane & 31, lh = lane >> 5;
 
   const char* wbase = reinterpret_cast<const char*>(Wp + (int64_t)(n0 >> 7) * S16 * 512);
-  const uint32_t woff = (uint32_t)tid * 16u;                                       // the block image is contiguous: unit tid + 256 q
+  const uint32_t woff = (uint32_t)wtid * 16u;                                      // the block image is contiguous: unit wtid + 256 RS q
   int row = m0 + 32 * wave + l31;
   row = (row < M ? row : M - 1) - m0;
   const char* xbase = reinterpret_cast<const char*>(A + (int64_t)m0 * K);
@@ -584,8 +591,8 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_
 #pragma unroll
     for (int r = 0; r < 16; ++r) accm[j][r] = accl[j][r] = 0.f;
 
-  u32x4_t wr[UPL];
-  constexpr bool TWO = OCC == 2 || KS == 2;                                        // two waves per SIMD: 256 registers each
+  u32x4_t wr[UPLW];
+  constexpr bool TWO = OCC == 2 || KS == 2 || RS == 2;                                        // two waves per SIMD: 256 registers each
   constexpr bool DEEP = !TWO;                                                      // registers to spare: activations two blocks ahead
   constexpr bool DIRECT = PRE && TWO;                                              // pieces straight into the next block's operand set
   f32x4 xr[DEEP ? 2 : 1][4];
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_
   auto wload = [&](int c) {
     const char* src = wbase + (int64_t)bix(c) * 16384;
 #pragma unroll
-    for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(src + q * 4096 + woff);
+    for (int q = 0; q < UPLW; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(src + q * (4096 * RS) + woff);
   };
   // PRE: A is the producer's fragment-ordered, already split image (frag_layout.h): per (32-row group, 32-wide block) four 1 KiB
   // pieces [h g0 | l g0 | h g1 | l g1], each [lane][8 f16] -- one contiguous wave load per operand register quad, no arithmetic here
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_
   if (DIRECT) xloadset(0, 0);
   else xload(0, xr[0]);
 #pragma unroll
-  for (int q = 0; q < UPL; ++q) lds[tid + 256 * q] = wr[q];
+  for (int q = 0; q < UPLW; ++q) lds[wtid + 256 * RS * q] = wr[q];
   if (!DIRECT) {
     psplit(xr[0][0], xr[0][1], ah[0][0], al[0][0]);
     psplit(xr[0][2], xr[0][3], ah[0][1], al[0][1]);
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : OCC) void split_linear_h3p_
 #define RBA_XI(P) (DEEP ? (P) ^ 1 : 0)
 #define RBA_BLOCK(B, P, CUR, NXT)                                                                                       \
   {                                                                                                                     \
-    if (!(PROBE & 256)) { _Pragma("unroll") for (int q = 0; q < UPL; ++q)(NXT)[tid + 256 * q] = wr[q]; }                \
+    if (!(PROBE & 256)) { _Pragma("unroll") for (int q = 0; q < UPLW; ++q)(NXT)[wtid + 256 * RS * q] = wr[q]; }        \
     if (!(PROBE & 1)) wload((B) + 2);                                                                                   \
     if (DIRECT) xloadset((B) + 1, (P) ^ 1);                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
@@ -854,12 +861,34 @@ inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const floa
   return launch_h3p<0>(x, wp, bias, out, M, N, K, st);
 }
 
+// Round 4: the 256 x 128 form (RS = 2: eight waves, one weight ring for two 128-row halves -- see the kernel) for launches whose tiles fill the
+// chip evenly.  Measured (profiles/r04_k6_rs2.txt, isolated launches, bit-identical results): 1.10-1.15x where the 256 x 128 tiles make whole
+// rounds of the 256 CUs or one round that is at least three quarters full (Swin-B stage-3 fc1 69 -> 62 us, stage-4 qkv / fc1 45 -> 40 / 55 -> 50 us,
+// Swin-L stage-3 fc1 / fc2 130 -> 117 / 126 -> 110 us), 0.81-0.96x where they leave CUs idle (<= 128 tiles: stage-3 proj / fc2 of Swin-B) or end
+// in a round that is less than three quarters full (1.5 rounds: Swin-B stage-3 qkv).  rba_k6_rs (tools): 0 = this rule, 1 = never, 2 = whenever there
+// are at least 160 tiles of 256 x 128.
+extern "C" int rba_k6_rs;
+inline bool h3p_use_rs2(int64_t M, int N) {
+  if (rba_k6_rs == 1) return false;
+  const int64_t t = ((M + 255) / 256) * ((N + 127) / 128);
+  if (t < 160) return false;
+  if (rba_k6_rs == 2) return true;
+  const int64_t last = t % 256;                                       // workgroups in the last round of the 256 CUs (0 = full)
+  return last == 0 || last >= 192;
+}
+
 // A operand = the producer's split fragment image (PRE); residual may be null
 template <int ACT, bool RES, int OCC>
 int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K,
                    hipStream_t st) {
-  const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
+  if (OCC == 2 && h3p_use_rs2(M, N)) {
+    const int64_t MT2 = (M + 255) / 256;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, 2, true, false, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
+                       reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT2, NT, nullptr, res, ConvShape{0, 0, 0}, 0);
+    return 0;
+  }
+  const int64_t MT = (M + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, OCC, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr, res, ConvShape{0, 0, 0}, rba_k6_stagger);
@@ -868,8 +897,15 @@ int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const f
 // out = the split fragment image of act(x W^T + bias) (FOUT); x either fp32 rows or a split image (PRE)
 template <int ACT, bool PRE, int OCC>
 int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* out_frag, int64_t M, int N, int K, hipStream_t st) {
-  const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
+  if (OCC == 2 && PRE && h3p_use_rs2(M, N)) {
+    const int64_t MT2 = (M + 255) / 256;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, false, 2, true, true, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
+                       reinterpret_cast<const float*>(x), wp, bias, reinterpret_cast<float*>(out_frag), (int)M, N, K, (int)MT2, NT, nullptr, nullptr,
+                       ConvShape{0, 0, 0}, 0);
+    return 0;
+  }
+  const int64_t MT = (M + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, false, OCC, PRE, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(x), wp, bias, reinterpret_cast<float*>(out_frag), (int)M, N, K, (int)MT, NT, nullptr,
@@ -879,8 +915,15 @@ int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* o
 // 3 x 3 convolution (pad 1) over the split image of NHWC activations: M = B H W output pixels, K = 9 Cin (two workgroups per CU)
 inline int launch_h3p_conv_pre(const void* xf, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
                                hipStream_t st) {
-  const int64_t MT = (M + 127) / 128;
   const int NT = (N + 127) / 128;
+  if (h3p_use_rs2(M, N)) {
+    const int64_t MT2 = (M + 255) / 256;
+    if (MT2 * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
+                       reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, 9 * Cin, (int)MT2, NT, nullptr, nullptr, ConvShape{H, W, Cin});
+    return 0;
+  }
+  const int64_t MT = (M + 127) / 128;
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, 9 * Cin, (int)MT, NT, nullptr, nullptr, ConvShape{H, W, Cin});

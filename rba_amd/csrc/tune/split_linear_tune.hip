@@ -4,6 +4,7 @@
 #include "split_linear_experiments.h"
 #include "../split_linear_h3.h"
 extern "C" int rba_k6_occ = 1;
+extern "C" int rba_k6_rs = 1;
 extern "C" int rba_k6_stagger = 0;          // the product library's tools-only knob, defined here for this separate library
 #include "../mlp_fused_h3.h"
 
@@ -151,6 +152,34 @@ extern "C" int rba_split_linear_h3_tune(const float* x, const void* weight_packe
       const int64_t MT = (M + 127) / 128; const int NT = (N + 127) / 128;
       hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 1, true, false, 2>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, x, wp, bias, out,
                          (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
+    // round 4: the product's launch forms on split-image operands (timing only: x is read as if it were a split image), one 128 x 128 tile per
+    // workgroup, two workgroups per CU (5204: fp32 rows out = qkv; 5214: GELU + split image out = fc1) -- and the 256 x 128 / 8-wave / shared weight
+    // ring form RS = 2 of the same two launches (7104, 7114)
+    case 5204: {
+      const int64_t MT = (M + 127) / 128; const int NT = (N + 127) / 128;
+      hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out,
+                         (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
+    case 5214: {
+      const int64_t MT = (M + 127) / 128; const int NT = (N + 127) / 128;
+      hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, false, false, 2, true, true, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, st, x, wp, bias, out,
+                         (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
+    case 7104: {
+      const int64_t MT = (M + 255) / 256; const int NT = (N + 127) / 128;
+      hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, false, 2>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, x, wp, bias,
+                         out, (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
+    case 7114: {
+      const int64_t MT = (M + 255) / 256; const int NT = (N + 127) / 128;
+      hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, false, false, 2, true, true, 1, false, 2>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, x, wp, bias,
+                         out, (int)M, N, K, (int)MT, NT, nullptr);
+      rc = 0; break; }
+    case 7004: {                                                                     // RS = 2 on fp32 rows (results checked by tools/gemm_h3_sweep.py)
+      const int64_t MT = (M + 255) / 256; const int NT = (N + 127) / 128;
+      if (act == 1) hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, false, false, 2, false, false, 1, false, 2>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, x, wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr);
+      else hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, false, false, 1, false, 2>), dim3((unsigned)(MT * NT)), dim3(512), 0, st, x, wp, bias, out, (int)M, N, K, (int)MT, NT, nullptr);
       rc = 0; break; }
     case 5104: {
       const int64_t MT = (M + 127) / 128; const int NT = (N + 127) / 128;
