@@ -415,6 +415,8 @@ def main():
         import ctypes
         from rba_amd import _lib
         ctypes.c_int.in_dll(_lib.load(), "rba_k6_stagger").value = int(os.environ["RBA_K6_STAGGER"])
+    if "RBA_K6_RS" not in os.environ:
+        ops.set_concurrent_streams(max(1, args.streams))        # S images of a step run on S streams at once: launch-geometry hint (include/rba_hip.h)
     a = A.complete(A.ARCHS[args.arch])
     model = load_checkpoint(MaskFormer(a), A.seeded_weights(a, 0)).to(dev).eval()
     model.fused_upsample = args.k1 == "up4"
@@ -760,6 +762,8 @@ def main():
         try:
             n1 = max(10, min(args.steps, 30))
             single = {}
+            if "RBA_K6_RS" not in os.environ:
+                ops.set_concurrent_streams(1)                          # one image at a time from here on
             prev_fused = model.fused_upsample
             for label, replay in (("eager", False), ("model_graph_replay", True)):
                 model.graph_replay = replay

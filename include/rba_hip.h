@@ -3,7 +3,7 @@
  *
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated; no environment variables are read and
- *     there is no mutable global state (the only process-wide side effect is that the first launch of a kernel that needs
+ *     there is no mutable global state except the launch-geometry hint of rba_set_concurrent_streams (the only other process-wide side effect is that the first launch of a kernel that needs
  *     more than 64 KiB of LDS sets that kernel's hipFuncAttributeMaxDynamicSharedMemorySize once); re-entrant; tensors
  *     are dense row-major ("contiguous") in the index order written next to them;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
@@ -52,6 +52,12 @@ extern "C" {
 
 /* Library/ABI version (major*100 + minor). */
 int rba_hip_version(void);
+
+/* Launch-geometry hint, the library's only caller-set state: the number of streams of this process that launch forwards concurrently
+ * (default 1).  With n >= 2 the K6 launches that fill only half the chip take whole CUs (8-wave 256 x 128 workgroups) and leave the rest to the
+ * other streams' kernels.  Affects speed only: every kernel form gives bit-identical results.  Returns the previous setting (1 or 2).
+ * Not thread-safe against concurrent launches; set it before the streams start (bench.py, evaluate_ood.run_evaluations do). */
+int rba_set_concurrent_streams(int n);
 
 /* K1.  mask [Q,HW] full-resolution mask logits; cls_prob [Q,K] = softmax(class logits)[:, :-1].
  *   sem[k,p]  = sum_q cls_prob[q,k] * sigmoid(mask[q,p])      (ascending-q fp32 FMA order)

@@ -17,6 +17,7 @@ _vp = ctypes.c_void_p
 # name -> argtypes ; every function returns int (hipError_t)
 SIGNATURES = {
     "rba_hip_version": [],
+    "rba_set_concurrent_streams": [_i],
     "rba_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp],
     "rba_reduce_ws_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp],
     "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -77,7 +78,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 182        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 183        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

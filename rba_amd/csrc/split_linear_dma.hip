@@ -15,7 +15,17 @@
 extern "C" __attribute__((visibility("default"))) int rba_k6_variant = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_stagger = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_occ = 2;
-extern "C" __attribute__((visibility("default"))) int rba_k6_rs = 0;       // 256 x 128 / 8-wave form: 0 = by tile count (split_linear_h3.h), 1 = never, 2 = always
+extern "C" __attribute__((visibility("default"))) int rba_k6_rs = 0;       // 256 x 128 / 8-wave form: 0 = by tile count (split_linear_h3.h), 1 = never, 2 = always, 3 = from 64 tiles
+
+// The one piece of caller-set state of the library (include/rba_hip.h): how many streams of this process launch forwards CONCURRENTLY.  With two
+// or more, the half-chip K6 launches (128 tiles of 256 x 128: Swin-B stage-3 proj / fc2, and the 1.5-round qkv) run the 8-wave form too: its
+// workgroups own whole CUs, so such a launch takes 128 CUs and leaves the other 128 to the other streams' kernels instead of half of every CU
+// (3 streams: 136.3 -> 139.7 images/s; alone it is slower, 116.3 -> 112.0: profiles/r04_bench_*.json).  Results are bit-identical either way.
+extern "C" int rba_set_concurrent_streams(int n) {
+  const int prev = rba_k6_rs == 3 ? 2 : 1;
+  rba_k6_rs = n >= 2 ? 3 : 0;
+  return prev;
+}
 
 extern "C" int rba_split_linear_f32(const float* x, const void* weight_planes, const float* bias, float* out, int64_t M, int N,
                                     int K, int act, void* stream) {
@@ -161,7 +171,8 @@ extern "C" int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_spl
       default: rc = launch_h3q<H3Q_SPLIT, 1>(x, wp, bias, nullptr, out_frag, M, N, K, st);
     }
   } else if (x_is_split && h3q_supported(M, N, K) &&
-             (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768 && ((M + 127) / 128) * ((N + 127) / 128) > 512)))
+             (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768 && ((M + 127) / 128) * ((N + 127) / 128) > 512 && !h3p_use_rs2(M, N))))
+    // (round 4: where the 256 x 128 form of the pipelined kernel applies it beats both -- Swin-L stage 3: 130 (128 x 128) / 136-146 (sub-tiles) / 117 us)
     // fc1 + GELU with the epilogue deferred into the next sub-tile's k loop: pays where the 128 x 128 kernel needs more than one round of
     // workgroups AND the k loop is long (Swin-L: stage 3 165 -> 143 us, stage 4 147 -> 142 us); a one-round launch (Swin-B stage 4: 512
     // tiles, 61 vs 72 us) or a 16-block loop (Swin-B stage 3: 65 vs 71 us) is better off on the 128 x 128 kernel

@@ -871,6 +871,7 @@ extern "C" int rba_k6_rs;
 inline bool h3p_use_rs2(int64_t M, int N) {
   if (rba_k6_rs == 1) return false;
   const int64_t t = ((M + 255) / 256) * ((N + 127) / 128);
+  if (rba_k6_rs == 3) return t >= 64;                                 // tools: also the half-chip launches (128 tiles: stage-3 proj / fc2 of Swin-B)
   if (t < 160) return false;
   if (rba_k6_rs == 2) return true;
   const int64_t last = t % 256;                                       // workgroups in the last round of the 256 CUs (0 = full)

@@ -197,6 +197,10 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
     use_graphs = on_gpu and bool(int(getattr(args, "graph", 0)))
+    prev_streams = None
+    if on_gpu:
+        from . import ops as _ops
+        prev_streams = _ops.set_concurrent_streams(n_streams)   # launch-geometry hint (include/rba_hip.h): speed only, bit-identical results
     prev_replay = getattr(model, "graph_replay", None)
     if prev_replay is not None:
         model.graph_replay = use_graphs                         # MaskFormer.rba_scores replays per (image shape, stream)
@@ -317,6 +321,8 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
                       host_thread={n: round(v, 3) for n, v in host.items()})
     if prev_replay is not None:
         model.graph_replay = prev_replay
+    if prev_streams is not None:
+        _ops.set_concurrent_streams(prev_streams)
     s_all = torch.cat(scores) if scores else torch.empty(0, device=dev)
     y_all = torch.cat(labels) if labels else torch.empty(0, dtype=torch.bool, device=dev)
     return D.pooled_ood_metrics(s_all, y_all)

@@ -799,6 +799,14 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     return out
 
 
+def set_concurrent_streams(n):
+    """Tell the kernel library how many HIP streams of this process run forwards at the same time (default 1): with two or more, the K6 launches
+    that would fill only half the chip use whole-CU workgroups and leave the other CUs to the other streams (include/rba_hip.h).  Speed only --
+    results are bit-identical.  Returns the previous setting.  Call it before the streams start launching (and before capturing hipGraphs: a
+    graph replays the launch forms it was captured with)."""
+    return int(_lib.load().rba_set_concurrent_streams(int(n)))
+
+
 # ---------------------------------------------------------------------------------------------------------------- small token Linears
 TOKEN_LINEAR = os.environ.get("RBA_TOKEN_LINEAR", "1") != "0"      # A/B switch (tools): 0 sends the small Linears back to hipBLASLt + separate kernels
 

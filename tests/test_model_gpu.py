@@ -699,3 +699,26 @@ def test_rba_scores_soak_three_streams_graph_replay():
     import k1_soak
     r = k1_soak.soak_model(forwards=60)
     assert r["live_graphs"] == 3 and r["mismatching_forwards"] == 0, r
+
+
+def test_concurrent_streams_hint_changes_launch_forms_not_bits():
+    """ops.set_concurrent_streams(n >= 2) makes the half-chip K6 launches use the 256 x 128 / 8-wave form (include/rba_hip.h): the score map of a
+    Swin-B forward is bit-identical with and without the hint, and with the 8-wave form switched off altogether (rba_k6_rs = 1)."""
+    import ctypes
+    from rba_amd import _lib, ops
+    model, a, _ = build("swin_b_1dl", 0)
+    model.graph_replay = False
+    g = torch.Generator().manual_seed(21)
+    image = torch.randint(0, 256, (3, 512, 1024), generator=g, dtype=torch.uint8).cuda()
+    rs = ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs")
+    try:
+        assert ops.set_concurrent_streams(1) in (1, 2)
+        base = model.rba_scores([{"image": image}])[0].clone()
+        assert ops.set_concurrent_streams(3) == 1 and rs.value == 3
+        hinted = model.rba_scores([{"image": image}])[0].clone()
+        rs.value = 1
+        off = model.rba_scores([{"image": image}])[0].clone()
+    finally:
+        rs.value = 0
+    assert ops.set_concurrent_streams(1) == 1
+    assert torch.equal(base, hinted) and torch.equal(base, off)
