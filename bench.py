@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--sustain", type=float, default=5.0,
                     help="seconds of the SAME step loop run after the K timed steps (not part of `value`): the `sustained` object of the line -- images/s "
                          "and the mean shader clock once the chip has settled at its sustained MFMA clock; 0 = skip")
+    ap.add_argument("--cu-partition", type=int, default=0,
+                    help="experiment (tools): 1 = every stream of a step gets its own share of the 8 XCDs through a CU-masked HIP stream "
+                         "(hipExtStreamCreateWithCUMask; queue mask bit i -> XCD i %% 8), so concurrent forwards do not share CUs or L2s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
                     help="quick (default, <= ~15 s): ONE full-size forward of the oracle at the pre-chosen thread count + the isolated reduction; "
@@ -434,7 +437,26 @@ def main():
     S = max(1, args.streams)
     static_ins = [images[i % len(images)].clone() for i in range(S)]
     static_in = static_ins[0]
-    side_streams = [torch.cuda.Stream() for _ in range(S - 1)]
+    def masked_stream(xcds):
+        """a HIP stream whose kernels may only run on the given XCDs (experiment: --cu-partition)"""
+        import ctypes
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        word = 0
+        for b in range(32):
+            if (b % 8) in xcds:
+                word |= 1 << b
+        mask = (ctypes.c_uint32 * 8)(*([word] * 8))
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, mask)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask: hipError {rc}")
+        return torch.cuda.ExternalStream(st.value, device=dev)
+
+    part_streams = None
+    if args.cu_partition and S > 1:
+        bounds = [round(8 * j / S) for j in range(S + 1)]
+        part_streams = [masked_stream(set(range(bounds[j], bounds[j + 1]))) for j in range(S)]
+    side_streams = part_streams[1:] if part_streams else [torch.cuda.Stream() for _ in range(S - 1)]
     k1_probe = {}
 
     def predict_part(src):
@@ -500,7 +522,7 @@ def main():
             part_graphs = []
             with torch.no_grad():
                 for j in range(S):
-                    st = torch.cuda.Stream() if j == 0 else side_streams[j - 1]
+                    st = (part_streams[0] if part_streams else torch.cuda.Stream()) if j == 0 else side_streams[j - 1]
                     st.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(st):
                         predict_part(static_ins[j])                      # warm the stream's allocator pool
@@ -808,7 +830,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.arch}, {Q} queries, {K} classes, 1x3x{h}x{w} uint8 image per GPU per stream per step "
                                    f"= {world * S} image(s) per step ({baseline_config(args.arch, h, w, world, S)}); random-init seeded weights",
-                       "images_per_gpu_per_step": S, "global_batch_per_step": world * S, "hip_streams": S, "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
+                       "images_per_gpu_per_step": S, "global_batch_per_step": world * S, "hip_streams": S, "cu_partition": bool(part_streams), "k1_variant": args.k1, "hip_graph": graph is not None or part_graphs is not None,
                        "k1_launches_alone_on_main_stream_per_step": (sum(1 for g_ in part_graphs if not g_[3]) if part_graphs is not None else S),
                        "sharding": f"{world} process(es), one per GPU, images independent, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "rba_reduce_up4_kernel" if args.k1 == "up4" else "rba_reduce_pk_kernel",

@@ -24,8 +24,24 @@ def read_image(path) -> np.ndarray:
         return np.asarray(im.convert("RGB"))
 
 
+def read_label(path) -> np.ndarray:
+    """First channel of the label image as HW uint8: what `read_image(path)[:, :, 0]` gives (a grey PNG converted to RGB repeats its
+    value), without the detour through three channels when the file is single-channel 8-bit."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode == "L":
+            return np.asarray(im)
+        return np.asarray(im.convert("RGB"))[:, :, 0]
+
+
 def _to_item(image, label):
     return torch.from_numpy(np.ascontiguousarray(image.transpose(2, 0, 1))), torch.from_numpy(label.astype(np.int64))
+
+
+def _to_raw_item(image, label):
+    """The same sample as the decoders left it: image uint8 [H,W,3] (channels last), label uint8 [H,W].  For loaders that move the
+    transpose to the GPU and never need int64 labels (evaluate_ood.run_evaluations): three 6-16 MB host passes per image less."""
+    return torch.from_numpy(np.ascontiguousarray(image)), torch.from_numpy(np.ascontiguousarray(label, dtype=np.uint8))
 
 
 class RoadAnomaly(Dataset):
@@ -38,11 +54,17 @@ class RoadAnomaly(Dataset):
     def __len__(self):
         return len(self.images)
 
-    def __getitem__(self, index):
+    def _decode(self, index):
         image = read_image(self.images[index])
-        label = read_image(self.labels[index])[:, :, 0].copy()
+        label = read_label(self.labels[index]).copy()
         label[label == 2] = 1
-        return _to_item(image, label)
+        return image, label
+
+    def __getitem__(self, index):
+        return _to_item(*self._decode(index))
+
+    def raw_item(self, index):
+        return _to_raw_item(*self._decode(index))
 
 
 class FishyscapesLAF(Dataset):
@@ -55,10 +77,14 @@ class FishyscapesLAF(Dataset):
     def __len__(self):
         return len(self.images)
 
+    def _decode(self, index):
+        return read_image(self.images[index]), read_label(self.labels[index])
+
     def __getitem__(self, index):
-        image = read_image(self.images[index])
-        label = read_image(self.labels[index])[:, :, 0]
-        return _to_item(image, label)
+        return _to_item(*self._decode(index))
+
+    def raw_item(self, index):
+        return _to_raw_item(*self._decode(index))
 
 
 _FACTORIES = {
@@ -79,15 +105,19 @@ def get_dataset(name, datasets_folder):
     return _FACTORIES[name](datasets_folder)
 
 
-def prefetch(dataset, indices, num_threads=4, depth=None, pin=False, label_dtype=None):
+def prefetch(dataset, indices, num_threads=4, depth=None, pin=False, label_dtype=None, raw=False):
     """Yield ``dataset[i]`` for i in `indices`, in order, decoded ahead of the consumer by `num_threads` threads (at most `depth`
     items in flight).  Threads, not DataLoader worker processes: Pillow's decoders release the GIL, so PNG/JPEG decoding scales
     across threads, and forking workers from a process that already holds a HIP context and the model cost more than the whole
     evaluation of a 100-image benchmark (measured: 8 worker processes 4.6 images/s, this 15-16 images/s serial,
     profiles/r02_evaluator.json)."""
     indices = list(indices)
+    raw = raw and hasattr(dataset, "raw_item")     # raw: (image uint8 [H,W,3], label uint8 [H,W]) where the dataset offers it (see _to_raw_item)
 
     def get(i):
+        if raw:
+            item = dataset.raw_item(i)
+            return tuple(t.pin_memory() for t in item) if pin else item
         item = dataset[i]
         if label_dtype is not None:               # the readers yield int64 labels like the reference; uint8 holds {0, 1, 255} in 1/8 the bytes
             item = (item[0], item[1].to(label_dtype)) + tuple(item[2:])

@@ -192,7 +192,9 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     dev = model.device
     on_gpu = dev.type == "cuda"
     nw = max(0, int(args.num_workers))
-    loader = (tuple(t[None] for t in item) for item in prefetch(dataset, mine, nw, pin=on_gpu and nw > 0, label_dtype=torch.uint8))       # batch-1 items [1,3,H,W], [1,H,W]
+    # batch-1 items.  On a HIP device the decode threads hand the image over as the decoder left it (uint8 [1,H,W,3]; the transpose to [3,H,W]
+    # is one 6 MB copy on the GPU instead of a strided host pass per image) with uint8 labels; on the CPU path [1,3,H,W] as the reference yields
+    loader = (tuple(t[None] for t in item) for item in prefetch(dataset, mine, nw, pin=on_gpu and nw > 0, label_dtype=torch.uint8, raw=on_gpu))
     n_streams = max(1, int(getattr(args, "streams", 3))) if on_gpu else 1
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
@@ -270,6 +272,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
             st = streams[k % len(streams)]
             i = mine[k]
             k += 1
+            hwc = xb[j].dim() == 3 and xb[j].shape[-1] == 3 and xb[j].shape[0] != 3      # a raw item: channels last
             shape = tuple(xb[j].shape)
             first_of_shape = shape not in seen_shapes
             if first_of_shape and on_gpu:
@@ -286,6 +289,8 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
             with ctx:
                 t_a = time.perf_counter()
                 x = xb[j].to(dev, non_blocking=True)
+                if hwc:
+                    x = x.permute(2, 0, 1).contiguous()            # [3,H,W] as the model takes it
                 y = yb[j].to(dev, non_blocking=True)
                 # a graph belongs to the stream it was captured on; the first image of a shape runs on the main stream (above) and
                 # is scored eagerly there

@@ -53,6 +53,9 @@ def test_road_anomaly(tmp_path):
         assert x.dtype == torch.uint8 and x.shape == (3, 24, 40) and y.dtype == torch.int64 and y.shape == (24, 40)
         assert np.array_equal(x.numpy().transpose(1, 2, 0), imgs[i])
         assert np.array_equal(y.numpy(), (labs[i] == 2).astype(np.int64))       # 2 -> 1 (road_anomaly.py:38-39)
+        xr, yr = ds.raw_item(i)                                                   # the evaluator's loader form: channels last, uint8 labels
+        assert xr.dtype == torch.uint8 and xr.shape == (24, 40, 3) and yr.dtype == torch.uint8 and xr.is_contiguous()
+        assert torch.equal(xr.permute(2, 0, 1), x) and torch.equal(yr.to(torch.int64), y)
 
 
 def test_fishyscapes_laf(tmp_path):
@@ -62,6 +65,10 @@ def test_fishyscapes_laf(tmp_path):
     for i in range(2):
         x, y = ds[i]
         assert np.array_equal(x.numpy().transpose(1, 2, 0), imgs[i]) and np.array_equal(y.numpy(), labs[i].astype(np.int64))
+        xr, yr = ds.raw_item(i)
+        assert torch.equal(xr.permute(2, 0, 1), x) and torch.equal(yr.to(torch.int64), y) and yr.dtype == torch.uint8
+    got = list(DS.prefetch(ds, range(2), 2, raw=True))                           # raw items through the decode threads, in order
+    assert all(torch.equal(a[0], ds.raw_item(i)[0]) and torch.equal(a[1], ds.raw_item(i)[1]) for i, a in enumerate(got))
     with pytest.raises(KeyError):
         DS.get_dataset("cityscapes", str(tmp_path))
 

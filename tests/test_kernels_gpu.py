@@ -631,6 +631,40 @@ def test_split_linear_from_split_activations(ops, M, N, K):
     assert torch.equal(ops.split_linear(xs, planes, None, out_features=N), ops.split_linear(x, planes, None, out_features=N))
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (8192, 512, 2048), (8100, 1536, 512), (3680, 2048, 512), (40000, 256, 288), (16500, 640, 544)])
+def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
+    """Round 4: the 256 x 128 / eight-wave / shared-weight-ring form of the pipelined f16x3 kernel (rba_k6_rs: 1 = off, 3 = from 64 tiles -- what
+    ops.set_concurrent_streams(n >= 2) selects) against the 128 x 128 form, on split-image operands: fp32 rows out (plain, GELU, ReLU), the
+    residual epilogue, GELU + split image out; M not a multiple of 256 (a whole 128-row half beyond M), N not a multiple of 128."""
+    import ctypes
+    from rba_amd import _lib
+    rs = ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs")
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = dev(torch.randn(M, K, generator=g) * 3), dev(torch.randn(N, K, generator=g) * K ** -0.5)
+    b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+    planes = ops.split_weight(w, mode="f16x3")
+    xs = ops.SplitActivations.pack(x)
+
+    def run():
+        outs = [ops.split_linear(xs, planes, b, out_features=N, **kw) for kw in ({}, {"gelu": True}, {"relu": True})]
+        outs.append(ops.split_linear(xs, planes, b, out_features=N, residual=r.clone()))
+        if N % 32 == 0:
+            so = ops.split_linear(xs, planes, b, gelu=True, out_features=N, split_out=True)
+            outs.append(so.data[: M // 32 * 32 * N].clone())
+            outs.append(so.unpack())
+        return outs
+    try:
+        rs.value = 1
+        want = run()
+        rs.value = 3
+        got = run()
+    finally:
+        rs.value = 0
+    assert ((M + 255) // 256) * ((N + 127) // 128) >= 64                      # the 8-wave form was reached
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (131072, 512, 128), (3000, 1120, 544), (2048, 4096, 1024), (130, 96, 96), (8192, 256, 512)])
 def test_split_linear_gelu_split_output(ops, M, N, K):
     """fc1 -> fc2 hand-over: GELU(x W^T + b) written by the operand-swapped GEMM as SplitActivations == pack(fp32 result), bit for bit,
