@@ -169,7 +169,7 @@ def _thread_safe(dataset):
     return False
 
 
-def threaded(loader, max_threads=12, force=None):
+def threaded(loader, max_threads=8, force=None):
     """The batches of `loader` -- a map-style ``torch.utils.data.DataLoader`` with worker PROCESSES, e.g. the reference's
     ``DataLoader(dataset, shuffle=False, batch_size=1, num_workers=15)`` (evaluate_ood.py:210-211) -- produced in the same order, through the
     same batch sampler and collate function, by decode THREADS of this process; anything else is returned unchanged.  Why: with worker
@@ -226,8 +226,25 @@ class _ThreadedView:
                 return {k: pinned(v) for k, v in b.items()}
             return b
 
+        try:
+            from torch.utils.data._utils.collate import default_collate
+        except Exception:       # pragma: no cover
+            default_collate = None
+
+        def batch1(item):
+            """default_collate of ONE sample without its copy: tensors gain a leading 1 as views (torch.stack would copy 6 MB of image and
+            16 MB of int64 label per item inside the decode thread)"""
+            if torch.is_tensor(item):
+                return item[None]
+            if isinstance(item, (list, tuple)) and all(torch.is_tensor(t) for t in item):
+                return [t[None] for t in item]                      # default_collate returns a list for sequence samples
+            return None
+
         def get(batch_indices):
-            b = collate([ds[i] for i in batch_indices])
+            items = [ds[i] for i in batch_indices]
+            b = batch1(items[0]) if len(items) == 1 and collate is default_collate and default_collate is not None else None
+            if b is None:
+                b = collate(items)
             return pinned(b) if pin else b
 
         yield from _ahead(get, self.loader.batch_sampler, self.num_threads)
