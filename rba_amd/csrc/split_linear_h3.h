@@ -48,21 +48,27 @@ __device__ __forceinline__ void split_h3(const f32x4 u, const f32x4 v, f16x8_t& 
   l = __builtin_bit_cast(f16x8_t, lp);
 }
 
-// gelu_erf (split_linear_dma.h) on two values with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32): same formula, same
-// rounding per operation, half the VALU issues
+// Exact-form GELU (nn.GELU default, swin.py:51) on two values with packed fp32 arithmetic, erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7)
+// like gelu_erf (split_linear_dma.h), re-arranged in round 4 for fewer instructions -- the fc1 epilogue is bound by VALU issue:
+//   gelu(v) = 0.5 v (1 + erf(v / sqrt 2)) = max(v, 0) - |v| * (0.5 erfc(|v| / sqrt 2)),   0.5 erfc(|z|) = (b1 t + ... + b5 t^5) e^(-z^2),
+//   t = 1 / (1 + p |z|), b_i = a_i / 2; with a = |v|:  1 + p |z| = a (p / sqrt 2) + 1  and  e^(-z^2) = exp2(-(a u0)^2), u0 = sqrt(log2(e) / 2)
+// -- no select on the sign, no separate x = |v| / sqrt 2, the 0.5 and the log2(e) folded into constants: per PAIR 12 packed + 4 transcendental
+// + 2 plain instructions (was 11 + 4 + 10).  Same polynomial, so the same 1.5e-7 bound; v = +inf gives NaN (inf * 0) where the old form gave
+// inf -- the f16x3 kernels never produce an infinity (out-of-range values are NaN already).
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
-  const f32x2 x = (f32x2){fabsf(v.x), fabsf(v.y)} * 0.70710678118654752440f;
-  const f32x2 d = x * 0.3275911f + 1.0f;
+  const f32x2 a = {fabsf(v.x), fabsf(v.y)};
+  const f32x2 d = a * 0.23164189f + 1.0f;                                         // 0.3275911 / sqrt(2)
   const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  f32x2 p = t * 1.061405429f + -1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t + -0.284496736f;
-  p = p * t + 0.254829592f;
-  const f32x2 nx2 = -x * x;
-  const f32x2 ex = {__expf(nx2.x), __expf(nx2.y)};
-  const f32x2 e = p * t * ex;
-  const f32x2 w = {v.x >= 0.f ? 2.0f - e.x : e.x, v.y >= 0.f ? 2.0f - e.y : e.y};
-  return v * 0.5f * w;
+  f32x2 p = t * 0.5307027145f + -0.7265760135f;
+  p = p * t + 0.7107068705f;
+  p = p * t + -0.142248368f;
+  p = p * t + 0.127414796f;
+  const f32x2 u = a * 0.8493218003f;                                              // sqrt(log2(e) / 2)
+  const f32x2 s = -u * u;
+  const f32x2 ex = {__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)};
+  const f32x2 q = p * t * ex;
+  const f32x2 r = (v + a) * 0.5f;                                                 // max(v, 0), exactly, in two packed instructions (fmaxf costs four plain ones per pair)
+  return r - a * q;
 }
 
 // One thread per 16-byte unit of the packed image (see the layout above); rows N .. Np - 1 of the last 128-row tile are zero.

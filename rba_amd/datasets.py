@@ -38,6 +38,12 @@ def _to_item(image, label):
     return torch.from_numpy(np.ascontiguousarray(image.transpose(2, 0, 1))), torch.from_numpy(label.astype(np.int64))
 
 
+# PIL hands numpy a read-only buffer; the raw item is only ever READ (copied into pinned memory / to the device): silence torch's one-time
+# "array is not writable" note instead of paying a 6 MB copy per image for it
+import warnings as _warnings
+_warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+
+
 def _to_raw_item(image, label):
     """The same sample as the decoders left it: image uint8 [H,W,3] (channels last), label uint8 [H,W].  For loaders that move the
     transpose to the GPU and never need int64 labels (evaluate_ood.run_evaluations): three 6-16 MB host passes per image less."""
