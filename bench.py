@@ -881,7 +881,9 @@ def main():
                                                budget_scale=args.cpu_budget, mode=args.cpu_baseline, threads=args.cpu_threads)
         # where the command's wall time goes: the timed region is short by contract (K steps); the CPU baseline is most of the rest
         res["wall_time_s"] = {"command_total": time.perf_counter() - t_cmd0, "timed_region": elapsed,
-                              "setup_warmup_probes_gpu_phase": t_gpu_done - t_cmd0 - elapsed, "cpu_baseline": time.perf_counter() - t_gpu_done,
+                              "sustained_leg": sustained["seconds"] if sustained is not None else 0.0,
+                              "setup_warmup_probes_gpu_phase": t_gpu_done - t_cmd0 - elapsed - (sustained["seconds"] if sustained is not None else 0.0),
+                              "cpu_baseline": time.perf_counter() - t_gpu_done,
                               "gpu_span_of_timed_region_s": gpu_busy_s}
         print(json.dumps(res), flush=True)
     if dist is not None:

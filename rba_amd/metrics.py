@@ -12,19 +12,28 @@ One global descending sort (rocPRIM radix sort on the GPU), integer cumsums, flo
 import torch
 
 
+def _sorted_curve(scores: torch.Tensor, labels: torch.Tensor):
+    """-> (fps, tps, thresholds) at each distinct threshold, descending score order.  One key-value sort (the order inside a run of equal scores
+    does not matter: the counts are read at the LAST index of every run), the cumulative positives in int32 while they fit -- at 288 images of
+    1024 x 2048 this is 6 x 10^8 pairs, and an int64 gather + cumsum of them was a third of the metric's time (round 4)."""
+    scores = scores.reshape(-1)
+    labels = labels.reshape(-1)
+    s, order = torch.sort(scores, descending=True)
+    n = s.numel()
+    small = n < 2 ** 31 - 1
+    y = labels[order].to(torch.int32 if small else torch.int64)
+    del order
+    distinct = torch.nonzero(s[1:] != s[:-1]).reshape(-1)
+    idx = torch.cat([distinct, torch.tensor([n - 1], device=s.device, dtype=distinct.dtype)])
+    tps = torch.cumsum(y, 0, dtype=y.dtype)[idx].to(torch.int64)
+    fps = 1 + idx - tps
+    return fps, tps, s[idx]
+
+
 @torch.no_grad()
 def binary_clf_curve(scores: torch.Tensor, labels: torch.Tensor):
     """fps, tps (int64) at each distinct threshold, descending score order."""
-    scores = scores.reshape(-1)
-    labels = labels.reshape(-1)
-    order = torch.argsort(scores, descending=True, stable=True)
-    s = scores[order]
-    y = labels[order].to(torch.int64)
-    n = s.numel()
-    distinct = torch.nonzero(s[1:] != s[:-1]).reshape(-1)
-    idx = torch.cat([distinct, torch.tensor([n - 1], device=s.device, dtype=distinct.dtype)])
-    tps = torch.cumsum(y, 0)[idx]
-    fps = 1 + idx - tps
+    fps, tps, _ = _sorted_curve(scores, labels)
     return fps, tps
 
 
@@ -62,12 +71,7 @@ def ood_metrics(scores: torch.Tensor, labels: torch.Tensor) -> dict:
 def roc_at_tpr95(scores: torch.Tensor, labels: torch.Tensor):
     """OODEvaluator.calculate_auroc (support.py:247-257): (auc of roc_curve, fpr and threshold of the first ROC point with
     tpr > 0.95; if there is none: fpr 0 and the last threshold).  roc_curve's first threshold is +inf (scikit-learn >= 1.3)."""
-    scores, labels = scores.reshape(-1), labels.reshape(-1)
-    fps, tps = binary_clf_curve(scores, labels)
-    order = torch.argsort(scores, descending=True, stable=True)
-    s = scores[order]
-    distinct = torch.nonzero(s[1:] != s[:-1]).reshape(-1)
-    thr = s[torch.cat([distinct, torch.tensor([s.numel() - 1], device=s.device, dtype=distinct.dtype)])]
+    fps, tps, thr = _sorted_curve(scores, labels)
     P, Nn = tps[-1].double(), fps[-1].double()
     if fps.numel() > 2:
         d2f = fps[2:] - 2 * fps[1:-1] + fps[:-2]
