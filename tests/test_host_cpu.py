@@ -385,3 +385,23 @@ def test_emitted_isa_has_no_unfenced_16bit_destination_hazards():
     assert not isa_hazards.scan(mk(hi, "ds_write_b128 v2, v[24:27]"))["D"]        # not a VALU reader
     assert len(isa_hazards.scan(mk("v_rcp_f32_e32 v4, v1", "v_mul_f32_e32 v5, v4, v4"))["T"]) == 1
     assert not isa_hazards.scan(mk("v_rcp_f32_e32 v4, v1", "v_exp_f32_e32 v5, v4"))["T"]
+
+
+def test_bench_names_its_workload_and_configs2_flag():
+    """VERDICT r3 #5d: `--gpus 8 --images-per-gpu 2` is exactly BASELINE configs[2] (batch 16 sharded 8x) and the line says so; any other shape of the
+    run is labelled as what it is.  The flag is an alias of --streams (one image per stream per step)."""
+    import bench
+    assert "configs[2]: batch 16" in bench.baseline_config("swin_b_1dl", 1024, 2048, 8, 2)
+    assert "configs[1]" in bench.baseline_config("swin_b_1dl", 1024, 2048, 1, 3) and "configs[2] exactly = --gpus 8 --images-per-gpu 2" in bench.baseline_config("swin_b_1dl", 1024, 2048, 8, 3)
+    assert bench.baseline_config("swin_l_1dl", 1024, 2048) == "BASELINE.json configs[3]" and bench.baseline_config("swin_b_9dl", 720, 1280) == "BASELINE.json configs[4]"
+    assert bench.baseline_config("swin_b_1dl", 512, 512) == "not a BASELINE.json configuration"
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8", "--images-per-gpu", "2"]
+        a = bench.parse()
+        assert a.streams == 2 and a.gpus == 8 and a.graph == 1 and a.cpu_baseline == "quick" and a.sustain == 5.0
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+        assert a.streams == 3 and a.gpus == 1 and a.steps == 20 and a.warmup == 3
+    finally:
+        sys.argv = old
