@@ -243,6 +243,18 @@ extern "C" int rba_split_linear_h3_timing(const float* x, const void* weight_pac
   else if (probe == 1400)
     hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, true, false, 1, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias,
                        out, (int)M, N, K, (int)MT, NT, dbg);
+  else if (probe == 1500)                      // round 4: the fc1 launch form (GELU, split image in and out), 128 x 128 tiles
+    hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, true, false, 2, true, true, 1>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp,
+                       bias, out, (int)M, N, K, (int)MT, NT, dbg);
+  else if (probe == 1600) {                    // ... and its 256 x 128 / 8-wave form (RS = 2)
+    const int64_t MT2 = (M + 255) / 256;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<1, 0, true, false, 2, true, true, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, (hipStream_t)stream,
+                       x, wp, bias, out, (int)M, N, K, (int)MT2, NT, dbg);
+  } else if (probe == 1700) {                  // RS = 2, fp32 rows out, no activation (the qkv launch form)
+    const int64_t MT2 = (M + 255) / 256;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, true, false, 2, true, false, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, (hipStream_t)stream,
+                       x, wp, bias, out, (int)M, N, K, (int)MT2, NT, dbg);
+  }
   else if (probe == 1001)
     hipLaunchKernelGGL((split_linear_h3l_kernel<1, 4, 0, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, (hipStream_t)stream, x, wp, bias, out,
                        (int)M, N, K, (int)MT, NT, dbg, ConvShape{0, 0, 0});

@@ -19,11 +19,13 @@ fn.restype = ctypes.c_int
 M, N, K = (int(v) for v in sys.argv[1:4])
 probe = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 x = torch.randn(M, K, device="cuda")
+if probe in (1300, 1400, 1500, 1600, 1700):          # launch forms that read a split image
+    x = ops.SplitActivations.pack(x).data
 w = torch.randn(N, K, device="cuda") * K ** -0.5
 b = torch.randn(N, device="cuda")
 p3 = ops.split_weight(w, mode="f16x3")
 out = torch.empty(M, N, device="cuda")
-nwg = ((M + 127) // 128) * ((N + 127) // 128)
+nwg = ((M + (255 if probe in (1600, 1700) else 127)) // (256 if probe in (1600, 1700) else 128)) * ((N + 127) // 128)
 dbg = torch.zeros(nwg * 6, dtype=torch.int64, device="cuda")
 for _ in range(3):
     rc = fn(x.data_ptr(), p3.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, probe, dbg.data_ptr(), torch.cuda.current_stream().cuda_stream)
