@@ -722,3 +722,40 @@ def test_concurrent_streams_hint_changes_launch_forms_not_bits():
         rs.value = 0
     assert ops.set_concurrent_streams(1) == 1
     assert torch.equal(base, hinted) and torch.equal(base, off)
+
+
+def test_model_with_captured_graphs_can_be_deep_copied_and_never_thrashes():
+    """hipGraphs cannot be copied -- copy.deepcopy(model) leaves them behind and the copy captures its own; keys that were only
+    seen once never evict a captured graph; a model whose image shapes churn faster than graphs are replayed stops capturing."""
+    import copy
+    model, a, _ = build("tiny3", 0)
+    g = torch.Generator().manual_seed(5)
+    im = torch.randint(0, 256, (3, 64, 96), generator=g, dtype=torch.uint8).cuda()
+    want = model.rba_scores([{"image": im}])[0].clone()
+    for _ in range(3):
+        assert torch.equal(model.rba_scores([{"image": im}])[0], want)
+    assert model.live_graphs() == 1
+    for k_ in range(2 * model.GRAPH_MAX):                                  # one-off shapes: placeholders only, the captured graph stays
+        model.rba_scores([{"image": torch.randint(0, 256, (3, 32 + 4 * k_, 48), generator=g, dtype=torch.uint8).cuda()}])
+    assert model.live_graphs() == 1
+    assert torch.equal(model.rba_scores([{"image": im}])[0], want)
+    twin = copy.deepcopy(model)
+    assert twin.live_graphs() == 0 and model.live_graphs() == 1
+    for _ in range(3):
+        assert torch.equal(twin.rba_scores([{"image": im}])[0], want)
+    assert twin.live_graphs() == 1
+    # churn: every shape comes exactly twice (captured, replayed once, evicted before it pays) -> the model gives up capturing
+    churn, _, _ = build("tiny3", 0)
+    churn.GRAPH_MAX = 2
+    shapes = [(32 + 4 * k_, 64) for k_ in range(2 * churn.GRAPH_MAX + churn.GRAPH_THRASH_MAX + 3)]
+    for hw in shapes:
+        x = torch.randint(0, 256, (3,) + hw, generator=g, dtype=torch.uint8).cuda()
+        churn.rba_scores([{"image": x}])
+        churn.rba_scores([{"image": x}])
+    assert churn.__dict__.get("_graph_thrash", 0) >= churn.GRAPH_THRASH_MAX and churn.live_graphs() <= churn.GRAPH_MAX
+    n_before = churn.live_graphs()
+    x = torch.randint(0, 256, (3, 200, 64), generator=g, dtype=torch.uint8).cuda()
+    churn.rba_scores([{"image": x}]); churn.rba_scores([{"image": x}]); churn.rba_scores([{"image": x}])
+    assert churn.live_graphs() == n_before                                  # no new capture any more
+    churn.drop_graphs()
+    assert churn.__dict__.get("_graph_thrash", 0) == 0
