@@ -61,77 +61,87 @@ __global__ void token_linear_pack_kernel(const float* __restrict__ w, rba_u32x4*
   }
 }
 
-// CTW: 16-column tiles per wave (N <= 16 CTW TLW).  LN: residual + LayerNorm epilogue (single problem).
+// CTW: 16-column tiles per wave (N <= 16 CTW TLW).  LN: residual + LayerNorm epilogue (single problem).  RT: 16-row token tiles per workgroup
+// (1 or 2; with 2 every weight fragment a wave loads feeds two row tiles: half the workgroups, half the weight bytes pulled from L2).
 constexpr int TLW = 4;
-template <int CTW, bool LN>
+template <int CTW, bool LN, int RT = 1>
 __global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __restrict__ x, TlProblems ps, const float* __restrict__ residual,
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K) {
   const TlProblem p = blockIdx.y == 0 ? ps.p[0] : (blockIdx.y == 1 ? ps.p[1] : ps.p[2]);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = lane & 15, kb = lane >> 4;
-  const int row0 = blockIdx.x * 16;
-  const int row = min(row0 + t, M - 1);
+  const int row0 = blockIdx.x * (16 * RT);
+  int row[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) row[rt] = min(row0 + 16 * rt + t, M - 1);
   const int KB = K >> 5, NT = (p.N + 15) >> 4;
   const int nt0 = wave * CTW;                                                     // this wave's first column tile
-  const float* xa = x + (int64_t)row * K + 8 * kb;
-  const float* xb = p.x_add ? p.x_add + (int64_t)row * K + 8 * kb : nullptr;
-  const bool has_add = xb != nullptr;                                             // workgroup-uniform
+  const bool has_add = p.x_add != nullptr;                                        // workgroup-uniform
   const rba_u32x4* wl = p.wp + lane;
 
-  tl_f32x4 accm[CTW], accl[CTW];
+  tl_f32x4 accm[RT][CTW], accl[RT][CTW];
 #pragma unroll
-  for (int i = 0; i < CTW; ++i) accm[i] = accl[i] = (tl_f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < CTW; ++i) accm[rt][i] = accl[rt][i] = (tl_f32x4){0.f, 0.f, 0.f, 0.f};
 
   // NS-deep register ring: the loads of block b + NS - 1 are issued before block b is consumed.  Every workgroup streams the whole packed
   // weight (256 KiB at K = N = 256, 1 MiB at K = 1 024) and all workgroups walk the same lines at the same time.  Measured at 2 048 rows
   // (profiles/r04_token_linear.txt; two-problem launch / K = 256 + LayerNorm / K = 1 024 + LayerNorm): one block of look-ahead 12 / 18 (mean of
-  // both LayerNorm forms) us; FOUR stages 10.6 / 9.6 / 20.4 us (the product); eight waves x six stages (192 KB in flight per workgroup)
+  // both LayerNorm forms) us; FOUR stages 10.6 / 9.6 / 20.4 us; eight waves x six stages (192 KB in flight per workgroup)
   // 11.3 / 9.6 / 25.6 us -- more bytes in flight do not help, so the launch is not latency-bound any more but bound by the L2 serving the
   // same weight lines to 128 workgroups at once; cutting the columns into groups (4x the workgroups, a quarter of the weight each) is
   // slower still (23 us at K = 1 024: three MFMAs per 2 KB of loads).  At K = 1 024 the library GEMM + LayerNorm pair it replaces took 16 us.
-  constexpr int NS = 4;
-  f32x4 a[NS][2], ad[NS][2];
+  constexpr int NS = RT == 2 ? 3 : 4;
+  f32x4 a[NS][RT][2], ad[NS][RT][2];
   rba_u32x4 wf[NS][CTW][2];
   auto loads = [&](int b, int s) {
     if (b >= KB) return;                                                            // wave-uniform
-    const int bc = b;
-    a[s][0] = *reinterpret_cast<const f32x4*>(xa + 32 * bc);
-    a[s][1] = *reinterpret_cast<const f32x4*>(xa + 32 * bc + 4);
-    if (has_add) {
-      ad[s][0] = *reinterpret_cast<const f32x4*>(xb + 32 * bc);
-      ad[s][1] = *reinterpret_cast<const f32x4*>(xb + 32 * bc + 4);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float* xa = x + (int64_t)row[rt] * K + 8 * kb + 32 * b;
+      a[s][rt][0] = *reinterpret_cast<const f32x4*>(xa);
+      a[s][rt][1] = *reinterpret_cast<const f32x4*>(xa + 4);
+      if (has_add) {
+        const float* xb = p.x_add + (int64_t)row[rt] * K + 8 * kb + 32 * b;
+        ad[s][rt][0] = *reinterpret_cast<const f32x4*>(xb);
+        ad[s][rt][1] = *reinterpret_cast<const f32x4*>(xb + 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < CTW; ++i) {
       const int nt = min(nt0 + i, NT - 1);                                        // tiles beyond N: a valid address, result unused
-      const rba_u32x4* src = wl + ((int64_t)nt * KB + bc) * 128;
+      const rba_u32x4* src = wl + ((int64_t)nt * KB + b) * 128;
       wf[s][i][0] = src[0];
       wf[s][i][1] = src[64];
     }
   };
   auto compute = [&](int s) {
-    f32x4 u = a[s][0], v = a[s][1];
-    if (has_add) {
-      u = u + ad[s][0];
-      v = v + ad[s][1];
-    }
-    rba_u32x4 hp, lp;
-    uint32_t h_, l_;
-    rba_split_f16x2(u.x, u.y, h_, l_); hp.x = h_; lp.x = l_;
-    rba_split_f16x2(u.z, u.w, h_, l_); hp.y = h_; lp.y = l_;
-    rba_split_f16x2(v.x, v.y, h_, l_); hp.z = h_; lp.z = l_;
-    rba_split_f16x2(v.z, v.w, h_, l_); hp.w = h_; lp.w = l_;
-    const tl_f16x8 xh = __builtin_bit_cast(tl_f16x8, hp), xl = __builtin_bit_cast(tl_f16x8, lp);
 #pragma unroll
-    for (int i = 0; i < CTW; ++i) {
-      const tl_f16x8 wh = __builtin_bit_cast(tl_f16x8, wf[s][i][0]);
-      accm[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, accm[i], 0, 0, 0);
-    }
+    for (int rt = 0; rt < RT; ++rt) {
+      f32x4 u = a[s][rt][0], v = a[s][rt][1];
+      if (has_add) {
+        u = u + ad[s][rt][0];
+        v = v + ad[s][rt][1];
+      }
+      rba_u32x4 hp, lp;
+      uint32_t h_, l_;
+      rba_split_f16x2(u.x, u.y, h_, l_); hp.x = h_; lp.x = l_;
+      rba_split_f16x2(u.z, u.w, h_, l_); hp.y = h_; lp.y = l_;
+      rba_split_f16x2(v.x, v.y, h_, l_); hp.z = h_; lp.z = l_;
+      rba_split_f16x2(v.z, v.w, h_, l_); hp.w = h_; lp.w = l_;
+      const tl_f16x8 xh = __builtin_bit_cast(tl_f16x8, hp), xl = __builtin_bit_cast(tl_f16x8, lp);
 #pragma unroll
-    for (int i = 0; i < CTW; ++i) {
-      const tl_f16x8 wh = __builtin_bit_cast(tl_f16x8, wf[s][i][0]), wlo = __builtin_bit_cast(tl_f16x8, wf[s][i][1]);
-      accl[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh, accl[i], 0, 0, 0);
-      accl[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, accl[i], 0, 0, 0);
+      for (int i = 0; i < CTW; ++i) {
+        const tl_f16x8 wh = __builtin_bit_cast(tl_f16x8, wf[s][i][0]);
+        accm[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, accm[rt][i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < CTW; ++i) {
+        const tl_f16x8 wh = __builtin_bit_cast(tl_f16x8, wf[s][i][0]), wlo = __builtin_bit_cast(tl_f16x8, wf[s][i][1]);
+        accl[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh, accl[rt][i], 0, 0, 0);
+        accl[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, accl[rt][i], 0, 0, 0);
+      }
     }
   };
 #pragma unroll
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __r
     }
   }
 
-  // lane: token row t, channels n = 16 (nt0 + i) + 4 kb + r
-  float val[CTW][4];
+  // lane: token rows row0 + 16 rt + t, channels n = 16 (nt0 + i) + 4 kb + r
+  float val[RT][CTW][4];
 #pragma unroll
   for (int i = 0; i < CTW; ++i) {
     const int n = 16 * (nt0 + i) + 4 * kb;
@@ -161,24 +171,29 @@ __global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __r
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = fmaf(accl[i][r], 0.00048828125f, accm[i][r]) + bv[r];
-      if (p.act == 2) v = fmaxf(v, 0.f);
-      val[i][r] = ok ? v : 0.f;
-    }
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaf(accl[rt][i][r], 0.00048828125f, accm[rt][i][r]) + bv[r];
+        if (p.act == 2) v = fmaxf(v, 0.f);
+        val[rt][i][r] = ok ? v : 0.f;
+      }
   }
-  const bool rowok = row0 + t < M;
   if (!LN) {
 #pragma unroll
-    for (int i = 0; i < CTW; ++i) {
-      const int n = 16 * (nt0 + i) + 4 * kb;
-      if (rowok && nt0 + i < NT) {
-        if (n + 3 < p.N) {
-          *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.ld + n) = (f32x4){val[i][0], val[i][1], val[i][2], val[i][3]};
-        } else {
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool rowok = row0 + 16 * rt + t < M;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) p.out[(int64_t)row * p.ld + n + r] = val[i][r];
+      for (int i = 0; i < CTW; ++i) {
+        const int n = 16 * (nt0 + i) + 4 * kb;
+        if (rowok && nt0 + i < NT) {
+          if (n + 3 < p.N) {
+            *reinterpret_cast<f32x4*>(p.out + (int64_t)row[rt] * p.ld + n) = (f32x4){val[rt][i][0], val[rt][i][1], val[rt][i][2], val[rt][i][3]};
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) p.out[(int64_t)row[rt] * p.ld + n + r] = val[rt][i][r];
+          }
         }
       }
     }
@@ -186,60 +201,74 @@ __global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __r
   }
   // ---- residual + LayerNorm over the complete row (N % 16 == 0): s = residual + (x W^T + bias), y = (s - mean) rstd g + b, the
   // statistics as in rba_add_layer_norm_f32 (mean first, then the centred sum of squares)
-  __shared__ float red[2][TLW][16];
-  float s1 = 0.f;
+  __shared__ float red[2][TLW][RT][16];
+  float s1[RT];
 #pragma unroll
-  for (int i = 0; i < CTW; ++i) {
-    if (nt0 + i < NT) {
-      const int n = 16 * (nt0 + i) + 4 * kb;
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * p.N + n);          // LN form: ld == N
+  for (int rt = 0; rt < RT; ++rt) {
+    s1[rt] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        val[i][r] = rv[r] + val[i][r];
-        s1 += val[i][r];
+    for (int i = 0; i < CTW; ++i) {
+      if (nt0 + i < NT) {
+        const int n = 16 * (nt0 + i) + 4 * kb;
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + (int64_t)row[rt] * p.N + n);          // LN form: ld == N
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          val[rt][i][r] = rv[r] + val[rt][i][r];
+          s1[rt] += val[rt][i][r];
+        }
       }
     }
+    s1[rt] += __shfl_xor(s1[rt], 16, RBA_WAVE);
+    s1[rt] += __shfl_xor(s1[rt], 32, RBA_WAVE);
+    if (kb == 0) red[0][wave][rt][t] = s1[rt];
   }
-  s1 += __shfl_xor(s1, 16, RBA_WAVE);
-  s1 += __shfl_xor(s1, 32, RBA_WAVE);
-  if (kb == 0) red[0][wave][t] = s1;
   __syncthreads();
-  float tot = 0.f;
+  float mean[RT], s2[RT];
 #pragma unroll
-  for (int w_ = 0; w_ < TLW; ++w_) tot += red[0][w_][t];
-  const float mean = tot / (float)p.N;
-  float s2 = 0.f;
+  for (int rt = 0; rt < RT; ++rt) {
+    float tot = 0.f;
 #pragma unroll
-  for (int i = 0; i < CTW; ++i) {
-    if (nt0 + i < NT) {
+    for (int w_ = 0; w_ < TLW; ++w_) tot += red[0][w_][rt][t];
+    mean[rt] = tot / (float)p.N;
+    s2[rt] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = val[i][r] - mean;
-        s2 = fmaf(d, d, s2);
+    for (int i = 0; i < CTW; ++i) {
+      if (nt0 + i < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = val[rt][i][r] - mean[rt];
+          s2[rt] = fmaf(d, d, s2[rt]);
+        }
       }
     }
+    s2[rt] += __shfl_xor(s2[rt], 16, RBA_WAVE);
+    s2[rt] += __shfl_xor(s2[rt], 32, RBA_WAVE);
+    if (kb == 0) red[1][wave][rt][t] = s2[rt];
   }
-  s2 += __shfl_xor(s2, 16, RBA_WAVE);
-  s2 += __shfl_xor(s2, 32, RBA_WAVE);
-  if (kb == 0) red[1][wave][t] = s2;
   __syncthreads();
-  tot = 0.f;
 #pragma unroll
-  for (int w_ = 0; w_ < TLW; ++w_) tot += red[1][w_][t];
-  const float var = tot / (float)p.N;
-  const float rstd = rsqrtf(var + eps);
+  for (int rt = 0; rt < RT; ++rt) {
+    float tot = 0.f;
 #pragma unroll
-  for (int i = 0; i < CTW; ++i) {
-    if (rowok && nt0 + i < NT) {
-      const int n = 16 * (nt0 + i) + 4 * kb;
-      const f32x4 g = *reinterpret_cast<const f32x4*>(ln_w + n), be = *reinterpret_cast<const f32x4*>(ln_b + n);
-      f32x4 y;
+    for (int w_ = 0; w_ < TLW; ++w_) tot += red[1][w_][rt][t];
+    const float rstd = rsqrtf(tot / (float)p.N + eps);
+    const bool rowok = row0 + 16 * rt + t < M;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) y[r] = (val[i][r] - mean) * rstd * g[r] + be[r];
-      *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.N + n) = y;
+    for (int i = 0; i < CTW; ++i) {
+      if (rowok && nt0 + i < NT) {
+        const int n = 16 * (nt0 + i) + 4 * kb;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(ln_w + n), be = *reinterpret_cast<const f32x4*>(ln_b + n);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = (val[rt][i][r] - mean[rt]) * rstd * g[r] + be[r];
+        *reinterpret_cast<f32x4*>(p.out + (int64_t)row[rt] * p.N + n) = y;
+      }
     }
   }
 }
+
+// tools / tests: 0 = product rule (two row tiles per workgroup for K >= 512 and at least 4 096 rows), 1 = always one row tile, 2 = always two
+extern "C" __attribute__((visibility("default"))) int rba_token_rt = 0;
 
 template <bool LN>
 int launch_token_linear(const float* x, const TlProblems& ps, int nprob, const float* residual, const float* ln_w, const float* ln_b, float eps,
@@ -247,8 +276,13 @@ int launch_token_linear(const float* x, const TlProblems& ps, int nprob, const f
   int nmax = 0;
   for (int i = 0; i < nprob; ++i) nmax = ps.p[i].N > nmax ? ps.p[i].N : nmax;
   const int ctw = (((nmax + 15) >> 4) + TLW - 1) / TLW;
-  const dim3 grid((unsigned)((M + 15) / 16), (unsigned)nprob);
-#define RBA_TL(C) hipLaunchKernelGGL((token_linear_kernel<C, LN>), grid, dim3(64 * TLW), 0, st, x, ps, residual, ln_w, ln_b, eps, M, K)
+  // two row tiles where that still leaves at least 128 workgroups: at 2 048 rows it does not (64 workgroups: 28.6 us against 20.4 with one tile),
+  // at 4 830 rows it does (40.0 -> 30.9 us; profiles/r04_token_linear.txt)
+  const bool two = rba_token_rt == 2 || (rba_token_rt == 0 && K >= 512 && M >= 4096);
+  const dim3 grid((unsigned)((M + (two ? 31 : 15)) / (two ? 32 : 16)), (unsigned)nprob);
+#define RBA_TL(C)                                                                                                                     \
+  if (two) hipLaunchKernelGGL((token_linear_kernel<C, LN, 2>), grid, dim3(64 * TLW), 0, st, x, ps, residual, ln_w, ln_b, eps, M, K);   \
+  else hipLaunchKernelGGL((token_linear_kernel<C, LN, 1>), grid, dim3(64 * TLW), 0, st, x, ps, residual, ln_w, ln_b, eps, M, K)
   switch (ctw) {
     case 1: RBA_TL(1); break;
     case 2: RBA_TL(2); break;

@@ -521,7 +521,8 @@ def test_split_linear_vs_fp64(ops, M, N, K, gelu, has_bias, mode):
 
 @pytest.mark.parametrize("M,N,K,relu,has_bias,has_add", [(2048, 256, 256, False, True, True), (2048, 96, 256, False, True, True), (2048, 256, 1024, False, True, False),
                                                          (4830, 256, 256, True, True, False), (4830, 32, 256, False, False, True), (37, 192, 64, False, True, True),
-                                                         (1, 16, 32, False, True, False), (2048, 100, 96, True, True, False), (301, 256, 160, False, False, False)])
+                                                         (1, 16, 32, False, True, False), (2048, 100, 96, True, True, False), (301, 256, 160, False, False, False),
+                                                         (1001, 192, 544, True, True, True), (17, 256, 512, False, True, False)])
 def test_token_linear_vs_fp64(ops, M, N, K, relu, has_bias, has_add):
     """Row-complete token Linear (csrc/token_linear.hip): act((x + x_add) W^T + b) against fp64 at the level of the fp32 GEMM it replaces,
     ragged M (rows per workgroup = 16), N not a multiple of 16, odd block counts; x_add is added exactly as the separate torch add did."""
@@ -549,7 +550,7 @@ def test_token_linear_vs_fp64(ops, M, N, K, relu, has_bias, has_add):
         ops.token_linear(dev(x), SimpleNamespace(weight=dev(torch.zeros(272, K)), bias=None))     # N > 256
 
 
-@pytest.mark.parametrize("M,C,K", [(2048, 256, 256), (2048, 256, 1024), (4830, 256, 256), (50, 64, 128), (999, 128, 96)])
+@pytest.mark.parametrize("M,C,K", [(2048, 256, 256), (2048, 256, 1024), (4830, 256, 256), (50, 64, 128), (999, 128, 96), (1001, 256, 544), (17, 64, 512)])
 def test_token_linear_residual_layer_norm(ops, M, C, K):
     """norm(residual + Linear(x)) in the Linear's epilogue (msdeformattn.py:134-138): against fp64, and against the unfused composition
     (the same Linear, then rba_add_layer_norm_f32) at fp32 round-off"""
@@ -572,6 +573,18 @@ def test_token_linear_residual_layer_norm(ops, M, C, K):
     assert maxerr(out, unf.cpu()) < 5e-6
     with pytest.raises(RbaHipError):
         ops.token_linear(dev(x), lin, residual=dev(res))                    # residual without norm
+    # both workgroup shapes (one / two 16-row tiles per workgroup: rba_token_rt) give the same rows -- same products, same order
+    import ctypes
+    from rba_amd import _lib
+    rt = ctypes.c_int.in_dll(_lib.load(), "rba_token_rt")
+    try:
+        rt.value = 1
+        one = ops.token_linear(dev(x), lin, residual=dev(res), norm=norm)
+        rt.value = 2
+        two = ops.token_linear(dev(x), lin, residual=dev(res), norm=norm)
+    finally:
+        rt.value = 0
+    assert torch.equal(one, two) and torch.equal(out, one)
 
 
 def test_token_linear_multi(ops):
