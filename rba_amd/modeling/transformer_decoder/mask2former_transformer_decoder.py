@@ -71,8 +71,15 @@ class _MHAParams(nn.Module):
             return _qlinear(o, self.out_proj.weight)
         if key_add is not None:
             key = key + key_add
-        # self-attention: key / value are the (<= 128) queries themselves -> the skinny kernel too (hipBLASLt takes 33 us for
-        # 100 x 256 x 256); cross-attention: thousands of memory tokens -> library GEMM
+        if B * S > 128:
+            # a memory level beyond the row-complete kernel's range (C5's 14 400-token level): the key / value projections are ordinary token
+            # Linears -> K6 where it pays (ops.linear decides; the packed planes are cached on the views), not a library GEMM
+            lk, lv = self._kv_views()
+            k = ops.linear(key.contiguous(), lk).view(B, S, nH, E // nH)
+            v = ops.linear(value.contiguous(), lv).view(B, S, nH, E // nH)
+            o = ops.masked_xattn(q, k, v, mask_logits)
+            return _qlinear(o, self.out_proj.weight)
+        # self-attention: key / value are the (<= 128) queries themselves -> the skinny kernel too (hipBLASLt takes 33 us for 100 x 256 x 256)
         k = _qlinear(key, w[E:2 * E], b[E:2 * E]).view(B, S, nH, E // nH)
         v = _qlinear(value, w[2 * E:], b[2 * E:]).view(B, S, nH, E // nH)
         o = ops.masked_xattn(q, k, v, mask_logits)
