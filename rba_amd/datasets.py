@@ -51,6 +51,8 @@ def _to_raw_item(image, label):
 
 
 class RoadAnomaly(Dataset):
+    KIND = "road_anomaly"
+
     def __init__(self, dataset_root):
         with open(os.path.join(dataset_root, "frame_list.json")) as f:
             names = json.load(f)
@@ -72,8 +74,14 @@ class RoadAnomaly(Dataset):
     def raw_item(self, index):
         return _to_raw_item(*self._decode(index))
 
+    def decode_spec(self, index):
+        """(kind, image path, label path): what a decode worker process needs to produce raw_item(index) (rba_amd._decode_worker)"""
+        return self.KIND, self.images[index], self.labels[index]
+
 
 class FishyscapesLAF(Dataset):
+    KIND = "fishyscapes_laf"
+
     def __init__(self, dataset_root):
         labels_path = os.path.join(dataset_root, "fishyscapes_lostandfound")
         files = sorted(os.listdir(labels_path))
@@ -92,6 +100,10 @@ class FishyscapesLAF(Dataset):
     def raw_item(self, index):
         return _to_raw_item(*self._decode(index))
 
+    def decode_spec(self, index):
+        """(kind, image path, label path): what a decode worker process needs to produce raw_item(index) (rba_amd._decode_worker)"""
+        return self.KIND, self.images[index], self.labels[index]
+
 
 _FACTORIES = {
     "road_anomaly": lambda root: RoadAnomaly(os.path.join(root, "RoadAnomaly", "RoadAnomaly_jpg")),
@@ -109,6 +121,123 @@ def get_dataset(name, datasets_folder):
     if name not in _FACTORIES:
         raise KeyError(f"unknown dataset {name!r}; available: {available_datasets()}")
     return _FACTORIES[name](datasets_folder)
+
+
+def decode_spec_of(dataset):
+    """index -> (kind, image path, label path) for this module's readers and torch Subsets of them; None for anything else"""
+    if hasattr(dataset, "decode_spec"):
+        return dataset.decode_spec
+    from torch.utils.data import Subset
+    if isinstance(dataset, Subset):
+        inner = decode_spec_of(dataset.dataset)
+        if inner is not None:
+            return lambda i: inner(dataset.indices[i])
+    return None
+
+
+class ProcessDecoder:
+    """Decode worker PROCESSES for datasets that offer `decode_spec` (this module's readers): `n` children started with subprocess
+    (`python -m rba_amd._decode_worker`: numpy + Pillow only -- not forks of the process that holds the model and its HIP context); a
+    sample goes to whichever worker is free, comes back through a file on /dev/shm, and the samples are yielded IN ORDER as
+    raw items (image uint8 [H,W,3], label uint8 [H,W]), page-locked when `pin`.  Why processes at all: decode THREADS share the interpreter
+    lock with the thread that launches the GPU work -- beyond ~8 of them the evaluator gets slower, not faster (profiles/r04_evaluator_288.json)."""
+
+    def __init__(self, n):
+        import subprocess
+        import sys
+        import tempfile
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        self.tmp = tempfile.mkdtemp(prefix="rba_decode_", dir=base)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+        self.stats = {"items": 0, "wait_worker_s": 0.0, "round_trip_s": 0.0, "child_decode_s": 0.0, "child_write_s": 0.0, "take_s": 0.0}
+        self.procs = [subprocess.Popen([sys.executable, "-m", "rba_amd._decode_worker", self.tmp], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       text=True, bufsize=1, env=env) for _ in range(max(1, int(n)))]
+
+    def close(self):
+        import shutil
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:       # noqa: BLE001
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:       # noqa: BLE001
+                p.kill()
+        shutil.rmtree(self.tmp, ignore_errors=True)
+        self.procs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def items(self, dataset, indices, depth=None, pin=False):
+        """raw items of dataset[indices] (`dataset`: one with `decode_spec`, or a Subset of one), in order; each sample is handed to a free worker by one of this process's helper threads,
+        which then reads the answer file and page-locks it (file read and memcpy run without the interpreter lock)"""
+        import itertools
+        import queue
+        import time
+        free = queue.Queue()
+        for p in self.procs:
+            free.put(p)
+        tags = itertools.count()
+        st = self.stats
+
+        spec = decode_spec_of(dataset)
+        if spec is None:
+            raise TypeError(f"{type(dataset).__name__} offers no decode_spec(index): the process loader needs file paths, not a __getitem__")
+
+        def get(i):
+            kind, ip, lp = spec(i)
+            t0 = time.perf_counter()
+            p = free.get()
+            tag = str(next(tags))                           # unique per request: the answer file's name
+            t1 = time.perf_counter()
+            try:
+                p.stdin.write(f"{tag}\t{kind}\t{ip}\t{lp}\n")
+                p.stdin.flush()
+                line = p.stdout.readline()
+            finally:
+                free.put(p)
+            t2 = time.perf_counter()
+            if not line:
+                raise RuntimeError(f"decode worker exited (sample {i})")
+            f = line.rstrip("\n").split("\t")
+            if f[0] != tag or f[1] == "ERR":
+                raise RuntimeError(f"decode worker: sample {i}: {' '.join(f[1:])}")
+            h, w, path = int(f[1]), int(f[2]), f[3]
+            n = 4 * h * w
+            try:
+                return self._take(path, n, h, w, pin, i)
+            finally:
+                t3 = time.perf_counter()
+                st["items"] += 1
+                st["wait_worker_s"] += t1 - t0
+                st["round_trip_s"] += t2 - t1
+                st["child_decode_s"] += float(f[4]) * 1e-3
+                st["child_write_s"] += float(f[5]) * 1e-3
+                st["take_s"] += t3 - t2
+
+        n = len(self.procs)
+        yield from _ahead(get, indices, n + max(2, n // 2), depth or 3 * n)
+
+    @staticmethod
+    def _take(path, n, h, w, pin, i):
+        """the answer file's bytes as (image [H,W,3], label [H,W]) uint8 views of one buffer (page-locked when `pin`); the file is removed"""
+        if pin:
+            buf = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            with open(path, "rb", buffering=0) as fh:
+                got = fh.readinto(buf.numpy())
+            if got != n:
+                raise RuntimeError(f"decode worker: sample {i}: short answer file ({got} of {n} bytes)")
+        else:
+            buf = torch.from_numpy(np.fromfile(path, dtype=np.uint8))
+        os.unlink(path)
+        return buf[: 3 * h * w].view(h, w, 3), buf[3 * h * w:].view(h, w)
 
 
 def prefetch(dataset, indices, num_threads=4, depth=None, pin=False, label_dtype=None, raw=False):

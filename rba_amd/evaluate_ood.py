@@ -95,7 +95,10 @@ SCORE_FUNCS = {"rba": get_RbA, "pebal": get_energy, "energy": get_energy, "neg_l
 def build_parser():
     p = argparse.ArgumentParser(description="OOD Evaluation (rba_amd)")
     p.add_argument("--batch_size", type=int, default=1)
-    p.add_argument("--num_workers", type=int, default=8, help="image-decoding threads (the reference: DataLoader workers)")
+    p.add_argument("--num_workers", type=int, default=8, help="image-decoding threads / processes (the reference: DataLoader workers)")
+    p.add_argument("--loader", choices=("threads", "processes"), default="threads",
+                   help="decode in threads of this process, or in `--num_workers` child processes (rba_amd._decode_worker: numpy + Pillow "
+                        "only, started with subprocess -- not forks of this process); same samples, same order")
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--out_path", type=str, default="results")
     p.add_argument("--verbose", type=lambda v: str(v).lower() not in ("0", "false", "no", ""), default=True)
@@ -194,7 +197,28 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     nw = max(0, int(args.num_workers))
     # batch-1 items.  On a HIP device the decode threads hand the image over as the decoder left it (uint8 [1,H,W,3]; the transpose to [3,H,W]
     # is one 6 MB copy on the GPU instead of a strided host pass per image) with uint8 labels; on the CPU path [1,3,H,W] as the reference yields
-    loader = (tuple(t[None] for t in item) for item in prefetch(dataset, mine, nw, pin=on_gpu and nw > 0, label_dtype=torch.uint8, raw=on_gpu))
+    from .datasets import decode_spec_of
+    use_procs = getattr(args, "loader", "threads") == "processes" and on_gpu and nw > 0 and decode_spec_of(dataset) is not None
+    proc_stats = {}
+    if use_procs:
+        def _from_processes():
+            # main() starts the children once, before the first model is loaded (they import while it loads); a direct caller without
+            # `args.decoder` pays their start-up (~0.25 s) inside its first loop
+            pd = getattr(args, "decoder", None)
+            own = pd is None
+            if own:
+                pd = open_decoder(args)
+            before = dict(pd.stats)
+            try:
+                yield from pd.items(dataset, mine, pin=True)
+            finally:
+                proc_stats.update({n: v - before[n] for n, v in pd.stats.items()})
+                if own:                                     # children ended, /dev/shm directory removed -- also when the loop raises
+                    pd.close()
+        items = _from_processes()
+    else:
+        items = prefetch(dataset, mine, nw, pin=on_gpu and nw > 0, label_dtype=torch.uint8, raw=on_gpu)
+    loader = (tuple(t[None] for t in item) for item in items)
     n_streams = max(1, int(getattr(args, "streams", 3))) if on_gpu else 1
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
@@ -321,9 +345,11 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     if timing is not None:
         n_graphs = (sum(1 for gs in graphed.values() for e in gs.graphs.values() if isinstance(e, tuple)) if graphed else 0)
         n_graphs += model.live_graphs() if hasattr(model, "live_graphs") else 0
-        timing.update(images=k, seconds=dt, images_per_s=(k / dt if dt > 0 else 0.0), num_workers=nw, streams=len(streams),
+        timing.update(images=k, seconds=dt, images_per_s=(k / dt if dt > 0 else 0.0), num_workers=nw, loader=("processes" if use_procs else "threads"), streams=len(streams),
                       hip_graphs=n_graphs, bf16x6_rescored_images=list(fallbacks),
                       host_thread={n: round(v, 3) for n, v in host.items()})
+        if proc_stats.get("items"):
+            timing["decode_processes_ms_per_sample"] = {n: round(v / proc_stats["items"] * 1e3, 2) for n, v in proc_stats.items() if n != "items"}
     if prev_replay is not None:
         model.graph_replay = prev_replay
     if prev_streams is not None:
@@ -339,6 +365,14 @@ class _nullcontext:
 
     def __exit__(self, *a):
         return False
+
+
+def open_decoder(args):
+    """The decode worker processes of `--loader processes` (None for the thread loader): started once per run, shared by every model x dataset"""
+    if getattr(args, "loader", "threads") != "processes" or int(args.num_workers) <= 0 or args.device != "cuda":
+        return None
+    from .datasets import ProcessDecoder
+    return ProcessDecoder(int(args.num_workers))
 
 
 def main(argv=None):
@@ -363,6 +397,20 @@ def main(argv=None):
         models = [m for m in models if m in args.selected_models]
     if not models:
         raise ValueError("Number of models chosen is 0, either the models folder is empty or no models were selected")
+    args.decoder = open_decoder(args)
+    try:
+        _evaluate_models(models, names, args, rank, world, device)
+    finally:
+        if args.decoder is not None:
+            args.decoder.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _evaluate_models(models, names, args, rank, world, device):
+    from pprint import pprint
+    from .datasets import get_dataset
     for model_name in models:
         exp = os.path.join(args.models_folder, model_name)
         store = os.path.join(args.out_path, model_name)
@@ -392,9 +440,6 @@ def main(argv=None):
             Path(store).mkdir(exist_ok=True, parents=True)
             with open(os.path.join(store, "results.pkl"), "wb") as f:
                 pickle.dump(results, f)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

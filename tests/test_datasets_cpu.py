@@ -126,3 +126,41 @@ def test_threaded_view_of_a_process_dataloader_yields_the_same_batches(monkeypat
     monkeypatch.setenv("RBA_LOADER_PROCESSES", "1")
     procs = DataLoader(ds, batch_size=1, num_workers=2)
     assert threaded(procs) is procs
+
+
+def test_process_decoder_yields_the_raw_items_in_order(tmp_path):
+    """`--loader processes`: child processes (rba_amd._decode_worker, numpy + Pillow only) give exactly dataset.raw_item(i), in the order
+    asked, for both readers (RoadAnomaly's 2 -> 1 relabelling included); a missing file is an error in the parent, not a hang; the
+    /dev/shm directory is gone afterwards."""
+    import os
+    import pytest
+    from rba_amd import datasets as DS
+    make_fs_laf(str(tmp_path), n=5)
+    make_road_anomaly(str(tmp_path), n=4)
+    for name in ("fishyscapes_laf", "road_anomaly"):
+        ds = DS.get_dataset(name, str(tmp_path))
+        order = list(range(len(ds)))[::-1] + [0, 0]
+        with DS.ProcessDecoder(3) as pd:
+            tmp = pd.tmp
+            got = list(pd.items(ds, order))
+            assert os.listdir(tmp) == []                                 # every answer file consumed
+        assert not os.path.exists(tmp)
+        assert len(got) == len(order)
+        for i, (x, y) in zip(order, got):
+            xr, yr = ds.raw_item(i)
+            assert x.dtype == torch.uint8 and y.dtype == torch.uint8 and torch.equal(x, xr) and torch.equal(y, yr), (name, i)
+    ds = DS.get_dataset("fishyscapes_laf", str(tmp_path))
+    os.remove(ds.images[2])
+    with DS.ProcessDecoder(2) as pd:
+        with pytest.raises(RuntimeError, match="sample 2"):
+            list(pd.items(ds, range(len(ds))))
+
+
+def test_decode_worker_imports_neither_torch_nor_the_package_ops():
+    """the worker process must stay a plain numpy + Pillow process: no torch import (seconds of start-up per worker), no HIP library"""
+    import subprocess
+    import sys
+    code = "import sys, rba_amd._decode_worker; print(int('torch' in sys.modules), int('rba_amd._lib' in sys.modules))"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.split()
+    assert out == ["0", "0"]

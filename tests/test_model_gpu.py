@@ -278,10 +278,11 @@ def test_evaluate_ood_cli_end_to_end(tmp_path, monkeypatch):
     mtime = (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns
     E.main(argv)
     assert (tmp_path / "results" / "tiny" / "results.pkl").stat().st_mtime_ns == mtime
-    # every pipelining mode of the scoring loop gives the same pooled metrics: decode threads x HIP streams
+    # every pipelining mode of the scoring loop gives the same pooled metrics: decode threads / processes x HIP streams
     for k, extra in enumerate((["--num_workers", "0", "--streams", "1", "--graph", "0"], ["--num_workers", "3", "--streams", "2", "--graph", "0"],
                                ["--num_workers", "2", "--streams", "1", "--graph", "0"], ["--num_workers", "3", "--streams", "3", "--graph", "1"],
-                               ["--num_workers", "0", "--streams", "1", "--graph", "1"])):
+                               ["--num_workers", "0", "--streams", "1", "--graph", "1"],
+                               ["--num_workers", "3", "--streams", "3", "--graph", "1", "--loader", "processes"])):
         out = tmp_path / f"results_{k}"
         E.main(argv[:4] + ["--out_path", str(out), "--verbose", "false"] + extra)
         with open(out / "tiny" / "results.pkl", "rb") as f:

@@ -65,6 +65,10 @@ def main():
                        ("graph_10workers_3streams", ["--num_workers", "10"]),
                        ("graph_12workers_3streams", ["--num_workers", "12"]),
                        ("graph_6workers_3streams", ["--num_workers", "6"]),
+                       ("graph_8processes_3streams", ["--loader", "processes"]),
+                       ("graph_12processes_3streams", ["--loader", "processes", "--num_workers", "12"]),
+                       ("graph_16processes_3streams", ["--loader", "processes", "--num_workers", "16"]),
+                       ("graph_24processes_3streams", ["--loader", "processes", "--num_workers", "24"]),
                        ("serial_like_reference_loop", ["--num_workers", "0", "--streams", "1", "--graph", "0"])):
         if only is not None and tag not in only:
             continue
@@ -73,13 +77,18 @@ def main():
         args = E.build_parser().parse_args(["--models_folder", os.path.join(work, "ckpts"), "--datasets_folder", os.path.join(work, "data"),
                                             "--dataset_mode", "selective", "--selected_datasets", "fishyscapes_laf", "--out_path", out,
                                             "--verbose", "0"] + extra)
+        args.decoder = E.open_decoder(args)                      # as main() does: before the model is loaded
         model = E.get_model(os.path.join(mdir, "config.yaml"), os.path.join(mdir, "model_final.pth"))
         from rba_amd.datasets import get_dataset
         ds = get_dataset("fishyscapes_laf", args.datasets_folder)
         E.run_evaluations(model, torch.utils.data.Subset(ds, [0, 1]), "warm", "fishyscapes_laf", args)       # warm-up: plans, weight planes
         m = E.run_evaluations(model, ds, "swin_b_1dl", "fishyscapes_laf", args, timing=timing)
         res[tag] = {"images_per_s": round(timing["images_per_s"], 2), "seconds": round(timing["seconds"], 3), "metrics": m,
-                    "num_workers": timing["num_workers"], "streams": timing["streams"], "host_thread": timing.get("host_thread"), "hip_graphs": timing.get("hip_graphs")}
+                    "num_workers": timing["num_workers"], "loader": timing.get("loader"), "streams": timing["streams"], "host_thread": timing.get("host_thread"), "hip_graphs": timing.get("hip_graphs")}
+        if "decode_processes_ms_per_sample" in timing:
+            res[tag]["decode_processes_ms_per_sample"] = timing["decode_processes_ms_per_sample"]
+        if args.decoder is not None:
+            args.decoder.close()
         del model
         torch.cuda.empty_cache()
     # ---- the reference's OWN loop with the drop-in classes: evaluate_ood.py:205-235 builds
