@@ -414,6 +414,10 @@ def main():
         import ctypes
         from rba_amd import _lib
         ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs").value = int(os.environ["RBA_K6_RS"])
+    if os.environ.get("RBA_K6_RS_MIN_K"):                     # tools: the 256 x 128 form only for K >= this
+        import ctypes
+        from rba_amd import _lib
+        ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs_min_k").value = int(os.environ["RBA_K6_RS_MIN_K"])
     if os.environ.get("RBA_K6_STAGGER"):                      # tools: late start of every CU's second K6 workgroup (100 MHz ticks)
         import ctypes
         from rba_amd import _lib

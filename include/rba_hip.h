@@ -282,6 +282,16 @@ int rba_patch_im2col_f32(const float* image, float* out, int h, int w, int Hp, i
  * exp(-0.5 (x/sigma)^2), x = -(k-1)/2 .. (k-1)/2.  kernel_size odd, <= 15; in != out. */
 int rba_gaussian_blur_f32(const float* in, float* out, int H, int W, int kernel_size, float sigma, void* stream);
 
+/* Two small steps of the masked decoder (decoder_small.hip):
+ * rba_quad_mean_f32:         out[r][s] = ((v[r][0][s] + v[r][1][s]) + (v[r][2][s] + v[r][3][s])) * 0.25 for v [rows, 4, S]: the bilinear sample at the
+ *                            centre of a 2 x 2 cell = the attention-mask logits of an intermediate decoder layer from mask logits evaluated at the
+ *                            four source pixels of every attention cell (what F.interpolate of the whole map gives, bit for bit;
+ *                            mask2former_transformer_decoder.py:472-489).
+ * rba_softmax_drop_last_f32: prob[r][k] = softmax(logits[r][:])[k] for k < K1 - 1 (F.softmax(mask_cls, -1)[..., :-1], maskformer_model.py:381-383:
+ *                            K1's class probabilities without the "no object" column).  2 <= K1 <= 64. */
+int rba_quad_mean_f32(const float* v, float* out, int64_t rows, int S, void* stream);
+int rba_softmax_drop_last_f32(const float* logits, float* prob, int64_t rows, int K1, void* stream);
+
 /* Open-set panoptic epilogue of the RbA map (MaskFormer.panoptic_inference, maskformer_model.py:454-481):
  * rba_threshold_u8:   out[i] = score[i] > threshold
  * rba_morph3x3_u8:    3x3 box erosion (dilate = 0) or dilation (dilate = 1) of a 0/1 map, out-of-image neighbours ignored

@@ -59,6 +59,8 @@ SIGNATURES = {
     "rba_bn_relu_conv1x1_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp],
     "rba_resample_bilinear_ac_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_gaussian_blur_f32": [_vp, _vp, _i, _i, _i, ctypes.c_float, _vp],
+    "rba_quad_mean_f32": [_vp, _vp, _i64, _i, _vp],
+    "rba_softmax_drop_last_f32": [_vp, _vp, _i64, _i, _vp],
     "rba_threshold_u8": [_vp, _vp, _i64, ctypes.c_float, _vp],
     "rba_morph3x3_u8": [_vp, _vp, _i, _i, _i, _vp],
     "rba_ccl4_roots_i32": [_vp, _vp, _i, _i, _vp],
@@ -78,7 +80,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 183        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 184        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -15,6 +15,7 @@
 extern "C" __attribute__((visibility("default"))) int rba_k6_variant = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_stagger = 0;
 extern "C" __attribute__((visibility("default"))) int rba_k6_occ = 2;
+extern "C" __attribute__((visibility("default"))) int rba_k6_rs_min_k = 512;  // the 256 x 128 form only from this K on (0: any K; see h3p_use_rs2)
 extern "C" __attribute__((visibility("default"))) int rba_k6_rs = 0;       // 256 x 128 / 8-wave form: 0 = by tile count (split_linear_h3.h), 1 = never, 2 = always, 3 = from 64 tiles
 
 // The one piece of caller-set state of the library (include/rba_hip.h): how many streams of this process launch forwards CONCURRENTLY.  With two
@@ -171,7 +172,7 @@ extern "C" int rba_split_linear_f16x3_gelu_split_out(const void* x, int x_is_spl
       default: rc = launch_h3q<H3Q_SPLIT, 1>(x, wp, bias, nullptr, out_frag, M, N, K, st);
     }
   } else if (x_is_split && h3q_supported(M, N, K) &&
-             (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768 && ((M + 127) / 128) * ((N + 127) / 128) > 512 && !h3p_use_rs2(M, N))))
+             (rba_k6_variant == 2 || (rba_k6_variant == 0 && K >= 768 && ((M + 127) / 128) * ((N + 127) / 128) > 512 && !h3p_use_rs2(M, N, K))))
     // (round 4: where the 256 x 128 form of the pipelined kernel applies it beats both -- Swin-L stage 3: 130 (128 x 128) / 136-146 (sub-tiles) / 117 us)
     // fc1 + GELU with the epilogue deferred into the next sub-tile's k loop: pays where the 128 x 128 kernel needs more than one round of
     // workgroups AND the k loop is long (Swin-L: stage 3 165 -> 143 us, stage 4 147 -> 142 us); a one-round launch (Swin-B stage 4: 512

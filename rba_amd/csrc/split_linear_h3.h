@@ -872,10 +872,14 @@ inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const floa
 // rounds of the 256 CUs or one round that is at least three quarters full (Swin-B stage-3 fc1 69 -> 62 us, stage-4 qkv / fc1 45 -> 40 / 55 -> 50 us,
 // Swin-L stage-3 fc1 / fc2 130 -> 117 / 126 -> 110 us), 0.81-0.96x where they leave CUs idle (<= 128 tiles: stage-3 proj / fc2 of Swin-B) or end
 // in a round that is less than three quarters full (1.5 rounds: Swin-B stage-3 qkv).  rba_k6_rs (tools): 0 = this rule, 1 = never, 2 = whenever there
-// are at least 160 tiles of 256 x 128.
+// are at least 160 tiles of 256 x 128.  Only for K >= rba_k6_rs_min_k = 512: the short-K launches of Swin stages 1-2 (K = 128 / 256, 1 000-3 000 tiles) are
+// bound by HBM and by their epilogues, and IN THE NETWORK (cold operands) two independent 128 x 128 workgroups per CU overlap one tile's stores with the
+// other's loads better than one 8-wave workgroup: per-dispatch rocprofv3 times of one image, stage-1 qkv 72-77 -> 65 us, stage-2 qkv 52-57 -> 47-51,
+// stage-2 fc1 83 -> 76-77 (profiles/r04_k6_rs2_min_k.txt; same-box bench A/B +0.7 % single stream, +0.2 % three streams).
 extern "C" int rba_k6_rs;
-inline bool h3p_use_rs2(int64_t M, int N) {
-  if (rba_k6_rs == 1) return false;
+extern "C" int rba_k6_rs_min_k;
+inline bool h3p_use_rs2(int64_t M, int N, int K) {
+  if (rba_k6_rs == 1 || K < rba_k6_rs_min_k) return false;
   const int64_t t = ((M + 255) / 256) * ((N + 127) / 128);
   if (rba_k6_rs == 3) return t >= 64;                                 // tools: also the half-chip launches (128 tiles: stage-3 proj / fc2 of Swin-B)
   if (t < 160) return false;
@@ -889,7 +893,7 @@ template <int ACT, bool RES, int OCC>
 int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K,
                    hipStream_t st) {
   const int NT = (N + 127) / 128;
-  if (OCC == 2 && h3p_use_rs2(M, N)) {
+  if (OCC == 2 && h3p_use_rs2(M, N, K)) {
     const int64_t MT2 = (M + 255) / 256;
     hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, 2, true, false, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
                        reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT2, NT, nullptr, res, ConvShape{0, 0, 0}, 0);
@@ -905,7 +909,7 @@ int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const f
 template <int ACT, bool PRE, int OCC>
 int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* out_frag, int64_t M, int N, int K, hipStream_t st) {
   const int NT = (N + 127) / 128;
-  if (OCC == 2 && PRE && h3p_use_rs2(M, N)) {
+  if (OCC == 2 && PRE && h3p_use_rs2(M, N, K)) {
     const int64_t MT2 = (M + 255) / 256;
     hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, false, 2, true, true, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
                        reinterpret_cast<const float*>(x), wp, bias, reinterpret_cast<float*>(out_frag), (int)M, N, K, (int)MT2, NT, nullptr, nullptr,
@@ -923,7 +927,7 @@ int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* o
 inline int launch_h3p_conv_pre(const void* xf, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
                                hipStream_t st) {
   const int NT = (N + 127) / 128;
-  if (h3p_use_rs2(M, N)) {
+  if (h3p_use_rs2(M, N, 9 * Cin)) {
     const int64_t MT2 = (M + 255) / 256;
     if (MT2 * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,

@@ -18,6 +18,13 @@ from .modeling.meta_arch import mask_former_head as _head  # noqa: F401
 from .registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY
 
 
+def _class_prob(mask_cls):
+    """F.softmax(mask_cls, -1)[..., :-1] (reference maskformer_model.py:381-383), one launch"""
+    if mask_cls.shape[-1] <= 64:
+        return ops.softmax_drop_last(mask_cls.contiguous())
+    return F.softmax(mask_cls, dim=-1)[..., :-1].contiguous()
+
+
 @META_ARCH_REGISTRY.register()
 class MaskFormer(nn.Module):
     def __init__(self, arch, backbone_name=None, head_name="MaskFormerHead"):
@@ -85,7 +92,7 @@ class MaskFormer(nn.Module):
 
     def _post(self, mask_cls, mask_pred, image_size, padded, want_sem_seg, want_argmax, score="rba"):
         """Up-sample (:294-299), semantic inference (:381-386), crop (:330-332), RbA (evaluate_ood.py:150)."""
-        prob = F.softmax(mask_cls, dim=-1)[..., :-1].contiguous()
+        prob = _class_prob(mask_cls)
         H, W = padded
         exact4 = mask_pred.shape[-2] * 4 == H and mask_pred.shape[-1] * 4 == W
         if self.fused_upsample and exact4 and prob.shape[1] <= 32:
@@ -179,7 +186,7 @@ class MaskFormer(nn.Module):
                 # :316-320: crop + resize the MASK LOGITS to the requested resolution first, semantic inference on those
                 up = ops.resample_bilinear(mask_pred[i].contiguous(), padded)[:, : sizes[i][0], : sizes[i][1]].contiguous()
                 up = ops.resample_bilinear(up, (height, width))
-                prob = F.softmax(mask_cls[i], dim=-1)[..., :-1].contiguous()
+                prob = _class_prob(mask_cls[i])
                 rba, sem, arg = ops.rba_reduce(up, prob, True, return_argmax)
             else:
                 rba, sem, arg = self._post(mask_cls[i], mask_pred[i], sizes[i], padded, True, return_argmax)

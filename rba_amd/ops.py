@@ -1103,6 +1103,32 @@ def gaussian_blur(score, kernel_size=7, sigma=1.0):
 
 
 @_hip_op
+def quad_mean(v):
+    """v [..., 4, S] -> ((v0 + v1) + (v2 + v3)) * 0.25 [..., S]: the bilinear sample at the centre of each 2 x 2 cell (rba_quad_mean_f32)"""
+    lib = _lib.load()
+    _chk(v, "v")
+    if v.dim() < 2 or v.shape[-2] != 4:
+        raise RbaHipError(f"quad_mean expects [..., 4, S], got {tuple(v.shape)}")
+    S = v.shape[-1]
+    out = torch.empty(v.shape[:-2] + (S,), dtype=torch.float32, device=v.device)
+    _lib.check(lib.rba_quad_mean_f32(_p(v), _p(out), v.numel() // (4 * S) if S else 0, S, _stream()), "rba_quad_mean_f32")
+    return out
+
+
+@_hip_op
+def softmax_drop_last(logits):
+    """F.softmax(logits, -1)[..., :-1] as one launch (rba_softmax_drop_last_f32): [..., K + 1] -> [..., K] contiguous, K + 1 <= 64"""
+    lib = _lib.load()
+    _chk(logits, "logits")
+    K1 = logits.shape[-1]
+    if not 2 <= K1 <= 64:
+        raise RbaHipError(f"softmax_drop_last supports 2..64 classes, got {K1}")
+    out = torch.empty(logits.shape[:-1] + (K1 - 1,), dtype=torch.float32, device=logits.device)
+    _lib.check(lib.rba_softmax_drop_last_f32(_p(logits), _p(out), logits.numel() // K1, K1, _stream()), "rba_softmax_drop_last_f32")
+    return out
+
+
+@_hip_op
 def ood_components(score, threshold, min_dummy=None):
     """Open-set panoptic epilogue of a score map [H,W] (maskformer_model.py:454-474): binary = score > threshold, 3x3 opening
     then closing, 4-connected components.  Returns (labels int32 [H,W] with 0 = background and components numbered 1..n in

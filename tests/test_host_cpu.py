@@ -405,3 +405,15 @@ def test_bench_names_its_workload_and_configs2_flag():
         assert a.streams == 3 and a.gpus == 1 and a.steps == 20 and a.warmup == 3
     finally:
         sys.argv = old
+
+
+def test_registries_hold_the_reference_names():
+    """the names a reference config.yaml selects components by (META_ARCHITECTURE, BACKBONE.NAME, SEM_SEG_HEAD.NAME, PIXEL_DECODER_NAME,
+    TRANSFORMER_DECODER_NAME) resolve in the registries -- a decorator separated from its class shows up here, not on the GPU box"""
+    import rba_amd.maskformer_model  # noqa: F401  (imports register everything)
+    from rba_amd import registry as R
+    for reg, names in ((R.META_ARCH_REGISTRY, ["MaskFormer"]), (R.BACKBONE_REGISTRY, ["D2SwinTransformer", "build_resnet_backbone"]),
+                       (R.SEM_SEG_HEADS_REGISTRY, ["MaskFormerHead", "MSDeformAttnPixelDecoder"]),
+                       (R.TRANSFORMER_DECODER_REGISTRY, ["MultiScaleMaskedTransformerDecoder"])):
+        for n in names:
+            assert isinstance(reg.get(n), type) or callable(reg.get(n)), n

@@ -652,6 +652,8 @@ def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
     import ctypes
     from rba_amd import _lib
     rs = ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs")
+    min_k = ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs_min_k")               # product: the 8-wave form from K = 512 on; here for every K
+    prev_min_k = min_k.value
     g = torch.Generator().manual_seed(M + N + K)
     x, w = dev(torch.randn(M, K, generator=g) * 3), dev(torch.randn(N, K, generator=g) * K ** -0.5)
     b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
@@ -667,12 +669,15 @@ def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
             outs.append(so.unpack())
         return outs
     try:
+        min_k.value = 0
         rs.value = 1
         want = run()
         rs.value = 3
         got = run()
     finally:
         rs.value = 0
+        min_k.value = prev_min_k
+    assert prev_min_k == 512
     assert ((M + 255) // 256) * ((N + 127) // 128) >= 64                      # the 8-wave form was reached
     for a_, b_ in zip(got, want):
         assert torch.equal(a_, b_)
@@ -909,6 +914,41 @@ def test_resample_bilinear_nhwc(ops, h, w, H, W, C, has_add):
 
 
 # ----------------------------------------------------------------------------------- gaussian smoothing of the score map
+@pytest.mark.parametrize("B,Q,S", [(1, 100, 2048), (2, 16, 77), (1, 3, 1), (1, 100, 8192)])
+def test_quad_mean_is_the_centre_sample_bit_for_bit(ops, B, Q, S):
+    """rba_quad_mean_f32 == ((v0 + v1) + (v2 + v3)) * 0.25 (the torch expression it replaced in the sparse prediction head) exactly, and equals
+    F.interpolate(bilinear, align_corners=False) of a [2h, 2w] map down to [h, w] at the same four pixels"""
+    g = torch.Generator().manual_seed(S + Q)
+    v = dev(torch.randn(B, Q, 4, S, generator=g) * 7)
+    want = ((v[:, :, 0] + v[:, :, 1]) + (v[:, :, 2] + v[:, :, 3])) * 0.25
+    got = ops.quad_mean(v)
+    assert got.shape == (B, Q, S) and torch.equal(got, want)
+    assert ops.quad_mean(v[:, :0]).shape == (B, 0, S)
+    with pytest.raises(Exception):
+        ops.quad_mean(dev(torch.zeros(2, 3, 5)))
+
+
+@pytest.mark.parametrize("R,K1", [(100, 20), (1, 2), (257, 64), (300, 9)])
+def test_softmax_drop_last_vs_torch(ops, R, K1):
+    """rba_softmax_drop_last_f32 against F.softmax(x, -1)[..., :-1] in fp64; rows still sum to 1 with the dropped column; extreme logits"""
+    g = torch.Generator().manual_seed(R + K1)
+    x = torch.randn(R, K1, generator=g) * 6
+    x[0, 0] = 80.0                                                   # one dominant class: the others underflow towards 0, no NaN
+    if R > 2:
+        x[2] = -1.0e4
+        x[2, -1] = 0.0                                               # everything in the dropped "no object" column
+    want = F.softmax(x.double(), -1)[..., :-1]
+    got = ops.softmax_drop_last(dev(x))
+    assert got.shape == (R, K1 - 1) and got.is_contiguous()
+    assert torch.isfinite(got).all()
+    assert float((got.double().cpu() - want).abs().max()) < 3e-7
+    ref32 = F.softmax(dev(x), -1)[..., :-1]
+    assert float((got - ref32).abs().max()) < 3e-7
+    assert ops.softmax_drop_last(dev(x).view(1, R, K1)).shape == (1, R, K1 - 1)
+    with pytest.raises(Exception):
+        ops.softmax_drop_last(dev(torch.zeros(4, 65)))
+
+
 @pytest.mark.parametrize("H,W,k,sigma", [(1024, 2048, 7, 1.0), (60, 90, 7, 1.0), (33, 70, 5, 0.8), (4, 5, 7, 1.0), (129, 65, 15, 2.5)])
 def test_gaussian_blur_vs_oracle(ops, H, W, k, sigma):
     from oracle import ref_ops

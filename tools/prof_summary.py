@@ -4,6 +4,7 @@ whole-run per-kernel stats (what `--stats` prints) and the breakdown of ONE stea
 the last two launches of the K1 kernel), which excludes first-call MIOpen/hipBLASLt solver searches.
 
     python tools/prof_summary.py gpurun_out/prof/bench_results.db > profiles/rNN_bench_kernel_trace.md
+    python tools/prof_summary.py --sequence gpurun_out/prof/bench_results.db      # every dispatch of that step, in launch order, with its grid
 """
 import sqlite3
 import sys
@@ -34,5 +35,29 @@ def main(path, marker="rba_reduce"):
         print(f"\n`{marker}` launches: {len(d)}, avg {sum(d) / len(d) / 1e3:.1f} us, min {min(d) / 1e3:.1f} us, max {max(d) / 1e3:.1f} us")
 
 
+def sequence(path, marker="rba_reduce"):
+    """one steady-state step (single-stream run) dispatch by dispatch: the per-stage view -- the same instantiation serves several stages"""
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    gx = next((n for n in ("grid_x", "grid_size_x", "grid_size") if n in cols), None)
+    wx = next((n for n in ("workgroup_x", "workgroup_size_x", "workgroup_size") if n in cols), None)
+    k1 = list(c.execute(f"select start, end from kernels where name like '%{marker}%' order by start"))
+    t0, t1 = k1[-2][1], k1[-1][1]
+    sel = "name, start, end" + (f", {gx}" if gx else "") + (f", {wx}" if wx else "")
+    rows = list(c.execute(f"select {sel} from kernels where start>=? and end<=? order by start", (t0, t1)))
+    print(f"# one steady-state step, {len(rows)} dispatches in launch order (span {(t1 - t0) / 1e3:.0f} us)\n")
+    print("| # | start us | us | gap before us | workgroups | threads | kernel |\n|---|---:|---:|---:|---:|---:|---|")
+    prev = t0
+    for i, r in enumerate(rows):
+        g = r[3] if gx else 0
+        w = r[4] if (gx and wx) else (r[3] if wx else 0)
+        nm = r[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        print(f"| {i} | {(r[1] - t0) / 1e3:.1f} | {(r[2] - r[1]) / 1e3:.1f} | {(r[1] - prev) / 1e3:.1f} | {g // w if w else g} | {w} | `{nm[:110]}` |")
+        prev = r[2]
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    if sys.argv[1] == "--sequence":
+        sequence(*sys.argv[2:])
+    else:
+        main(*sys.argv[1:])
