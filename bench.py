@@ -414,6 +414,10 @@ def main():
         import ctypes
         from rba_amd import _lib
         ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs").value = int(os.environ["RBA_K6_RS"])
+    if os.environ.get("RBA_K6_KS"):                           # tools: A/B of the K-split 8-wave form of the single-resident launches (0 = rule, 1 = never, 2 = wherever legal)
+        import ctypes
+        from rba_amd import _lib
+        ctypes.c_int.in_dll(_lib.load(), "rba_k6_ks").value = int(os.environ["RBA_K6_KS"])
     if os.environ.get("RBA_K6_RS_MIN_K"):                     # tools: the 256 x 128 form only for K >= this
         import ctypes
         from rba_amd import _lib

@@ -259,6 +259,14 @@ int rba_split_linear_nchw_out_f32(const float* x, const void* weight_packed, con
 int rba_split_linear_nchw_out_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
                                         int rows_per_image, void* stream);
 
+/* The same projection on a RAW convolution output x whose GroupNorm(G) (+ ReLU when relu != 0) is applied while the rows are loaded:
+ * `self.mask_features(self.layer_1(y))` (pixel_decoder/msdeformattn.py:357-362; Conv2d(norm=GN, activation=relu) :278-297) without the pass
+ * that writes the normalised map.  mr [B][G][2] = (mean, rstd) from rba_group_norm_nhwc_stats_f32; gamma / beta [K]; K % G == 0,
+ * (K / G) % 4 == 0, rows_per_image % 128 == 0.  Bit-identical to rba_group_norm_nhwc_f32 followed by the entry above. */
+int rba_split_linear_nchw_out_gn_f16x3_f32(const float* x, const float* mr, const float* gamma, const float* beta, int G, int relu,
+                                           const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                                           int rows_per_image, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution over NHWC activations as an implicit GEMM on the same kernel:
  * x [B,H,W,C] -> out [B,H,W,N]; weight_packed = rba_split_weight_bf16x3 of the [N, 9*C] matrix w[n][(3*ky + kx)*C + c]
  * (conv weight [N,C,3,3] permuted to [N,3,3,C]); bias [N] or NULL.  C % 32 == 0.

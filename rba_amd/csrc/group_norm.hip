@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const float* __restr
   const float mean = mr[2 * (b * G + g)], rstd = mr[2 * (b * G + g) + 1];
   const float4 ga = reinterpret_cast<const float4*>(gamma)[j], be = reinterpret_cast<const float4*>(beta)[j];
   const float a0 = ga.x * rstd, a1 = ga.y * rstd, a2 = ga.z * rstd, a3 = ga.w * rstd;
-  const float b0 = be.x - mean * a0, b1 = be.y - mean * a1, b2 = be.z - mean * a2, b3 = be.w - mean * a3;
+  const float b0 = fmaf(-mean, a0, be.x), b1 = fmaf(-mean, a1, be.y), b2 = fmaf(-mean, a2, be.z), b3 = fmaf(-mean, a3, be.w);   // (what -ffp-contract=fast made of `be - mean * a`; explicit so that the folded forms match bit for bit)
   const int lo = s * PIX_CHUNK, hi = lo + PIX_CHUNK < P ? lo + PIX_CHUNK : P;
   const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)b * P * C) + j;
   float4* yp = reinterpret_cast<float4*>(y + (int64_t)b * P * C) + j;

@@ -339,11 +339,22 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3_kernel(const float* __
 struct ConvShape {
   int H, W, Cin;
 };
-template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false, bool NCHW = false>
+// GNF (round 4): the A rows are a RAW convolution output whose GroupNorm (+ ReLU) is applied while the tile is stored to LDS -- the arithmetic of
+// gn_apply_nhwc_kernel (group_norm.hip): a = gamma * rstd, b = fma(-mean, a, beta), y = fma(x, a, b), max(y, 0) -- so the normalised map is never
+// written (pixel_decoder/msdeformattn.py:357-362: `y = output_conv(y)` feeds only `mask_features(y)`).  mr [B][G][2] = (mean, rstd) from
+// rba_group_norm_nhwc_stats_f32; every 128-row tile lies inside one image (rows_per_image % 128 == 0, checked by the launcher).
+struct GnFold {
+  const float* mr;
+  const float* gamma;
+  const float* beta;
+  int G, cpg, relu;
+};
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false, bool NCHW = false, bool GNF = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
-                                                                 ConvShape cs = ConvShape{0, 0, 0}, const float* R = nullptr, int rows_per_image = 0) {
+                                                                 ConvShape cs = ConvShape{0, 0, 0}, const float* R = nullptr, int rows_per_image = 0,
+                                                                 GnFold gn = GnFold{nullptr, nullptr, nullptr, 1, 1, 0}) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int BM = 128, BN = 32 * CT;
@@ -402,12 +413,23 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 
   u32x4_t wr[UPL];
   f32x4 xr[4];
+  f32x4 gga = {0.f, 0.f, 0.f, 0.f}, gbe = {0.f, 0.f, 0.f, 0.f};                      // GNF: gamma / beta of this thread's four channels of the block in flight
+  float gmean = 0.f, grstd = 0.f;
+  const float* gmr = GNF ? gn.mr + (int64_t)(m0 / rows_per_image) * gn.G * 2 : nullptr;
   const int last = NB - 1;
   auto gload = [&](int c) {
     const int cc = c < last ? c : last;
     const char* ws = wbase + (int64_t)cc * 16384;
 #pragma unroll
     for (int q = 0; q < UPL; ++q) wr[q] = *reinterpret_cast<const u32x4_t*>(ws + q * (QSTEP * 16) + woff);
+    if (GNF) {
+      const int ch = cc * 32 + 4 * (tid & 7);
+      gga = *reinterpret_cast<const f32x4*>(gn.gamma + ch);
+      gbe = *reinterpret_cast<const f32x4*>(gn.beta + ch);
+      const int g = ch / gn.cpg;
+      gmean = gmr[2 * g];
+      grstd = gmr[2 * g + 1];
+    }
     if (CONV) {
       const int k0 = cc * 32, tap = k0 / cs.Cin, ch0 = k0 - tap * cs.Cin;
       const int ky = tap / 3, dy = ky - 1, dx = tap - 3 * ky - 1;
@@ -427,6 +449,21 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   auto lstore = [&](u32x4_t* buf) {
 #pragma unroll
     for (int q = 0; q < UPL; ++q) buf[tid + 256 * q] = wr[q];
+    if (GNF) {
+      f32x4 a, b;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = gga[i] * grstd;
+        b[i] = fmaf(-gmean, a[i], gbe[i]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y = fmaf(xr[q][i], a[i], b[i]);
+          xr[q][i] = gn.relu ? fmaxf(y, 0.f) : y;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) buf[xdst + 256 * q] = __builtin_bit_cast(u32x4_t, xr[q]);
   };
@@ -888,11 +925,32 @@ inline bool h3p_use_rs2(int64_t M, int N, int K) {
   return last == 0 || last >= 192;
 }
 
+// Round 4 (late): the K-split 8-wave form (KS = 2, see the kernel) for the single-resident launches with a LONG k loop -- exactly one 128 x 128 tile per CU
+// (129 ... 256 tiles) and K >= 1024: Swin-B stage-3 fc2 (8192 x 512 x 2048) 60.6 -> 55.9 us (tools/k6_ks2_ab.py; proj, K = 512: no gain, stays).  Every SIMD gets
+// a second wave without doubling the A traffic (64-column sub-tiles) or halving the workgroup count (256 x 128 tiles).  The two halves of K are summed in a
+// fixed order (even blocks, odd blocks, then even + odd): deterministic, but not the one-set kernel's order -- results differ from it in the last bits
+// (tests/test_kernels_gpu.py::test_split_linear_k_split_form holds both to the same fp64 bound).  Not under several concurrent streams (rba_k6_rs == 3: there
+// these launches take whole CUs with the 256 x 128 form).  rba_k6_ks (tools / tests): 0 = this rule, 1 = never, 2 = wherever the form is legal.
+extern "C" int rba_k6_ks;
+inline bool h3p_use_ks2(int64_t M, int N, int K) {
+  if (rba_k6_ks == 1 || (K & 63) || K < 128) return false;
+  if (rba_k6_ks == 2) return true;
+  const int64_t t = ((M + 127) / 128) * ((N + 127) / 128);
+  return rba_k6_rs != 3 && t > 128 && t <= 256 && K >= 1024;
+}
+
 // A operand = the producer's split fragment image (PRE); residual may be null
 template <int ACT, bool RES, int OCC>
 int launch_h3p_pre(const void* xf, const u32x4_t* wp, const float* bias, const float* res, float* out, int64_t M, int N, int K,
                    hipStream_t st) {
   const int NT = (N + 127) / 128;
+  if (OCC == 2 && h3p_use_ks2(M, N, K)) {
+    const int64_t MT1 = (M + 127) / 128;
+    if (MT1 * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, 2, true, false, 2>), dim3((unsigned)(MT1 * NT)), dim3(512), 0, st,
+                       reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, K, (int)MT1, NT, nullptr, res, ConvShape{0, 0, 0}, 0);
+    return 0;
+  }
   if (OCC == 2 && h3p_use_rs2(M, N, K)) {
     const int64_t MT2 = (M + 255) / 256;
     hipLaunchKernelGGL((split_linear_h3p_kernel<ACT, 0, false, RES, 2, true, false, 1, false, 2>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
@@ -979,6 +1037,17 @@ int launch_h3l_nchw(const float* x, const u32x4_t* wp, const float* bias, float*
   if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL((split_linear_h3l_kernel<0, CT, 0, false, false, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out,
                      (int)M, N, K, (int)MT, NT, nullptr, ConvShape{0, 0, 0}, nullptr, P);
+  return 0;
+}
+
+// the same with the GroupNorm (+ ReLU) of the input rows folded into the A load (GNF)
+template <int CT>
+int launch_h3l_nchw_gn(const float* x, const GnFold gn, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, int P, hipStream_t stream) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 32 * CT - 1) / (32 * CT);
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3l_kernel<0, CT, 0, false, false, false, true, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out,
+                     (int)M, N, K, (int)MT, NT, nullptr, ConvShape{0, 0, 0}, nullptr, P, gn);
   return 0;
 }
 

@@ -14,6 +14,9 @@ from ...registry import SEM_SEG_HEADS_REGISTRY
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from .ops.ms_deform_attn import MSDeformAttn
 
+# tools (A/B runs): RBA_MF_GN_FOLD=0 keeps the last FPN level's GroupNorm + ReLU a separate pass in front of the mask-feature projection
+FOLD_MASK_FEATURE_NORM = os.environ.get("RBA_MF_GN_FOLD", "1") != "0"
+
 
 class _LinearView:
     """A 1x1 convolution's parameters seen as an nn.Linear (weight [N,C], bias) for ops.linear."""
@@ -236,11 +239,18 @@ class MSDeformAttnPixelDecoder(nn.Module):
             last = idx == self.num_fpn_levels - 1                  # its GroupNorm is applied below by the full kernel: no separate stats pass
             prev_norm = (ops.group_norm_nhwc_stats(prev, 32, ly.norm.eps) if fold and not last else None, ly.norm)
             ph, pw = h, w
-        if prev_norm is not None:                              # the last level feeds the mask-feature projection: normalised here
-            prev = ops.group_norm_nhwc(prev, 32, prev_norm[1].weight, prev_norm[1].bias, prev_norm[1].eps, relu=True)
         mfw = self.mask_features.weight
         planes = self._cached(self.mask_features, "_rba_mf_planes_" + ops.SPLIT_MODE,           # per arithmetic form (f16x3 since round 3)
                               lambda: ops.split_weight(mfw.detach().view(mfw.shape[0], -1).contiguous()))
+        if prev_norm is not None and fold and FOLD_MASK_FEATURE_NORM and ops.split_linear_nchw_out_takes_gn(planes, ph * pw, d, 32):
+            # round 4: the last level's GroupNorm + ReLU feeds only the mask-feature projection (:357-362) -- applied inside that kernel's loads, the
+            # normalised 1/4-resolution map (134 MB at 1024 x 2048) is never written or read back
+            mr = ops.group_norm_nhwc_stats(prev, 32, prev_norm[1].eps)
+            mf = ops.split_linear_nchw_out_gn(prev.view(B * ph * pw, d), mr, prev_norm[1].weight, prev_norm[1].bias, 32, True, planes,
+                                              self.mask_features.bias, ph * pw, out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)
+            return mf, outs[0], outs[:self.maskformer_num_feature_levels]
+        if prev_norm is not None:                              # the last level feeds the mask-feature projection: normalised here
+            prev = ops.group_norm_nhwc(prev, 32, prev_norm[1].weight, prev_norm[1].bias, prev_norm[1].eps, relu=True)
         mf = ops.split_linear_nchw_out(prev.view(B * ph * pw, d), planes, self.mask_features.bias, ph * pw,
                                        out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)
         return mf, outs[0], outs[:self.maskformer_num_feature_levels]

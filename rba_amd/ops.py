@@ -748,6 +748,39 @@ def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
     return out
 
 
+def split_linear_nchw_out_takes_gn(planes, rows_per_image, K, num_groups):
+    """True when split_linear_nchw_out_gn applies: f16x3 planes, whole 128-row tiles per image, four-channel chunks inside one group."""
+    return planes.dtype == torch.float16 and rows_per_image % 128 == 0 and K % num_groups == 0 and (K // num_groups) % 4 == 0 and K % 32 == 0
+
+
+@_hip_op
+def split_linear_nchw_out_gn(x, mr, weight, bias_gn, num_groups, relu, planes, bias, rows_per_image, out_features=None):
+    """split_linear_nchw_out(group_norm_nhwc(x) [+ ReLU]) with the normalisation applied while the rows are loaded (f16x3 planes only): x [B*P, K] is the
+    RAW convolution output, mr [B, G, 2] its statistics (group_norm_nhwc_stats), weight / bias_gn the GroupNorm's affine.  Bit-identical to the two-call form."""
+    lib = _lib.load()
+    _chk(x, "x", dim=2)
+    _chk(mr, "mr", dim=3)
+    _chk(weight, "weight", dim=1)
+    _chk(bias_gn, "bias_gn", dim=1)
+    _chk(planes, "planes", dtype=torch.float16, dim=6)
+    M, K = x.shape
+    N = planes.shape[0] * 128 if out_features is None else int(out_features)
+    if (tuple(planes.shape[2:]) != (2, 128, 2, 8) or planes.shape[1] * 16 != K or (N + 127) // 128 != planes.shape[0] or rows_per_image < 1
+            or M % rows_per_image or not split_linear_nchw_out_takes_gn(planes, rows_per_image, K, num_groups)):
+        raise RbaHipError("split_linear_nchw_out_gn needs x [B*P, K], f16x3 split_weight(W [N,K]), P % 128 == 0 and (K / G) % 4 == 0")
+    B = M // rows_per_image
+    if tuple(mr.shape) != (B, num_groups, 2) or weight.numel() != K or bias_gn.numel() != K:
+        raise RbaHipError("mr must be [B, G, 2]; weight / bias_gn must have K elements")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+        if bias.numel() != N:
+            raise RbaHipError("bias must have N elements")
+    out = torch.empty((B, N, rows_per_image), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_split_linear_nchw_out_gn_f16x3_f32(_p(x), _p(mr), _p(weight), _p(bias_gn), int(num_groups), int(bool(relu)), _p(planes), _p(bias),
+                                                          _p(out), M, N, K, rows_per_image, _stream()), "rba_split_linear_nchw_out_gn_f16x3_f32")
+    return out
+
+
 @_hip_op
 def conv3x3_weight(weight, mode=None):
     """conv weight [N, C, 3, 3] -> split_weight (form `mode`, default ops.SPLIT_MODE) of the implicit-GEMM matrix [N, 9 C],

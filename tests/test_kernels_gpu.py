@@ -625,11 +625,23 @@ def test_split_linear_residual_epilogue(ops, M, N, K):
     assert out.data_ptr() == r2.data_ptr() and torch.equal(out, want)
 
 
+@pytest.fixture
+def k6_k_split_off():
+    """rba_k6_ks = 1 for the duration of a test that compares launch forms bit for bit."""
+    import ctypes
+    from rba_amd import _lib
+    ks = ctypes.c_int.in_dll(_lib.load(), "rba_k6_ks")
+    ks.value = 1
+    yield
+    ks.value = 0
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (8192, 2048, 512), (3000, 1100, 544), (2048, 3072, 1024), (130, 200, 96), (31, 128, 32),
                                    (8192, 512, 2048)])
-def test_split_linear_from_split_activations(ops, M, N, K):
+def test_split_linear_from_split_activations(ops, M, N, K, k6_k_split_off):
     """The f16x3 GEMM reading its A operand as the producer's split fragment image (SplitActivations): bit-identical to the
-    fp32-input kernel, with every epilogue (bias, GELU, ReLU, residual), one and two workgroups per CU, ragged M and N."""
+    fp32-input kernel, with every epilogue (bias, GELU, ReLU, residual), one and two workgroups per CU, ragged M and N.  (The K-split form, which
+    only split-image launches run and which sums K in its own order, is held off: test_split_linear_k_split_form covers it.)"""
     g = torch.Generator().manual_seed(M + N + K)
     x, w = dev(torch.randn(M, K, generator=g) * 3), dev(torch.randn(N, K, generator=g) * K ** -0.5)
     b, r = dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
@@ -668,19 +680,59 @@ def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
             outs.append(so.data[: M // 32 * 32 * N].clone())
             outs.append(so.unpack())
         return outs
+    ks = ctypes.c_int.in_dll(_lib.load(), "rba_k6_ks")                        # the K-split form (its own summation order) off: this test compares tile shapes
     try:
         min_k.value = 0
+        ks.value = 1
         rs.value = 1
         want = run()
         rs.value = 3
         got = run()
     finally:
         rs.value = 0
+        ks.value = 0
         min_k.value = prev_min_k
     assert prev_min_k == 512
     assert ((M + 255) // 256) * ((N + 127) // 128) >= 64                      # the 8-wave form was reached
     for a_, b_ in zip(got, want):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 2048), (8100, 500, 1024), (4224, 768, 3072), (300, 200, 128), (8192, 512, 576)])
+def test_split_linear_k_split_form(ops, M, N, K):
+    """Round 4: the K-split 8-wave form of the pipelined f16x3 kernel (KS = 2: two wave sets on the even / odd 32-wide blocks of K, summed through LDS in a
+    fixed order) that the single-resident launches with K >= 1024 run on one stream (Swin-B stage-3 fc2).  Not the one-set kernel's summation order, so not
+    bit-identical to it: both are held to the same fp64 bound, agree to a few ulp, and the form is deterministic.  rba_k6_ks: 1 = off, 2 = wherever legal."""
+    import ctypes
+    from rba_amd import _lib
+    ks = ctypes.c_int.in_dll(_lib.load(), "rba_k6_ks")
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = torch.randn(M, K, generator=g) * 3, torch.randn(N, K, generator=g) * K ** -0.5
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    planes = ops.split_weight(dev(w), mode="f16x3")
+    xs = ops.SplitActivations.pack(dev(x))
+    ref = F.linear(x.double(), w.double(), b.double())
+
+    def run():
+        return [ops.split_linear(xs, planes, dev(b), out_features=N), ops.split_linear(xs, planes, dev(b), out_features=N, relu=True),
+                ops.split_linear(xs, planes, dev(b), out_features=N, residual=dev(r).clone())]
+    try:
+        ks.value = 1
+        one = run()
+        ks.value = 2
+        two, again = run(), run()
+    finally:
+        ks.value = 0
+    refs = [ref, ref.relu(), ref + r.double()]
+    tol = 2e-5 * (K / 256) ** 0.5 + 2e-6
+    for o, t, a2, rf in zip(one, two, again, refs):
+        assert torch.equal(t, a2)                                              # deterministic
+        assert maxerr(o, rf) < tol and maxerr(t, rf) < tol                     # the same fp64 bound for both forms
+        assert maxerr(t, o.double()) < tol                                     # a few ulp of the largest outputs
+    if (K & 63) == 0:
+        assert not all(torch.equal(t, o) for t, o in zip(two, one)) or K < 256  # the form was reached (a different summation order shows in the last bits)
+    else:
+        assert all(torch.equal(t, o) for t, o in zip(two, one))               # odd block count: the form does not apply
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (131072, 512, 128), (3000, 1120, 544), (2048, 4096, 1024), (130, 96, 96), (8192, 256, 512)])
@@ -881,6 +933,31 @@ def test_split_linear_nchw_out(ops, B, P, K, N):
         assert torch.equal(out3, same3.contiguous())
     nb = ops.split_linear_nchw_out(dev(x), p3, None, P, out_features=N)
     assert maxerr(nb, ref - b.double()[None, :, None]) < 2e-5 * (K / 256) ** 0.5 + 2e-6
+
+
+@pytest.mark.parametrize("B,P,K,N,G,relu", [(1, 1024, 256, 256, 32, True), (2, 384, 256, 256, 32, True), (1, 256, 128, 40, 32, False), (3, 128, 64, 300, 4, True),
+                                              (1, 131072, 256, 256, 32, True)])
+def test_split_linear_nchw_out_with_folded_group_norm(ops, B, P, K, N, G, relu):
+    """round 4: GroupNorm (+ ReLU) of the input rows applied inside the projection's loads == group_norm_nhwc followed by the projection, bit for bit
+    (`mask_features(layer_1(y))`, pixel_decoder/msdeformattn.py:357-362)."""
+    g = torch.Generator().manual_seed(B + P + K + N)
+    x = torch.randn(B, P, K, generator=g) * 3 + 0.7
+    w, b = torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    ga, be = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    xd = dev(x)
+    p3 = ops.split_weight(dev(w), mode="f16x3")
+    assert ops.split_linear_nchw_out_takes_gn(p3, P, K, G)
+    two = ops.split_linear_nchw_out(ops.group_norm_nhwc(xd, G, dev(ga), dev(be), 1e-5, relu=relu).view(B * P, K), p3, dev(b), P, out_features=N)
+    mr = ops.group_norm_nhwc_stats(xd, G, 1e-5)
+    one = ops.split_linear_nchw_out_gn(xd.view(B * P, K), mr, dev(ga), dev(be), G, relu, p3, dev(b), P, out_features=N)
+    assert one.shape == (B, N, P) and torch.equal(one, two)
+    y = F.group_norm(x.double().permute(0, 2, 1), G, ga.double(), be.double(), 1e-5)
+    ref = F.linear((y.relu() if relu else y).permute(0, 2, 1), w.double(), b.double()).permute(0, 2, 1)
+    assert maxerr(one, ref) < 4e-5 * (K / 256) ** 0.5 + 4e-6
+    assert not ops.split_linear_nchw_out_takes_gn(p3, P + 4, K, G)                 # ragged images keep the two-call form
+    from rba_amd._lib import RbaHipError
+    with pytest.raises(RbaHipError):
+        ops.split_linear_nchw_out_gn(xd.view(B * P, K), mr[:, :1].contiguous(), dev(ga), dev(be), G, relu, p3, dev(b), P, out_features=N)
 
 
 # ----------------------------------------------------------------------------------- channels-last GroupNorm / resample
