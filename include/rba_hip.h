@@ -278,6 +278,17 @@ int rba_conv3x3_nhwc_f32(const float* x, const void* weight_packed, const float*
 int rba_conv3x3_nhwc_f16x3_f32(const float* x, const void* weight_packed, const float* bias, float* out, int B, int H, int W, int C,
                                int N, void* stream);
 
+/* GroupNorm statistics without a pass over the tensor (round 4): the FPN's lateral 1x1 convolution (fp32 rows in, K <= 256) and its 3x3 output
+ * convolution (split image in) also leave, per 128-row tile and group of N/G consecutive output channels, the moments (n, mean, M2) of their OUTPUT:
+ * moments [B][G][rows_per_image/128][3] floats.  rba_group_norm_nhwc_merge_f32 merges them (Chan, in double) into mr [B][G][2] = (mean, rstd) --
+ * what rba_group_norm_nhwc_stats_f32 computes by reading the output again (pixel_decoder/msdeformattn.py:222-235, 278-297: Conv2d(norm=GroupNorm(32, C))).
+ * N % 128 == 0, N/G in {4, 8, 16, 32}, rows_per_image % 128 == 0 (H*W for the convolution).  The outputs are those of the entries without moments, bit for bit. */
+int rba_split_linear_f16x3_gn_moments_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                                          int rows_per_image, int G, float* moments, void* stream);
+int rba_conv3x3_nhwc_f16x3_split_in_gn_moments_f32(const void* x_frag, const void* weight_packed, const float* bias, float* out, int B, int H,
+                                                   int W, int C, int N, int G, float* moments, void* stream);
+int rba_group_norm_nhwc_merge_f32(const float* moments, float* mr, int B, int G, int splits, float eps, void* stream);
+
 /* Front end of the Swin path in one pass: (image - mean) / std, ImageList zero padding to Hp x Wp, and the im2col of PatchEmbed's
  * 4x4 / stride-4 convolution (maskformer_model.py:255-257, backbone/swin.py:479-495): image [3,h,w] (device; uint8 or fp32) ->
  * out [(Hp/4)*(Wp/4), 64] fp32 with out[token][c*16 + ky*4 + kx] and columns 48..63 zero; mean / std: 3 host floats each.

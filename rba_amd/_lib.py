@@ -47,6 +47,9 @@ SIGNATURES = {
     "rba_split_linear_f16x3_gelu_split_out": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_linear_nchw_out_f16x3_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "rba_split_linear_f16x3_gn_moments_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
+    "rba_conv3x3_nhwc_f16x3_split_in_gn_moments_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "rba_group_norm_nhwc_merge_f32": [_vp, _vp, _i, _i, _i, ctypes.c_float, _vp],
     "rba_split_linear_nchw_out_gn_f16x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_conv3x3_nhwc_f16x3_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -81,7 +84,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 185        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 186        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

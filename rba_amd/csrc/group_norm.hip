@@ -245,3 +245,14 @@ extern "C" int rba_group_norm_nhwc_stats_f32(const float* x, float* mr, float* w
   hipLaunchKernelGGL(gn_merge_kernel, dim3(B * G), dim3(64), 0, st, workspace, mr, splits, eps);
   return rba_launch_status();
 }
+
+// The merge half alone: per-tile moments [B][G][splits][3] = (n, mean, M2) written by a producer's epilogue (rba_split_linear_f16x3_gn_moments_f32,
+// rba_conv3x3_nhwc_f16x3_split_in_gn_moments_f32) -> mr [B][G][2] = (mean, rstd); the Chan merge in double of rba_group_norm_nhwc_stats_f32.
+extern "C" int rba_group_norm_nhwc_merge_f32(const float* moments, float* mr, int B, int G, int splits, float eps, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && G >= 1 && splits >= 1 && (int64_t)B * G <= 0x7fffffff);
+  if (B == 0) return 0;
+  RBA_CHECK_ARG(moments && mr);
+  rba_begin();
+  hipLaunchKernelGGL(gn_merge_kernel, dim3(B * G), dim3(64), 0, (hipStream_t)stream, moments, mr, splits, eps);
+  return rba_launch_status();
+}

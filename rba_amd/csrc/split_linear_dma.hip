@@ -101,6 +101,41 @@ extern "C" int rba_conv3x3_nhwc_f16x3_f32(const float* x, const void* weight_pac
   return rba_launch_status();
 }
 
+// The FPN's lateral 1 x 1 convolution / output 3 x 3 convolution leaving the GroupNorm moments of their own output (GNM, split_linear_h3.h): `moments`
+// [B][G][rows_per_image / 128][3] = (n, mean, M2) per 128-row tile and group of N / G consecutive output channels -- rba_group_norm_nhwc_merge_f32 turns them
+// into the (mean, rstd) that rba_group_norm_nhwc_stats_f32 would compute with a pass over the output (pixel_decoder/msdeformattn.py:222-235, 278-297: Conv2d(norm=GN)).
+// fp32 rows in; K <= 256; N % 128 == 0; N / G in {4, 8, 16, 32}; rows_per_image % 128 == 0.
+extern "C" int rba_split_linear_f16x3_gn_moments_f32(const float* x, const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
+                                                     int rows_per_image, int G, float* moments, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && N >= 128 && (N % 128) == 0 && K >= 32 && (K % 32) == 0 && K <= 256 && G >= 1 && (N % G) == 0 && rows_per_image >= 128);
+  const int cpg = N / G;
+  RBA_CHECK_ARG((cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && (rows_per_image % 128) == 0);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && weight_packed && out && moments && (M % rows_per_image) == 0 && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out) & 15) == 0);
+  rba_begin();
+  const int rc = launch_h3l_gnm(x, reinterpret_cast<const u32x4_t*>(weight_packed), bias, out, M, N, K, GnMoments{moments, G, cpg, rows_per_image}, (hipStream_t)stream);
+  if (rc) return rc;
+  return rba_launch_status();
+}
+
+// split image in (rba_conv3x3_nhwc_f16x3_split_in_f32's operand), (H W) % 128 == 0, N % 128 == 0, N / G in {4, 8, 16, 32}
+extern "C" int rba_conv3x3_nhwc_f16x3_split_in_gn_moments_f32(const void* x_frag, const void* weight_packed, const float* bias, float* out, int B, int H,
+                                                              int W, int C, int N, int G, float* moments, void* stream) {
+  RBA_CHECK_ARG(B >= 0 && H >= 1 && W >= 1 && C >= 32 && (C % 32) == 0 && C <= 2048 && N >= 128 && (N % 128) == 0 && G >= 1 && (N % G) == 0);
+  const int cpg = N / G;
+  const int64_t P = (int64_t)H * W, M = (int64_t)B * P;
+  RBA_CHECK_ARG((cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && (P % 128) == 0 && P < (int64_t)1 << 31);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x_frag && weight_packed && out && moments && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x_frag | (uintptr_t)weight_packed | (uintptr_t)out | (uintptr_t)bias) & 15) == 0);
+  rba_begin();
+  const int rc = launch_h3p_conv_pre_gnm(x_frag, reinterpret_cast<const u32x4_t*>(weight_packed), bias, out, M, N, H, W, C, GnMoments{moments, G, cpg, (int)P},
+                                         (hipStream_t)stream);
+  if (rc) return rc;
+  return rba_launch_status();
+}
+
 // out = (residual + x W^T) + bias: the residual add of a transformer block (`x = x + proj(attn)`, `x = x + fc2(h)`: backbone/swin.py:284-293)
 // folded into the GEMM epilogue; `out` may alias `residual`.
 extern "C" int rba_split_linear_f16x3_res_f32(const float* x, const void* weight_packed, const float* bias, const float* residual, float* out,

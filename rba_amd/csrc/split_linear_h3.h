@@ -100,11 +100,21 @@ __global__ void split_weight_f16x2_kernel(const float* __restrict__ w, u32x4_t* 
 // its wave's 32 rows; value = main + 2^-11 low.  RES: out = (residual + value) + bias -- the `x = x + proj(...)` / `x = x + fc2(...)`
 // of a transformer block folded into the GEMM, in the fused add + LayerNorm kernel's own order of operations (bit-identical to it),
 // `out` may be the residual tensor itself (every element is read and written by the same lane).
-template <int ACT, int CT, int PROBE, bool RES>
+// GNM (round 4): the launch also leaves the GroupNorm moments of its OUTPUT -- per (128-row tile, group of cpg consecutive output channels) the triple
+// (n, mean, M2) in the workspace layout of gn_stats_nhwc_kernel / gn_merge_kernel (group_norm.hip): ws[((b G + g) splits + s) * 3], splits = P / 128 row tiles per
+// image -- so that the statistics pass over the convolution output (134 MB at the 1/4-resolution level) is never run: rba_group_norm_nhwc_merge_f32 turns them
+// into (mean, rstd).  Every row of the tile is a valid row of ONE image (M % 128 == 0, P % 128 == 0: the launcher checks), cpg in {4, 8, 16, 32}, N % 128 == 0.
+// Fixed summation order: 16 rows in a lane, lane halves, the cpg lanes of a group, the four waves (deterministic).
+struct GnMoments {
+  float* ws;
+  int G, cpg, P;
+};
+template <int ACT, int CT, int PROBE, bool RES, bool GNM = false>
 __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f32x16_t (&accl)[CT], const float* __restrict__ bias,
                                             float* C, const float* R, int M, int N, int m0, int n0, int BM, int BN, int wave, int l31,
-                                            int lh) {
+                                            int lh, GnMoments gm = GnMoments{nullptr, 1, 1, 128}, float* sh = nullptr) {
   const bool interior = m0 + BM <= M && n0 + BN <= N;
+  if (GNM) __syncthreads();                                                          // `sh` overlays the operand ring: every wave has left the k loop
 #pragma unroll
   for (int j = 0; j < CT; ++j) {
     const int col = n0 + 32 * j + l31;
@@ -131,6 +141,25 @@ __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f3
       v[r] = y.x;
       v[r + 1] = y.y;
     }
+    if (GNM) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sm += v[r];
+        sq = fmaf(v[r], v[r], sq);
+      }
+      sm += __shfl_xor(sm, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      for (int o = 1; o < gm.cpg; o <<= 1) {
+        sm += __shfl_xor(sm, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+      }
+      if (lh == 0 && (l31 & (gm.cpg - 1)) == 0) {
+        float* d = sh + ((wave * (BN / gm.cpg)) + (32 * j + l31) / gm.cpg) * 2;
+        d[0] = sm;
+        d[1] = sq;
+      }
+    }
     if (PROBE & 4) {
       float sum = 0.f;
 #pragma unroll
@@ -145,6 +174,24 @@ __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f3
         const int ro = 8 * (r >> 2) + (r & 3);
         if (rbase + ro < M) dst[(int64_t)ro * N] = v[r];
       }
+    }
+  }
+  if (GNM) {
+    __syncthreads();
+    const int gpt = BN / gm.cpg, t = 64 * wave + 32 * lh + l31;                       // thread of this 128-row half
+    if (t < gpt) {
+      double ds = 0, dq = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        ds += (double)sh[(w * gpt + t) * 2];
+        dq += (double)sh[(w * gpt + t) * 2 + 1];
+      }
+      const double n = 128.0 * gm.cpg, mean = ds / n, m2 = dq - ds * mean;
+      const int b = m0 / gm.P, sp = (m0 - b * gm.P) >> 7, splits = gm.P >> 7, g = n0 / gm.cpg + t;
+      float* o = gm.ws + (((int64_t)b * gm.G + g) * splits + sp) * 3;
+      o[0] = (float)n;
+      o[1] = (float)mean;
+      o[2] = (float)(m2 > 0 ? m2 : 0);
     }
   }
 }
@@ -349,12 +396,13 @@ struct GnFold {
   const float* beta;
   int G, cpg, relu;
 };
-template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false, bool NCHW = false, bool GNF = false>
+template <int ACT, int CT, int PROBE = 0, bool TIMING = false, bool CONV = false, bool RES = false, bool NCHW = false, bool GNF = false, bool GNM = false>
 __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
                                                                  ConvShape cs = ConvShape{0, 0, 0}, const float* R = nullptr, int rows_per_image = 0,
-                                                                 GnFold gn = GnFold{nullptr, nullptr, nullptr, 1, 1, 0}) {
+                                                                 GnFold gn = GnFold{nullptr, nullptr, nullptr, 1, 1, 0},
+                                                                 GnMoments gm = GnMoments{nullptr, 1, 1, 128}) {
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   constexpr int BM = 128, BN = 32 * CT;
@@ -512,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 
   if (TIMING) tm[2] = wall_clock64();
   if (NCHW) h3_epilogue_nchw<CT>(accm, accl, bias, C, M, N, rows_per_image, m0, n0, wave, l31, lh);
-  else h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
+  else h3_epilogue<ACT, CT, PROBE, RES, GNM>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh, gm, reinterpret_cast<float*>(lds));
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
@@ -588,11 +636,13 @@ __device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], co
 // a second copy of waves 0-3 that owns the NEXT 128 rows and walks the same k blocks through the SAME weight ring (staged once by all 512 threads), so
 // the packed weight crosses the vector L1 once per 256 rows instead of once per 128: operand traffic per MFMA 42.7 -> 32 B/clk/CU at full matrix rate.
 template <int ACT, int PROBE = 0, bool TIMING = false, bool RES = false, int OCC = 2, bool PRE = false, bool FOUT = false, int KS = 1,
-          bool CONVP = false, int RS = 1>
+          bool CONVP = false, int RS = 1, bool GNM = false>
 __global__ __launch_bounds__(256 * KS * RS, (KS == 2 || RS == 2) ? 1 : OCC) void split_linear_h3p_kernel(const float* __restrict__ A, const u32x4_t* __restrict__ Wp,
                                                                  const float* __restrict__ bias, float* C, int M, int N,
                                                                  int K, int MT, int NT, unsigned long long* dbg = nullptr,
-                                                                 const float* R = nullptr, ConvShape cs = ConvShape{0, 0, 0}, int stagger = 0) {
+                                                                 const float* R = nullptr, ConvShape cs = ConvShape{0, 0, 0}, int stagger = 0,
+                                                                 GnMoments gm = GnMoments{nullptr, 1, 1, 128}) {
+  static_assert(!GNM || (KS == 1 && !FOUT), "output moments: fp32-row epilogue, one wave set per K");
   unsigned long long tm[4];
   if (TIMING) tm[0] = wall_clock64();
   // experiment (tools): the second workgroup of every CU (the dispatcher hands out workgroups 256 .. 511 after every CU has its first)
@@ -864,7 +914,7 @@ __global__ __launch_bounds__(256 * KS * RS, (KS == 2 || RS == 2) ? 1 : OCC) void
     if (ks == 1) return;
   }
   if (FOUT) h3_epilogue_split<ACT, CT>(accm, accl, bias, C, M, N, m0, n0, wave, l31, lh);
-  else h3_epilogue<ACT, CT, PROBE, RES>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh);
+  else h3_epilogue<ACT, CT, PROBE, RES, GNM>(accm, accl, bias, C, R, M, N, m0, n0, BM, BN, wave, l31, lh, gm, reinterpret_cast<float*>(lds_all) + rs * 512);
   if (TIMING && tid == 0) {
     tm[3] = wall_clock64();
 #pragma unroll
@@ -981,6 +1031,33 @@ int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* o
                      nullptr, ConvShape{0, 0, 0}, rba_k6_stagger);
   return 0;
 }
+// the same convolution leaving the GroupNorm moments of its output (GNM, see h3_epilogue)
+inline int launch_h3p_conv_pre_gnm(const void* xf, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
+                                   const GnMoments gm, hipStream_t st) {
+  const int NT = (N + 127) / 128;
+  if (h3p_use_rs2(M, N, 9 * Cin)) {
+    const int64_t MT2 = (M + 255) / 256;
+    if (MT2 * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true, 2, true>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,
+                       reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, 9 * Cin, (int)MT2, NT, nullptr, nullptr, ConvShape{H, W, Cin}, 0, gm);
+    return 0;
+  }
+  const int64_t MT = (M + 127) / 128;
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true, 1, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, st,
+                     reinterpret_cast<const float*>(xf), wp, bias, out, (int)M, N, 9 * Cin, (int)MT, NT, nullptr, nullptr, ConvShape{H, W, Cin}, 0, gm);
+  return 0;
+}
+// fp32 rows in, fp32 rows out, no activation, 128-column tiles, plus the output's GroupNorm moments (the FPN's lateral 1 x 1 convolutions, K <= 256)
+inline int launch_h3l_gnm(const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, const GnMoments gm, hipStream_t stream) {
+  const int64_t MT = (M + 127) / 128;
+  const int NT = (N + 127) / 128;
+  if (MT * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL((split_linear_h3l_kernel<0, 4, 0, false, false, false, false, false, true>), dim3((unsigned)(MT * NT)), dim3(256), 0, stream, x, wp, bias, out,
+                     (int)M, N, K, (int)MT, NT, nullptr, ConvShape{0, 0, 0}, nullptr, 0, GnFold{nullptr, nullptr, nullptr, 1, 1, 0}, gm);
+  return 0;
+}
+
 // 3 x 3 convolution (pad 1) over the split image of NHWC activations: M = B H W output pixels, K = 9 Cin (two workgroups per CU)
 inline int launch_h3p_conv_pre(const void* xf, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
                                hipStream_t st) {

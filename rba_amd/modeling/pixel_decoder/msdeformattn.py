@@ -206,13 +206,21 @@ class MSDeformAttnPixelDecoder(nn.Module):
             x = features[f]
             h, w = int(x.shape[-2]), int(x.shape[-1])
             ad, ly = getattr(self, f"adapter_{j}"), getattr(self, f"layer_{j}")
-            lat = self._conv1x1(self._tokens(x), ad, use_bias=False)                       # raw lateral convolution [B, h*w, d]
+            tok = self._tokens(x)
+            lat_mr = None
+            if fold and tok.is_contiguous() and ops.linear_emits_gn_moments(B * h * w, d, tok.shape[-1], h * w, 32):
+                # round 4: the lateral convolution's epilogue leaves the GroupNorm moments of its output -- no statistics pass over `lat`
+                lin = self._cached(ad, "_rba_lin", lambda: _LinearView(ad.weight.view(ad.weight.shape[0], -1), ad.bias))
+                lat, lat_mr = ops.linear_gn_stats(tok, lin, 32, ad.norm.eps, h * w, use_bias=False)
+            else:
+                lat = self._conv1x1(tok, ad, use_bias=False)                               # raw lateral convolution [B, h*w, d]
             split = ops.conv3x3_takes_split(B * h * w, d) and d % 32 == 0
             yy = ops.SplitActivations.empty((B, h, w, d), prev.device) if split else None
             if fold:
                 # round 3: both GroupNorms of the top-down step are folded into the resample kernel's loads -- the lateral's (no ReLU) into its
                 # `add` operand, the previous level's (+ ReLU) into its taps: their "apply" passes (268 MB each at 256 x 512) are never run
-                lat_mr = ops.group_norm_nhwc_stats(lat, 32, ad.norm.eps)
+                if lat_mr is None:
+                    lat_mr = ops.group_norm_nhwc_stats(lat, 32, ad.norm.eps)
                 ups = []
                 for b in range(B):
                     xn = None if prev_norm is None else (prev_norm[0][b], prev_norm[1].weight, prev_norm[1].bias, True)
@@ -235,9 +243,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
                            for b in range(B)]                                                  # :357-358 fused sum
                     yy = ups[0][None] if B == 1 else torch.stack(ups)
             planes = self._cached(ly, "_rba_conv_" + ops.SPLIT_MODE, lambda: ops.conv3x3_weight(ly.weight.detach()))    # per arithmetic form
-            prev = ops.conv3x3_nhwc(yy, planes, None, out_features=d).view(B, h * w, d)   # raw: its GroupNorm + ReLU is folded into the next consumer
-            last = idx == self.num_fpn_levels - 1                  # its GroupNorm is applied below by the full kernel: no separate stats pass
-            prev_norm = (ops.group_norm_nhwc_stats(prev, 32, ly.norm.eps) if fold and not last else None, ly.norm)
+            last = idx == self.num_fpn_levels - 1                  # its GroupNorm is applied below, inside the mask-feature projection
+            if fold and split and ops.conv3x3_emits_gn_moments(B, h, w, d, 32):
+                prev, mr = ops.conv3x3_nhwc_gn_stats(yy, planes, 32, ly.norm.eps, None, out_features=d)     # round 4: statistics from the convolution's epilogue
+                prev_norm = (mr, ly.norm)
+                prev = prev.view(B, h * w, d)
+            else:
+                prev = ops.conv3x3_nhwc(yy, planes, None, out_features=d).view(B, h * w, d)   # raw: its GroupNorm + ReLU is folded into the next consumer
+                prev_norm = (ops.group_norm_nhwc_stats(prev, 32, ly.norm.eps) if fold and not last else None, ly.norm)
             ph, pw = h, w
         mfw = self.mask_features.weight
         planes = self._cached(self.mask_features, "_rba_mf_planes_" + ops.SPLIT_MODE,           # per arithmetic form (f16x3 since round 3)
@@ -245,7 +258,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         if prev_norm is not None and fold and FOLD_MASK_FEATURE_NORM and ops.split_linear_nchw_out_takes_gn(planes, ph * pw, d, 32):
             # round 4: the last level's GroupNorm + ReLU feeds only the mask-feature projection (:357-362) -- applied inside that kernel's loads, the
             # normalised 1/4-resolution map (134 MB at 1024 x 2048) is never written or read back
-            mr = ops.group_norm_nhwc_stats(prev, 32, prev_norm[1].eps)
+            mr = prev_norm[0] if prev_norm[0] is not None else ops.group_norm_nhwc_stats(prev, 32, prev_norm[1].eps)
             mf = ops.split_linear_nchw_out_gn(prev.view(B * ph * pw, d), mr, prev_norm[1].weight, prev_norm[1].bias, 32, True, planes,
                                               self.mask_features.bias, ph * pw, out_features=mfw.shape[0]).view(B, mfw.shape[0], ph, pw)
             return mf, outs[0], outs[:self.maskformer_num_feature_levels]

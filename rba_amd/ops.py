@@ -748,6 +748,78 @@ def split_linear_nchw_out(x, planes, bias, rows_per_image, out_features=None):
     return out
 
 
+GN_MOMENTS = os.environ.get("RBA_GN_MOMENTS", "1") != "0"      # A/B switch (tools): 0 keeps the separate statistics passes of the FPN's GroupNorms
+
+
+def _gn_moments_ok(rows_per_image, N, num_groups):
+    return (GN_MOMENTS and SPLIT_MODE == "f16x3" and rows_per_image % 128 == 0 and N % 128 == 0 and N % num_groups == 0
+            and (N // num_groups) in (4, 8, 16, 32))
+
+
+def linear_emits_gn_moments(M, N, K, rows_per_image, num_groups):
+    """True when linear_gn_stats runs as ONE GEMM whose epilogue leaves the GroupNorm moments of its output (the LDS-staged f16x3 kernel: K <= 256, 128-column tiles)."""
+    return _gn_moments_ok(rows_per_image, N, num_groups) and K <= 256 and K % 32 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 160 and M % rows_per_image == 0
+
+
+def conv3x3_emits_gn_moments(B, H, W, N, num_groups):
+    """True when conv3x3_nhwc_gn_stats runs the split-image convolution with the moment epilogue."""
+    return _gn_moments_ok(H * W, N, num_groups) and conv3x3_takes_split(B * H * W, N)
+
+
+def _merge_gn_moments(lib, moments, B, G, splits, eps):
+    mr = torch.empty((B, G, 2), dtype=torch.float32, device=moments.device)
+    _lib.check(lib.rba_group_norm_nhwc_merge_f32(_p(moments), _p(mr), B, G, splits, float(eps), _stream()), "rba_group_norm_nhwc_merge_f32")
+    return mr
+
+
+@_hip_op
+def linear_gn_stats(x, lin, num_groups, eps, rows_per_image, use_bias=True):
+    """(y, mr): y = F.linear(x, lin.weight[, lin.bias]) on tokens x [B, P, K] and mr [B, G, 2] = group_norm_nhwc_stats(y) -- the statistics come out of the
+    GEMM's epilogue (per-tile moments, merged in double) instead of a second pass over y.  y is bit-identical to linear(x, lin); mr equals the stats pass up
+    to the summation order.  Check linear_emits_gn_moments first."""
+    lib = _lib.load()
+    _chk(x, "x")
+    w = lin.weight
+    N, K = w.shape
+    M = x.numel() // K
+    if not linear_emits_gn_moments(M, N, K, rows_per_image, num_groups) or x.shape[-1] != K:
+        raise RbaHipError("linear_gn_stats: check linear_emits_gn_moments(M, N, K, rows_per_image, G) first")
+    bias = lin.bias if use_bias else None
+    planes = _cached_planes(lin, w)
+    B, splits = M // rows_per_image, rows_per_image // 128
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    mom = torch.empty((B, num_groups, splits, 3), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_split_linear_f16x3_gn_moments_f32(_p(x), _p(planes), _p(bias), _p(out), M, N, K, rows_per_image, int(num_groups), _p(mom), _stream()),
+               "rba_split_linear_f16x3_gn_moments_f32")
+    return out, _merge_gn_moments(lib, mom, B, int(num_groups), splits, eps)
+
+
+@_hip_op
+def conv3x3_nhwc_gn_stats(x, planes, num_groups, eps, bias=None, out_features=None):
+    """(y, mr): conv3x3_nhwc(x) of SplitActivations x [B,H,W,C] and the GroupNorm statistics of y [B, G, 2] from the convolution's own epilogue.
+    Check conv3x3_emits_gn_moments first."""
+    lib = _lib.load()
+    if not isinstance(x, SplitActivations) or len(x.shape) != 4:
+        raise RbaHipError("conv3x3_nhwc_gn_stats needs SplitActivations of logical shape [B,H,W,C]")
+    _chk(x.data, "x.data", dtype=torch.int32, dim=1)
+    _chk(planes, "planes", dtype=torch.float16, dim=6)
+    B, H, W, C = x.shape
+    N = planes.shape[0] * 128 if out_features is None else int(out_features)
+    if (tuple(planes.shape[2:]) != (2, 128, 2, 8) or planes.shape[1] * 16 != 9 * C or C % 32 or (N + 127) // 128 != planes.shape[0]
+            or not conv3x3_emits_gn_moments(B, H, W, N, num_groups)):
+        raise RbaHipError("conv3x3_nhwc_gn_stats: check conv3x3_emits_gn_moments(B, H, W, N, G) first")
+    if bias is not None:
+        _chk(bias, "bias", dim=1)
+        if bias.numel() != N:
+            raise RbaHipError("bias must have N elements")
+    splits = H * W // 128
+    out = torch.empty((B, H, W, N), dtype=torch.float32, device=x.device)
+    mom = torch.empty((B, num_groups, splits, 3), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rba_conv3x3_nhwc_f16x3_split_in_gn_moments_f32(_p(x.data), _p(planes), _p(bias), _p(out), B, H, W, C, N, int(num_groups), _p(mom),
+                                                                  _stream()), "rba_conv3x3_nhwc_f16x3_split_in_gn_moments_f32")
+    return out, _merge_gn_moments(lib, mom, B, int(num_groups), splits, eps)
+
+
 def split_linear_nchw_out_takes_gn(planes, rows_per_image, K, num_groups):
     """True when split_linear_nchw_out_gn applies: f16x3 planes, whole 128-row tiles per image, four-channel chunks inside one group."""
     return planes.dtype == torch.float16 and rows_per_image % 128 == 0 and K % num_groups == 0 and (K // num_groups) % 4 == 0 and K % 32 == 0

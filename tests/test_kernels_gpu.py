@@ -698,7 +698,7 @@ def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
         assert torch.equal(a_, b_)
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 512, 2048), (8100, 500, 1024), (4224, 768, 3072), (300, 200, 128), (8192, 512, 576)])
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 2048), (8100, 500, 1024), (4224, 1024, 3072), (300, 200, 128), (8192, 512, 576)])
 def test_split_linear_k_split_form(ops, M, N, K):
     """Round 4: the K-split 8-wave form of the pipelined f16x3 kernel (KS = 2: two wave sets on the even / odd 32-wide blocks of K, summed through LDS in a
     fixed order) that the single-resident launches with K >= 1024 run on one stream (Swin-B stage-3 fc2).  Not the one-set kernel's summation order, so not
@@ -958,6 +958,50 @@ def test_split_linear_nchw_out_with_folded_group_norm(ops, B, P, K, N, G, relu):
     from rba_amd._lib import RbaHipError
     with pytest.raises(RbaHipError):
         ops.split_linear_nchw_out_gn(xd.view(B * P, K), mr[:, :1].contiguous(), dev(ga), dev(be), G, relu, p3, dev(b), P, out_features=N)
+
+
+@pytest.mark.parametrize("B,P,K,N,G,has_bias", [(1, 32768, 256, 256, 32, False), (2, 16384, 128, 256, 32, True), (1, 131072, 128, 256, 32, False), (1, 20480, 64, 128, 8, False)])
+def test_linear_with_gn_moments_epilogue(ops, B, P, K, N, G, has_bias):
+    """round 4: the FPN's lateral 1 x 1 convolution leaves the GroupNorm moments of its output in its epilogue: the output is the plain Linear's bit for bit,
+    the merged (mean, rstd) equal the statistics pass over the output (and fp64) up to the summation order (pixel_decoder/msdeformattn.py:222-235)."""
+    g = torch.Generator().manual_seed(B + P + K + N)
+    x = dev(torch.randn(B, P, K, generator=g) * 2 + 0.3)
+    lin = torch.nn.Linear(K, N).cuda()
+    with torch.no_grad():
+        lin.weight.copy_(dev(torch.randn(N, K, generator=g) * K ** -0.5))
+        lin.bias.copy_(dev(torch.randn(N, generator=g)))
+    assert ops.linear_emits_gn_moments(B * P, N, K, P, G)
+    with torch.no_grad():
+        y, mr = ops.linear_gn_stats(x, lin, G, 1e-5, P, use_bias=has_bias)
+        want = ops.linear(x, lin, use_bias=has_bias)
+    assert torch.equal(y, want)
+    ref = ops.group_norm_nhwc_stats(want, G, 1e-5)
+    yd = want.double().view(B, P, G, N // G)
+    mean64, var64 = yd.mean(dim=(1, 3)), yd.var(dim=(1, 3), unbiased=False)
+    assert mr.shape == (B, G, 2)
+    assert maxerr(mr[..., 0], mean64) < 2e-6 and maxerr(ref[..., 0], mean64) < 2e-6
+    assert ((mr[..., 1].double().cpu() * (var64 + 1e-5).sqrt().cpu()) - 1).abs().max() < 2e-6
+    assert not ops.linear_emits_gn_moments(B * P, N, K, P + 64, G) and not ops.linear_emits_gn_moments(B * P, N, 512, P, G)
+
+
+@pytest.mark.parametrize("B,H,W,C,N,G", [(1, 128, 256, 256, 256, 32), (2, 64, 128, 64, 256, 32), (1, 256, 512, 256, 256, 32)])
+def test_conv3x3_with_gn_moments_epilogue(ops, B, H, W, C, N, G):
+    """round 4: the same for the FPN's 3 x 3 output convolution on its split-image operand (both tile forms of the pipelined kernel)."""
+    g = torch.Generator().manual_seed(B * 1000 + H * W + C)
+    x = dev(torch.randn(B, H, W, C, generator=g))
+    w = dev(torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5)
+    planes = ops.conv3x3_weight(w, mode="f16x3")
+    xs = ops.SplitActivations.pack(x.view(B * H * W, C))
+    xs = ops.SplitActivations(xs.data, (B, H, W, C))
+    assert ops.conv3x3_emits_gn_moments(B, H, W, N, G)
+    y, mr = ops.conv3x3_nhwc_gn_stats(xs, planes, G, 1e-5, None, out_features=N)
+    want = ops.conv3x3_nhwc(xs, planes, None, out_features=N)
+    assert torch.equal(y, want)
+    yd = want.double().view(B, H * W, G, N // G)
+    mean64, var64 = yd.mean(dim=(1, 3)), yd.var(dim=(1, 3), unbiased=False)
+    assert maxerr(mr[..., 0], mean64) < 2e-6
+    assert ((mr[..., 1].double().cpu() * (var64 + 1e-5).sqrt().cpu()) - 1).abs().max() < 2e-6
+    assert not ops.conv3x3_emits_gn_moments(B, 75, 50, N, G) and not ops.conv3x3_emits_gn_moments(B, H, W, N, 2)      # ragged tiles / 128-channel groups
 
 
 # ----------------------------------------------------------------------------------- channels-last GroupNorm / resample
