@@ -11,7 +11,7 @@ SOURCES = ["rba_reduce.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn
            "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "split_linear_dma.hip", "gaussian_blur.hip", "open_panoptic.hip", "dense_hybrid.hip", "patch_embed.hip", "token_linear.hip", "decoder_small.hip"]
 HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h",
            os.path.join("..", "..", "include", "rba_hip.h")]
-TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip")]
+TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip"), os.path.join("tune", "split_linear_ws.hip")]
 TUNE_LIB = os.path.join(HERE, "tune", "librba_tune.so")
 LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")
@@ -28,6 +28,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 MFMA_SOURCES = ({"split_linear.hip", "split_linear_dma.hip", "mask_logits.hip", "masked_xattn.hip", "skinny_linear.hip"}
                 if os.environ.get("RBA_NO_PACKED_FP32") == "1" else set())
+UNPACKED_SOURCES = MFMA_SOURCES
 
 
 def _run(cmd):
@@ -60,7 +61,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src):
         s, o = os.path.join(HERE, src), os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if src in MFMA_SOURCES else []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if src in UNPACKED_SOURCES else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             _run(cmd)
@@ -84,7 +85,8 @@ def build_tune(force: bool = False, verbose: bool = True) -> str:
     objs = []
     for src in TUNE_SOURCES:
         o = os.path.join(OBJ, "tune_" + os.path.basename(src).replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if MFMA_SOURCES and "split_linear" in src else []) + ["-c", os.path.join(HERE, src), "-o", o]
+        # (the weights-stationary experiment is always built without packed fp32: its waves run epilogues beside other waves' MFMAs)
+        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if (MFMA_SOURCES and "split_linear" in src) or src.endswith("split_linear_ws.hip") else []) + ["-c", os.path.join(HERE, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         _run(cmd)

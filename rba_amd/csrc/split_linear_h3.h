@@ -71,6 +71,7 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
   return r - a * q;
 }
 
+#ifndef RBA_H3_HELPERS_ONLY   // (split_linear_ws.hip takes the arithmetic and epilogue helpers of this file, not its kernels)
 // One thread per 16-byte unit of the packed image (see the layout above); rows N .. Np - 1 of the last 128-row tile are zero.
 __global__ void split_weight_f16x2_kernel(const float* __restrict__ w, u32x4_t* __restrict__ packed, int N, int K) {
   const int S = K >> 4;
@@ -95,6 +96,8 @@ __global__ void split_weight_f16x2_kernel(const float* __restrict__ w, u32x4_t* 
     dst[256] = __builtin_bit_cast(u32x4_t, p1);
   }
 }
+
+#endif  // RBA_H3_HELPERS_ONLY
 
 // Epilogue shared by the three kernels: lane holds D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] of each 32 x 32 tile of
 // its wave's 32 rows; value = main + 2^-11 low.  RES: out = (residual + value) + bias -- the `x = x + proj(...)` / `x = x + fc2(...)`
@@ -196,6 +199,7 @@ __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f3
   }
 }
 
+#ifndef RBA_H3_HELPERS_ONLY
 // The same accumulators written channel-major: out[b][n][p] for row m = b P + p (NHWC rows in, NCHW out: the mask-feature projection,
 // pixel_decoder/msdeformattn.py:362, whose consumer K4 wants [C][pixels]).  A lane's register quad r = 4 q .. 4 q + 3 is four CONSECUTIVE rows
 // (pixels) of one column (channel): one 16-byte store along the pixel axis when P % 4 == 0 (quads then never straddle two images).
@@ -569,6 +573,8 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   }
 }
 
+#endif  // RBA_H3_HELPERS_ONLY
+
 // Epilogue of the operand-swapped form (FOUT): the MFMAs ran with the weight fragment as A and the activation fragment as B, so a lane
 // holds D^T: row = lane % 32 of its wave's 32 rows, columns n = 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32-wide tile -- four
 // consecutive output channels per register quad.  The output is not an fp32 tensor but the NEXT Linear's split A operand (see "PRE"
@@ -613,6 +619,7 @@ __device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], co
   }
 }
 
+#ifndef RBA_H3_HELPERS_ONLY
 // ---- f16x3, straight-to-register activations, SOFTWARE-PIPELINED fragment reads (the form used for K > 256 with 128-column
 // tiles).  In the kernels above a wave issues its weight fragment reads, waits for LDS, issues 12 MFMAs, reads again, waits again:
 // per 32-wide block ~2800 cycles for 768 cycles of MFMA (tools/gemm_h3_timing.py; the second workgroup of the CU fills some of
@@ -1184,5 +1191,7 @@ inline int launch_h3p_res(const float* x, const u32x4_t* wp, const float* bias, 
                        K, (int)MT, NT, nullptr, res);
   return 0;
 }
+
+#endif  // RBA_H3_HELPERS_ONLY
 
 }  // namespace

@@ -6,6 +6,7 @@
 extern "C" int rba_k6_occ = 1;
 extern "C" int rba_k6_rs = 1;
 extern "C" int rba_k6_rs_min_k = 0;
+extern "C" int rba_k6_ks = 1;
 extern "C" int rba_k6_stagger = 0;          // the product library's tools-only knob, defined here for this separate library
 #include "../mlp_fused_h3.h"
 
