@@ -11,7 +11,7 @@ SOURCES = ["rba_reduce.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn
            "swin_window_attn.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "split_linear_dma.hip", "gaussian_blur.hip", "open_panoptic.hip", "dense_hybrid.hip", "patch_embed.hip", "token_linear.hip", "decoder_small.hip"]
 HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h",
            os.path.join("..", "..", "include", "rba_hip.h")]
-TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip"), os.path.join("tune", "split_linear_ws.hip")]
+TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip"), os.path.join("tune", "split_linear_ws.hip"), os.path.join("tune", "mlp_fused_h1.hip")]
 TUNE_LIB = os.path.join(HERE, "tune", "librba_tune.so")
 LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")
@@ -86,7 +86,7 @@ def build_tune(force: bool = False, verbose: bool = True) -> str:
     for src in TUNE_SOURCES:
         o = os.path.join(OBJ, "tune_" + os.path.basename(src).replace(".hip", ".o"))
         # (the weights-stationary experiment is always built without packed fp32: its waves run epilogues beside other waves' MFMAs)
-        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if (MFMA_SOURCES and "split_linear" in src) or src.endswith("split_linear_ws.hip") else []) + ["-c", os.path.join(HERE, src), "-o", o]
+        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if (MFMA_SOURCES and "split_linear" in src) or src.endswith("split_linear_ws.hip") or (src.endswith("mlp_fused_h1.hip") and os.environ.get("RBA_MLP1_UNPACKED") == "1") else []) + ["-c", os.path.join(HERE, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         _run(cmd)

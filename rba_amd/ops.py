@@ -8,6 +8,7 @@ no fallback path.
 import contextlib
 import ctypes
 import functools
+import math
 import os
 
 import torch
