@@ -14,6 +14,26 @@
 // (d / 16) ^ ((k >> 2) & 1) (conflict-free transposing reads).
 #pragma once
 
+// Timing build (tools only, csrc/tune/k5_timing.hip defines K5H_TIMING before including this header): every wave's lane 0 stamps the
+// 100 MHz wall clock at its phase boundaries into dbg[(workgroup * WAVES + wave) * 12 + i].  The product build compiles none of it.
+#ifdef K5H_TIMING
+#define K5H_DBG_PARAM , unsigned long long* __restrict__ dbg
+#define K5H_STAMP(i)                                                                                                              \
+  do {                                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    if ((threadIdx.x & 63) == 0)                                                                                                  \
+      dbg[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 12 + (i)] = wall_clock64(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                            \
+  } while (0)
+#define K5H_WAIT_VM() __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00 | 0xC000 * 0)
+#define K5H_SINK(x) asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (x)))))
+#else
+#define K5H_DBG_PARAM
+#define K5H_STAMP(i)
+#define K5H_WAIT_VM()
+#define K5H_SINK(x)
+#endif
+
 namespace {
 
 typedef _Float16 k5h_f16x8 __attribute__((ext_vector_type(8)));
@@ -37,7 +57,8 @@ __device__ __forceinline__ void k5h_split2(float a, float b, uint32_t& h, uint32
 template <int NT, int WAVES, bool FRAG, bool SOUT = false>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8))) void swin_window_attn_h3_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias, float* __restrict__ out,
-    int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale) {
+    int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale K5H_DBG_PARAM) {
+  K5H_STAMP(0);
   constexpr int HD = 32, NP = NT * 16, PL = NP * 64;                         // bytes per f16 plane
   // NT = 9 is only ever launched for 12 x 12 windows (144 tokens = 9 full key tiles): a compile-time window size turns the token -> (row,
   // column) divisions of the gather into multiply-shifts and removes the "key beyond the window" tests of the softmax (round 3: K5 is
@@ -106,6 +127,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       q_b = p[1];
     }
   }
+  K5H_STAMP(1);                                                                 // all global loads of the gather issued
+  K5H_WAIT_VM();
+  K5H_STAMP(2);                                                                 // ... and arrived
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int i = threadIdx.x + it * 64 * WAVES;
@@ -126,7 +150,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
     *reinterpret_cast<uint2*>(Kh + 3 * PL + vo) = make_uint2(l0, l1);
     if (d4 == 0) { tok[t] = tkv[it]; rid[t] = rgv[it]; }
   }
+  K5H_STAMP(3);                                                                 // split + LDS writes issued
   __syncthreads();
+  K5H_STAMP(4);                                                                 // barrier passed
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, kk = lane >> 4;
@@ -185,6 +211,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       }
       S[c] = a0;
     }
+#ifdef K5H_TIMING
+    K5H_WAIT_VM();
+    K5H_SINK((float)qh[0]);
+    K5H_STAMP(5);                                                               // Q split, bias fragments arrived
+#endif
     // three sweeps over the key tiles instead of three dependent MFMAs per tile: consecutive MFMAs then write DIFFERENT accumulators (no
     // dependent-issue stalls), every accumulator still receives its products in the order kh.qh, kh.ql, kl.qh (bit-identical)
     {
@@ -200,6 +231,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
 #pragma unroll
       for (int c = 0; c < NT; ++c) S[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[c], qh, S[c], 0, 0, 0);
     }
+    K5H_SINK(S[NT - 1][3]);
+    K5H_STAMP(6);                                                               // Q K^T done
     // ---- shift mask, padding keys; row max
     float m = -INFINITY;
     if (need_mask) {
@@ -244,6 +277,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
     float lsum = ls2.x + ls2.y;
     lsum += __shfl_xor(lsum, 16, RBA_WAVE);
     lsum += __shfl_xor(lsum, 32, RBA_WAVE);
+    K5H_SINK(lsum);
+    K5H_STAMP(7);                                                               // softmax done
     // ---- O = P . V: 32 keys (two key tiles) per step, two 16-wide d tiles, main + low accumulators
     f32x4_t Om[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, Ol[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -287,6 +322,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       Ol[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[0], pb, Ol[0], 0, 0, 0);
       Ol[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[1], pb, Ol[1], 0, 0, 0);
     }
+    K5H_SINK(Ol[1][3]);
+    K5H_STAMP(8);                                                               // P V done
     // ---- scatter: lane holds O[query = strip*16 + l15][d = 16 dt + 4 kk + r]
     const float inv = 1.0f / lsum;
     const int t = tok[strip * 16 + l15];
@@ -315,6 +352,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       }
     }
   }
+  K5H_STAMP(9);                                                                 // stores issued
+#ifdef K5H_TIMING
+  if ((threadIdx.x & 63) == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 12 + 10] = hw | ((unsigned long long)xcc << 32);
+  }
+#endif
 }
 
 template <int NT, int WAVES>
