@@ -27,6 +27,13 @@
   } while (0)
 #define K5H_WAIT_VM() __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00 | 0xC000 * 0)
 #define K5H_SINK(x) asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (x)))))
+#elif defined(K5H_ABLATE)
+// Ablation build (tools only, csrc/tune/k5_wpe_ab.hip): bit 0 = no bias-fragment loads, bit 1 = K / V / Q rows all read from the qkv bias
+// (no gather traffic), bit 2 = no stores.  Wrong results by construction; launch time only.
+#define K5H_DBG_PARAM , int ablate
+#define K5H_STAMP(i)
+#define K5H_WAIT_VM()
+#define K5H_SINK(x)
 #else
 #define K5H_DBG_PARAM
 #define K5H_STAMP(i)
@@ -54,11 +61,18 @@ __device__ __forceinline__ void k5h_split2(float a, float b, uint32_t& h, uint32
   l = r;
 }
 
-template <int NT, int WAVES, bool FRAG, bool SOUT = false>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8))) void swin_window_attn_h3_kernel(
+template <int NT, int WAVES, bool FRAG, bool SOUT = false, int WPE = 5>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void swin_window_attn_h3_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias, float* __restrict__ out,
     int H, int W, int Hp, int Wp, int nH, int ws, int shift, float scale K5H_DBG_PARAM) {
   K5H_STAMP(0);
+#ifdef K5H_ABLATE
+  // bits 3..: a late start for every second round of 256 workgroups, (ablate >> 3) * 0.5 us (do two co-resident workgroups run phase-locked?)
+  if ((ablate >> 3) && ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 8) & 1)) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)((ablate >> 3) * 50)) __builtin_amdgcn_s_sleep(4);
+  }
+#endif
   constexpr int HD = 32, NP = NT * 16, PL = NP * 64;                         // bytes per f16 plane
   // NT = 9 is only ever launched for 12 x 12 windows (144 tokens = 9 full key tiles): a compile-time window size turns the token -> (row,
   // column) divisions of the gather into multiply-shifts and removes the "key beyond the window" tests of the softmax (round 3: K5 is
@@ -97,6 +111,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       int rr = r + shift, cc = c + shift;
       rr = rr >= Hp ? rr - Hp : rr;
       cc = cc >= Wp ? cc - Wp : cc;
+#ifdef K5H_ABLATE
+      if (ablate & 2) rr = H;
+#endif
       if (rr < H && cc < W) {
         tkv[it] = rr * W + cc;
         const float* p = qkv_b + (int64_t)tkv[it] * tok_stride + h * HD + d4 * 4;
@@ -121,6 +138,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       int rr = r + shift, cc = c + shift;
       rr = rr >= Hp ? rr - Hp : rr;
       cc = cc >= Wp ? cc - Wp : cc;
+#ifdef K5H_ABLATE
+      if (ablate & 2) rr = H;
+#endif
       const float4* p = (rr < H && cc < W) ? reinterpret_cast<const float4*>(qkv_b + (int64_t)(rr * W + cc) * tok_stride + h * HD + kq * 8)
                                            : reinterpret_cast<const float4*>(qb + kq * 8);
       q_a = p[0];
@@ -198,8 +218,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
       const int k0i = c * 16 + kk * 4;
       f32x4_t a0 = {0.f, 0.f, 0.f, 0.f};
       if (FRAG) {
-        const float4 t4 = bfrag[c * 64];
-        a0 = (f32x4_t){t4.x, t4.y, t4.z, t4.w};
+#ifdef K5H_ABLATE
+        if (!(ablate & 1))
+#endif
+        {
+          const float4 t4 = bfrag[c * 64];
+          a0 = (f32x4_t){t4.x, t4.y, t4.z, t4.w};
+        }
       } else if (qt < N) {
         if (vec_bias && k0i + 3 < N) {
           const float4 t4 = *reinterpret_cast<const float4*>(brow + k0i);
@@ -341,6 +366,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(5, 8
         rba_split_f16x2(o.z, o.w, h1, l1);
         const auto p0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false), p1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
         const rba_u32x4 piece = {p0[0], p1[0], p0[1], p1[1]};
+#ifdef K5H_ABLATE
+        if (!(ablate & 4) || piece[0] == 0x12345678u)
+#endif
         if (t >= 0) {
           const int64_t row = (int64_t)b * H * W + t;
           char* dst = reinterpret_cast<char*>(out) + ((row >> 5) * nH + h) * 4096 + ((kk >> 1) * 2 + (kk & 1)) * 1024 +

@@ -14,7 +14,7 @@ from rba_amd import _lib, ops
 
 lib = _tune.load()
 fn = lib.rba_k5_timing
-fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
+fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_void_p]
 fn.restype = ctypes.c_int
 H, W, nH = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (64, 128, 16)
 C = nH * 32
@@ -29,13 +29,13 @@ Hp, Wp = (H + 11) // 12 * 12, (W + 11) // 12 * 12
 nwg = (Hp // 12) * (Wp // 12) * nH
 names = ["issue loads", "loads arrive", "split+LDS write", "barrier", "Q split+bias arrive", "QK^T", "softmax", "PV", "store"]
 big = torch.randn(64 << 20, device="cuda")                 # 256 MB: evicts qkv from L2 / Infinity Cache for the cold leg
-for shift in (0, 6):
+for shift, wpe in ((0, 5), (6, 5), (0, 6)):
     for cold in (0, 1):
         dbg = torch.zeros(nwg * 9 * 12, dtype=torch.int64, device="cuda")
         for _ in range(3):
             if cold:
                 big.add_(1.0)
-            rc = fn(qkv.data_ptr(), qb.data_ptr(), frag.data_ptr(), out.data_ptr(), 1, H, W, nH, shift, 1, dbg.data_ptr(),
+            rc = fn(qkv.data_ptr(), qb.data_ptr(), frag.data_ptr(), out.data_ptr(), 1, H, W, nH, shift, 1, wpe, dbg.data_ptr(),
                     torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "k5 timing")
             torch.cuda.synchronize()
@@ -43,7 +43,7 @@ for shift in (0, 6):
         t = d[:, :, :10].astype(np.float64) / 100.0         # us
         t -= t[:, :, 0].min()
         life = t[:, :, 9].max(axis=1) - t[:, :, 0].min(axis=1)
-        print(f"== {H}x{W} nH {nH} shift {shift} {'cold' if cold else 'warm'}: {nwg} workgroups, span {t[:, :, 9].max():.1f} us; workgroup lifetime median "
+        print(f"== {H}x{W} nH {nH} shift {shift} wpe {wpe} ({'96' if wpe == 5 else '80'} VGPRs) {'cold' if cold else 'warm'}: {nwg} workgroups, span {t[:, :, 9].max():.1f} us; workgroup lifetime median "
               f"{np.median(life):.2f} us (p10 {np.percentile(life, 10):.2f}, p90 {np.percentile(life, 90):.2f})")
         ph = t[:, :, 1:10] - t[:, :, 0:9]
         for i, n in enumerate(names):
