@@ -410,6 +410,10 @@ def main():
         import ctypes
         from rba_amd import _lib
         ctypes.c_int.in_dll(_lib.load(), "rba_k6_occ").value = int(os.environ["RBA_K6_OCC"])
+    if os.environ.get("RBA_K5_WPE"):                          # tools: A/B of K5's register budget (6 = 80 VGPRs, two workgroups per CU; 5 = 96 VGPRs, one)
+        import ctypes
+        from rba_amd import _lib
+        ctypes.c_int.in_dll(_lib.load(), "rba_k5_wpe").value = int(os.environ["RBA_K5_WPE"])
     if os.environ.get("RBA_K6_RS"):                           # tools: A/B of the 256 x 128 / 8-wave K6 form (0 = by tile count, 1 = never, 2 = always)
         import ctypes
         from rba_amd import _lib

@@ -343,6 +343,33 @@ __global__ void swin_bias_fragments_kernel(const float* __restrict__ bias, float
 
 #include "swin_window_attn_h3.h"
 
+// Register budget of the kernel (round 4, late): at 96 VGPRs a gfx950 CU holds ONE 9-wave workgroup although the occupancy API answers two (tools/micro/occ_probe.hip); at
+// amdgpu_waves_per_eu(6, 8) the same source compiles to 79 VGPRs without scratch, two workgroups are resident, outputs bit-identical.  Launch time: equal to 15 % shorter
+// depending on the box and the stage, 0-4 % with cold operands (profiles/r04_k5_wpe_ab.txt).  rba_k5_wpe (tools): 6 = default, 5 = the 96-VGPR build of rounds 2-4.
+extern "C" __attribute__((visibility("default"))) int rba_k5_wpe = 6;
+
+namespace {
+template <int NT, int WAVES>
+int launch_h3(const float* qkv, const float* qkv_bias, const float* bias, const float* bias_frag, float* out, int B, int H, int W,
+              int Hp, int Wp, int nH, int ws, int shift, float scale, hipStream_t st, bool split_out = false) {
+  const size_t shm = (size_t)(4 * NT * 16 * 64) + (size_t)(2 * NT * 16) * sizeof(int);
+  const dim3 grid(Wp / ws, Hp / ws, B * nH), block(64 * WAVES);
+#define K5H_LAUNCH(FRAG, SOUT, WPE, BIAS) hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, FRAG, SOUT, WPE>), grid, block, shm, st, qkv, qkv_bias, BIAS, out, H, W, Hp, Wp, nH, ws, shift, scale)
+  const bool w5 = rba_k5_wpe == 5;
+  if (split_out) {
+    if (!bias_frag) return (int)hipErrorInvalidValue;
+    if (w5) K5H_LAUNCH(true, true, 5, bias_frag); else K5H_LAUNCH(true, true, 6, bias_frag);
+  } else if (bias_frag) {
+    if (w5) K5H_LAUNCH(true, false, 5, bias_frag); else K5H_LAUNCH(true, false, 6, bias_frag);
+  } else {
+    if (w5) K5H_LAUNCH(false, false, 5, bias); else K5H_LAUNCH(false, false, 6, bias);
+  }
+#undef K5H_LAUNCH
+  return rba_launch_status();
+}
+
+}  // namespace
+
 extern "C" int64_t rba_swin_bias_fragments_elems(int nH, int ws) {
   if (nH <= 0 || ws <= 0 || ws * ws > 256) return 0;
   const int64_t NT = (ws * ws + 15) / 16;

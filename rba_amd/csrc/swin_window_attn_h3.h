@@ -68,9 +68,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE,
   K5H_STAMP(0);
 #ifdef K5H_ABLATE
   // bits 3..: a late start for every second round of 256 workgroups, (ablate >> 3) * 0.5 us (do two co-resident workgroups run phase-locked?)
-  if ((ablate >> 3) && ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 8) & 1)) {
+  if (((ablate >> 3) & 0xff) && ((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 8) & 1)) {
     const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)((ablate >> 3) * 50)) __builtin_amdgcn_s_sleep(4);
+    while (wall_clock64() - t0 < (unsigned long long)(((ablate >> 3) & 0xff) * 50)) __builtin_amdgcn_s_sleep(4);
   }
 #endif
   constexpr int HD = 32, NP = NT * 16, PL = NP * 64;                         // bytes per f16 plane
@@ -83,11 +83,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE,
   int* tok = reinterpret_cast<int*>(k5h_lds + 4 * PL);
   int* rid = tok + NP;
   const int N = NT == 9 ? 144 : ws * ws;
-  const int wx = blockIdx.x, wy = blockIdx.y;
+  int wx = blockIdx.x, wy = blockIdx.y, hz = blockIdx.z;
+#ifdef K5H_ABLATE
+  if (ablate & 0x4000) {   // heads vary fastest over the dispatch order: linear id -> (image, window row, window column, head)
+    const int L = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int hh = L % nH, wl = L / nH;
+    wx = wl % (int)gridDim.x;
+    wy = (wl / (int)gridDim.x) % (int)gridDim.y;
+    hz = (wl / (int)(gridDim.x * gridDim.y)) * nH + hh;
+  }
+#endif
   // the shift mask (swin.py:413-440) only separates tokens inside the LAST row / column of windows: everywhere else all 144 tokens share
   // region 0 and the 36 compare / add pairs per lane are skipped (workgroup-uniform branch)
   const bool need_mask = shift > 0 && (wy == (int)gridDim.y - 1 || wx == (int)gridDim.x - 1);
-  const int h = blockIdx.z % nH, b = blockIdx.z / nH;
+  const int h = hz % nH, b = hz / nH;
   const int C = nH * HD;
   const int64_t tok_stride = 3 * (int64_t)C;
   const float* qkv_b = qkv + (int64_t)b * H * W * tok_stride;
@@ -390,26 +399,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE,
     dbg[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6)) * 12 + 10] = hw | ((unsigned long long)xcc << 32);
   }
 #endif
-}
-
-template <int NT, int WAVES>
-int launch_h3(const float* qkv, const float* qkv_bias, const float* bias, const float* bias_frag, float* out, int B, int H, int W,
-              int Hp, int Wp, int nH, int ws, int shift, float scale, hipStream_t st, bool split_out = false) {
-  const size_t shm = (size_t)(4 * NT * 16 * 64) + (size_t)(2 * NT * 16) * sizeof(int);
-  const dim3 grid(Wp / ws, Hp / ws, B * nH), block(64 * WAVES);
-  if (split_out) {
-    if (!bias_frag) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, true, true>), grid, block, shm, st, qkv, qkv_bias, bias_frag, out, H, W, Hp,
-                       Wp, nH, ws, shift, scale);
-    return rba_launch_status();
-  }
-  if (bias_frag)
-    hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, true>), grid, block, shm, st, qkv, qkv_bias, bias_frag, out, H, W, Hp, Wp,
-                       nH, ws, shift, scale);
-  else
-    hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, false>), grid, block, shm, st, qkv, qkv_bias, bias, out, H, W, Hp, Wp, nH,
-                       ws, shift, scale);
-  return rba_launch_status();
 }
 
 }  // namespace

@@ -77,29 +77,44 @@ for (H, W, nH), wt in zip(stages, weights):
         print("  ".join(line))
 print("per image (warm / cold single launches): " + "  ".join(f"wpe{w} {tot[w] / 1e3:.3f} / {tot[(w, 'c')] / 1e3:.3f} ms" for w in (5, 6, 7, 8, 15)))
 
-# ablations on the stage-3 shape (wrong results by construction: launch time only)
-H, W, nH = 64, 128, 16
-C = nH * 32
-qkv = torch.randn(1, H * W, 3 * C, device="cuda")
-qb = torch.randn(3 * C, device="cuda") * 0.1
-frag = ops.swin_bias_fragments(torch.randn(nH, 144, 144, device="cuda"), 12)
-out = torch.zeros((H * W + 31) // 32 * 32 * C, device="cuda")
-st = torch.cuda.current_stream().cuda_stream
-for wpe in (5, 6):
-    line = [f"stage 3, shift 0, wpe{wpe}:"]
-    for ab, name in ((0, "product"), (1, "no bias loads"), (2, "no gather"), (4, "no stores"), (3, "no bias, no gather"), (7, "no global traffic"),
-                     (2 << 3, "late start 1 us"), (4 << 3, "2 us"), (6 << 3, "3 us"), (8 << 3, "4 us")):
-        ts = []
+# ablations (wrong results by construction except "heads fastest": launch time only); the ablation build's text has 72 VGPRs = two workgroups per CU at every wpe
+for (H, W, nH) in ((64, 128, 16), (128, 256, 8), (256, 512, 4)):
+    C = nH * 32
+    qkv = torch.randn(1, H * W, 3 * C, device="cuda")
+    qb = torch.randn(3 * C, device="cuda") * 0.1
+    frag = ops.swin_bias_fragments(torch.randn(nH, 144, 144, device="cuda"), 12)
+    out = torch.zeros((H * W + 31) // 32 * 32 * C, device="cuda")
+    ref = None
+    st = torch.cuda.current_stream().cuda_stream
+    line = [f"{H}x{W} nH {nH} shift 0, warm / cold us:"]
+    for ab, name in ((0, "product"), (0x4000, "heads fastest"), (1, "no bias loads"), (0x4001, "heads fastest, no bias"), (2, "no gather"), (4, "no stores"), (7, "no global traffic"),
+                     (2 << 3, "late start 1 us")):
+        def launch():
+            _lib.check(fn(qkv.data_ptr(), qb.data_ptr(), frag.data_ptr(), out.data_ptr(), 1, H, W, nH, 0, 1, 5, ab, st), "k5 ablate")
+        launch(); torch.cuda.synchronize()
+        if ab == 0:
+            ref = out.clone()
+        tag = "" if ab not in (0, 0x4000) else (" same bits" if torch.equal(out.view(torch.int32), ref.view(torch.int32)) else " DIFFERS")
+        ts, tc = [], []
         for i in range(7):
             busy @ busy
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                _lib.check(fn(qkv.data_ptr(), qb.data_ptr(), frag.data_ptr(), out.data_ptr(), 1, H, W, nH, 0, 1, wpe, ab, st), "k5 ablate")
+                launch()
             e1.record()
             torch.cuda.synchronize()
             if i >= 2:
                 ts.append(e0.elapsed_time(e1) * 1e2)
-        ts.sort()
-        line.append(f"{name} {ts[len(ts) // 2]:.1f} us")
+        for i in range(9):
+            big.add_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                tc.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort(); tc.sort()
+        line.append(f"{name} {ts[len(ts) // 2]:.1f} / {tc[len(tc) // 2]:.1f}{tag}")
     print("  ".join(line))
