@@ -356,8 +356,8 @@ int launch_h3(const float* qkv, const float* qkv_bias, const float* bias, const 
   const dim3 grid(Wp / ws, Hp / ws, B * nH), block(64 * WAVES);
 #define K5H_LAUNCH(FRAG, SOUT, WPE, BIAS) hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, FRAG, SOUT, WPE>), grid, block, shm, st, qkv, qkv_bias, BIAS, out, H, W, Hp, Wp, nH, ws, shift, scale)
   const bool w5 = rba_k5_wpe == 5;
+  if (split_out && !bias_frag) return (int)hipErrorInvalidValue;
   if (split_out) {
-    if (!bias_frag) return (int)hipErrorInvalidValue;
     if (w5) K5H_LAUNCH(true, true, 5, bias_frag); else K5H_LAUNCH(true, true, 6, bias_frag);
   } else if (bias_frag) {
     if (w5) K5H_LAUNCH(true, false, 5, bias_frag); else K5H_LAUNCH(true, false, 6, bias_frag);

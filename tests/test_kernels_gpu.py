@@ -387,31 +387,33 @@ def test_k5_window_attn_core(ops, H, W, ws, nH, shift):
 
 
 def test_k5_register_budgets_are_bit_identical(ops):
-    """Round 4 (late): the f16x3 window-attention kernel at 80 VGPRs (two 9-wave workgroups resident per CU, the default) and at 96 (one: rba_k5_wpe = 5,
-    the build of rounds 2-4) is the same arithmetic in the same order -- every output form bit for bit, shifted and unshifted, with window padding."""
+    """Round 4 (late): the f16x3 window-attention kernel at 80 VGPRs (two 9-wave workgroups resident per CU, the default) and at 96 (one: rba_k5_wpe = 5, the
+    build of rounds 2-4) is the same arithmetic in the same order -- every output form bit for bit, shifted and unshifted, with window padding, one and two images."""
     import ctypes
     from rba_amd import _lib
-    var = ctypes.c_int.in_dll(_lib.load(), "rba_k5_wpe")
-    assert var.value == 6
+    wpe = ctypes.c_int.in_dll(_lib.load(), "rba_k5_wpe")
+    assert wpe.value == 6
     g = torch.Generator().manual_seed(5)
-    H, W, nH, ws = 40, 70, 3, 12
-    C = nH * 32
-    qkv = dev(torch.randn(2, H * W, 3 * C, generator=g))
-    qb = dev(torch.randn(3 * C, generator=g) * 0.2)
-    bias = dev(torch.randn(nH, ws * ws, ws * ws, generator=g) * 0.5)
-    frag = ops.swin_bias_fragments(bias, ws)
-    for shift in (0, 6):
-        got = {}
-        for wpe in (6, 5):
-            var.value = wpe
-            try:
-                got[wpe] = (ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift),
-                            ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift, bias_frag=frag),
-                            ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift, bias_frag=frag, split_out=True).data)
-            finally:
-                var.value = 6
-        for a, b in zip(got[6], got[5]):
-            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for (B, H, W, nH) in ((2, 40, 70, 3), (1, 130, 150, 4), (1, 12, 12, 1)):
+        ws = 12
+        C = nH * 32
+        qkv = dev(torch.randn(B, H * W, 3 * C, generator=g))
+        qb = dev(torch.randn(3 * C, generator=g) * 0.2)
+        bias = dev(torch.randn(nH, ws * ws, ws * ws, generator=g) * 0.5)
+        frag = ops.swin_bias_fragments(bias, ws)
+        for shift in (0, 6):
+            got = []
+            for w in (6, 5):
+                wpe.value = w
+                try:
+                    so = ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift, bias_frag=frag, split_out=True)
+                    nfull = (B * H * W) // 32 * 32 * C                                  # whole 32-row groups of the image (the last group's padding rows are not written)
+                    got.append((ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift), ops.swin_window_attn(qkv, qb, bias, H, W, nH, ws, shift, bias_frag=frag),
+                                so.data[:nfull].clone(), so.unpack()))
+                finally:
+                    wpe.value = 6
+            for a, b in zip(got[0], got[1]):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
 # ----------------------------------------------------------------------------------- GroupNorm
