@@ -355,14 +355,14 @@ int launch_h3(const float* qkv, const float* qkv_bias, const float* bias, const 
   const size_t shm = (size_t)(4 * NT * 16 * 64) + (size_t)(2 * NT * 16) * sizeof(int);
   const dim3 grid(Wp / ws, Hp / ws, B * nH), block(64 * WAVES);
 #define K5H_LAUNCH(FRAG, SOUT, WPE, BIAS) hipLaunchKernelGGL((swin_window_attn_h3_kernel<NT, WAVES, FRAG, SOUT, WPE>), grid, block, shm, st, qkv, qkv_bias, BIAS, out, H, W, Hp, Wp, nH, ws, shift, scale)
-  const bool w5 = rba_k5_wpe == 5;
+  const int w = rba_k5_wpe;
   if (split_out && !bias_frag) return (int)hipErrorInvalidValue;
   if (split_out) {
-    if (w5) K5H_LAUNCH(true, true, 5, bias_frag); else K5H_LAUNCH(true, true, 6, bias_frag);
+    if (w == 5) K5H_LAUNCH(true, true, 5, bias_frag); else if (w == 7) K5H_LAUNCH(true, true, 7, bias_frag); else K5H_LAUNCH(true, true, 6, bias_frag);
   } else if (bias_frag) {
-    if (w5) K5H_LAUNCH(true, false, 5, bias_frag); else K5H_LAUNCH(true, false, 6, bias_frag);
+    if (w == 5) K5H_LAUNCH(true, false, 5, bias_frag); else if (w == 7) K5H_LAUNCH(true, false, 7, bias_frag); else K5H_LAUNCH(true, false, 6, bias_frag);
   } else {
-    if (w5) K5H_LAUNCH(false, false, 5, bias); else K5H_LAUNCH(false, false, 6, bias);
+    if (w == 5) K5H_LAUNCH(false, false, 5, bias); else if (w == 7) K5H_LAUNCH(false, false, 7, bias); else K5H_LAUNCH(false, false, 6, bias);
   }
 #undef K5H_LAUNCH
   return rba_launch_status();
