@@ -1,5 +1,7 @@
 """GPU: the whole product path (Swin -> pixel decoder -> masked decoder -> RbA reduction, HIP kernels K1-K5) against
 the golden fixtures of the reference and against the oracle run on the same seeded weights."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -669,7 +671,7 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
         # profiles/r04_k1_mx_soak.txt -- and restored the strict form.  It recurred ONCE in a full-suite run late in round 4 (1 of 5 runs that day): image 0,
         # 18 760 of 24 576 pixels, max 2.7e-6 -- a different summation order somewhere, not a corrupted tile.  On a mismatch the test now says which side moved:
         # the eager bf16x6 map is computed again AFTER the evaluator and both are compared with it.)
-        if not np.array_equal(s_, w_.cpu().numpy()):
+        if not np.array_equal(s_, w_.cpu().numpy()) or os.environ.get("RBA_TEST_FORCE_RESCORE_DIAG") == "1":    # (the env switch exercises the report path)
             model.graph_replay = False
             with ops.split_mode("bf16x6"):
                 after = model.rba_scores([{"image": imgs[k_].cuda()}])[0].cpu().numpy()
@@ -678,7 +680,20 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
                     "eager-before vs eager-after": d(w_.cpu().numpy(), after)}
             # Not reproduced on demand (5 consecutive suite runs, 3 fresh-box probes, 2 500 op-traced + 900 plain forwards of this very sequence: tools/flake_probe.py,
             # tools/rescore_soak.py), so the run is not failed for a perturbation 40x below the score tolerance -- but it is reported, with the side that moved.
+            # Round 4, last session: it is box-dependent (three of three suite runs on one box, none on most).  When it happens the process is the place to look: the
+            # eager bf16x6 forward is repeated with every op check-summed until two consecutive runs differ, and the first op that moved is part of the report.
             import warnings
+            import sys
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from _optrace import first_difference, traced
+            prev, moved = None, None
+            for rep_ in range(6):
+                with traced() as tr_, ops.split_mode("bf16x6"):
+                    model.rba_scores([{"image": imgs[k_].cuda()}])
+                if prev is not None and moved is None:
+                    moved = first_difference(prev, tr_)
+                prev = list(tr_)
+            diag["first op that moved between consecutive traced eager forwards"] = moved
             warnings.warn(f"bf16x6 re-score differs from the eager bf16x6 map in its last bits: {diag}")
             assert diag["evaluator vs eager-before"][0] < 2e-5, diag
     r = ev.evaluate_ood(scores, gts, verbose=False)
