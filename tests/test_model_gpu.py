@@ -682,6 +682,8 @@ def test_non_finite_f16x3_score_is_rescored_on_bf16x6(tmp_path, monkeypatch):
             # tools/rescore_soak.py), so the run is not failed for a perturbation 40x below the score tolerance -- but it is reported, with the side that moved.
             # Round 4, last session: it is box-dependent (three of three suite runs on one box, none on most).  When it happens the process is the place to look: the
             # eager bf16x6 forward is repeated with every op check-summed until two consecutive runs differ, and the first op that moved is part of the report.
+            # CAUGHT that way (profiles/r04_flake_cause.txt): F.conv2d [1,256,4,6] x [64,256,1,1] -- MIOpen's 1x1 convolution of the NCHW fallback layout; those
+            # convolutions now run as token Linears (pixel_decoder/msdeformattn.py::_conv1x1_nchw).  The report stays in case the NCHW path's 3x3 MIOpen calls move too.
             import warnings
             import sys
             sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
