@@ -220,6 +220,21 @@ int rba_split_linear_f16x3_frag_f32(const void* x_frag, const void* weight_packe
  *                                     (backbone/swin.py:165-168 -> :169); head_dim 32, 12 x 12 windows, bias_frag required. */
 int rba_swin_window_attn_split_out_f32(const float* qkv, const float* qkv_bias, const float* bias_frag, void* out_frag, int B, int H, int W,
                                        int nH, int hd, int ws, int shift, void* stream);
+/* K7 -- the attention half of a Swin block in one launch (backbone/swin.py:235-284: norm1 -> pad / roll / window_partition ->
+ * WindowAttention (:131-171: qkv, relative-position bias, SW-MSA mask of :413-440, softmax, proj) -> window_reverse / un-roll / crop ->
+ * `x = shortcut + x`), and optionally norm2 of :284-293:
+ *     x [B, H*W, C] <- x + proj(window_attention(qkv(norm1(x))));    y2 [B, H*W, C] = norm2(x) when y2 != NULL
+ * One workgroup per 12 x 12 window; f16x3 arithmetic (|values| < 65504, NaN beyond).  weight_image = rba_swin_attn_block_pack_f32 of
+ * qkv.weight [3C, C] and proj.weight [C, C] (rba_swin_attn_block_weight_bytes(C) bytes); bias_frag = rba_swin_bias_fragments_f32 of the
+ * gathered relative-position bias [C/32, 144, 144].  rba_swin_attn_block_supported(C, ws) says which geometries have a kernel
+ * (hipErrorInvalidValue otherwise: the caller keeps the unfused sequence rba_add_layer_norm -> rba_split_linear -> rba_swin_window_attn
+ * -> rba_split_linear). */
+int rba_swin_attn_block_supported(int C, int ws);
+int64_t rba_swin_attn_block_weight_bytes(int C);
+int rba_swin_attn_block_pack_f32(const float* qkv_weight, const float* proj_weight, void* image, int C, void* stream);
+int rba_swin_attn_block_f32(float* x, float* y2, const float* norm1_weight, const float* norm1_bias, float eps1, const void* weight_image,
+                            const float* qkv_bias, const float* bias_frag, const float* proj_bias, const float* norm2_weight,
+                            const float* norm2_bias, float eps2, int B, int H, int W, int C, int ws, int shift, void* stream);
 /*   rba_resample_bilinear_nhwc_split_out_f32 -> rba_conv3x3_nhwc_f16x3_split_in_f32 = the FPN's `lateral + F.interpolate(prev)` sum handed to
  *                                     its 3 x 3 output convolution as a split image of [B H W, C] rows (pixel_decoder/msdeformattn.py:352-361);
  *                                     the convolution (>= 256 tiles of 128 x 128) gathers the pieces of the neighbour pixels' rows. */

@@ -34,6 +34,10 @@ SIGNATURES = {
     "rba_swin_window_attn_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_window_attn_split_out_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_bias_fragments_elems": [_i, _i],
+    "rba_swin_attn_block_supported": [_i, _i],
+    "rba_swin_attn_block_weight_bytes": [_i],
+    "rba_swin_attn_block_pack_f32": [_vp, _vp, _vp, _i, _vp],
+    "rba_swin_attn_block_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_bias_fragments_f32": [_vp, _vp, _i, _i, _vp],
     "rba_skinny_linear_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "rba_skinny_linear_add_f32": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -84,7 +88,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 186        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 187        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

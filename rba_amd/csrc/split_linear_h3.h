@@ -182,7 +182,7 @@ __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f3
   if (GNM) {
     __syncthreads();
     const int gpt = BN / gm.cpg, t = 64 * wave + 32 * lh + l31;                       // thread of this 128-row half
-    if (t < gpt) {
+    if (t < gpt && m0 < M) {                                                           // (a 256-row form's second half may start at M: nothing to report, and no slot to write)
       double ds = 0, dq = 0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -1042,7 +1042,7 @@ int launch_h3p_fout(const void* x, const u32x4_t* wp, const float* bias, void* o
 inline int launch_h3p_conv_pre_gnm(const void* xf, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int H, int W, int Cin,
                                    const GnMoments gm, hipStream_t st) {
   const int NT = (N + 127) / 128;
-  if (h3p_use_rs2(M, N, 9 * Cin)) {
+  if ((M & 255) == 0 && h3p_use_rs2(M, N, 9 * Cin)) {                    // moments are per 128-row tile: the 256-row form only where both halves are whole tiles
     const int64_t MT2 = (M + 255) / 256;
     if (MT2 * NT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL((split_linear_h3p_kernel<0, 0, false, false, 2, true, false, 1, true, 2, true>), dim3((unsigned)(MT2 * NT)), dim3(512), 0, st,

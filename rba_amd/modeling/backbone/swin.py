@@ -33,6 +33,15 @@ class WindowAttention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3)
         self.proj = nn.Linear(dim, dim)
         self._bias_cache = None
+        self._block_image = None
+
+    def block_image(self):
+        """K7's packed qkv + proj weights (ops.swin_attn_block_weights), once per weight load."""
+        wq, wp = self.qkv.weight, self.proj.weight
+        key = (wq.data_ptr(), wq._version, wp.data_ptr(), wp._version, wq.device)
+        if self._block_image is None or self._block_image[0] != key:
+            self._block_image = (key, ops.swin_attn_block_weights(wq.detach().contiguous(), wp.detach().contiguous()))
+        return self._block_image[1]
 
     def gathered_bias(self):
         """[nH, N, N] relative-position bias (swin.py:148-155), gathered once per weight load."""
@@ -69,6 +78,22 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn
         t, tb = pending if pending is not None else (None, None)
         M, C = x.numel() // x.shape[-1], x.shape[-1]
+        if x.is_cuda and x.dim() == 3 and ops.swin_attn_block_ok(C, self.num_heads, self.window_size):
+            # K7: norm1 -> qkv -> (shifted-)window attention -> proj -> + shortcut -> norm2 in ONE kernel, in place over x
+            if pending is not None:
+                x = x + t + tb
+            x = x.contiguous()
+            bias_frag = a.gathered_bias()[1]
+            x, y = ops.swin_attn_block(x, (self.norm1.weight, self.norm1.bias, self.norm1.eps), a.block_image(), a.qkv.bias, bias_frag, a.proj.bias, H, W,
+                                       self.window_size, self.shift_size, norm2=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
+            hidden = self.mlp.fc1.out_features
+            if ops.mlp_fused_ok(M, C, hidden):
+                return ops.mlp_fused(y, self.mlp.fc1, self.mlp.fc2, x), None
+            if ops.linear_residual_fused(M, C, hidden):
+                y = ops.linear(y, self.mlp.fc1, gelu=True, split_out=ops.linear_takes_split(M, C, hidden))
+                return ops.linear(y, self.mlp.fc2, residual=x), None
+            y = ops.linear(y, self.mlp.fc1, gelu=True)
+            return x, (ops.linear(y, self.mlp.fc2, use_bias=False), self.mlp.fc2.bias)
         # where the consumer is the pipelined f16x3 GEMM, the LayerNorm hands its output over already split and in MFMA fragment
         # order (ops.SplitActivations): one split per element instead of one per column tile, contiguous operand loads
         x, y = ops.add_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, t, tb, inplace_sum=True,

@@ -293,6 +293,64 @@ def swin_window_attn(qkv, qkv_bias, rel_bias, H, W, num_heads, window_size, shif
     return out
 
 
+SWIN_ATTN_FUSED = os.environ.get("RBA_SWIN_ATTN_FUSED", "1") != "0"      # A/B switch (tools): 0 keeps the unfused LN -> qkv -> K5 -> proj sequence
+
+
+def swin_attn_block_ok(C, num_heads, window_size):
+    """True when swin_attn_block() has a kernel for this geometry (K7: head_dim 32, 12 x 12 windows, f16x3 mode)."""
+    return (SWIN_ATTN_FUSED and SPLIT_MODE == "f16x3" and num_heads * 32 == C
+            and bool(_lib.load().rba_swin_attn_block_supported(int(C), int(window_size))))
+
+
+@_hip_op
+def swin_attn_block_weights(qkv_weight, proj_weight):
+    """qkv.weight [3C, C] + proj.weight [C, C] -> K7's per-head image of MFMA operand fragments (uint8; once per weight load)."""
+    lib = _lib.load()
+    _chk(qkv_weight, "qkv_weight", dim=2)
+    _chk(proj_weight, "proj_weight", dim=2)
+    C = proj_weight.shape[0]
+    if tuple(qkv_weight.shape) != (3 * C, C) or tuple(proj_weight.shape) != (C, C) or C % 32:
+        raise RbaHipError("swin_attn_block_weights needs qkv.weight [3C, C] and proj.weight [C, C], C % 32 == 0")
+    img = torch.empty(int(lib.rba_swin_attn_block_weight_bytes(C)), dtype=torch.uint8, device=qkv_weight.device)
+    _lib.check(lib.rba_swin_attn_block_pack_f32(_p(qkv_weight), _p(proj_weight), _p(img), C, _stream()), "rba_swin_attn_block_pack_f32")
+    return img
+
+
+@_hip_op
+def swin_attn_block(x, norm1, image, qkv_bias, bias_frag, proj_bias, H, W, window_size, shift, norm2=None):
+    """K7: x [B, H*W, C] <- x + proj(window_attention(qkv(norm1(x)))) IN PLACE (swin.py:235-284); with ``norm2`` also returns
+    y2 = norm2(x) (:284-293).  norm1 / norm2 = (weight, bias, eps); image = swin_attn_block_weights(...); bias_frag = swin_bias_fragments(...).
+    Returns (x, y2 | None).  Check swin_attn_block_ok first."""
+    lib = _lib.load()
+    _chk(x, "x", dim=3)
+    B, L, C = x.shape
+    if L != H * W or not lib.rba_swin_attn_block_supported(int(C), int(window_size)):
+        raise RbaHipError("swin_attn_block: check swin_attn_block_ok(C, num_heads, window_size) first; x must be [B, H*W, C]")
+    g1, b1, eps1 = norm1
+    for t, name in ((g1, "norm1.weight"), (b1, "norm1.bias"), (proj_bias, "proj_bias")):
+        _chk(t, name, dim=1)
+        if t.numel() != C:
+            raise RbaHipError(f"{name} must have C elements")
+    _chk(qkv_bias, "qkv_bias", dim=1)
+    _chk(bias_frag, "bias_frag", dim=1)
+    _chk(image, "image", dtype=torch.uint8, dim=1)
+    if (qkv_bias.numel() != 3 * C or image.numel() != lib.rba_swin_attn_block_weight_bytes(int(C))
+            or bias_frag.numel() != lib.rba_swin_bias_fragments_elems(C // 32, int(window_size))):
+        raise RbaHipError("qkv_bias must be [3C]; image / bias_frag must come from swin_attn_block_weights / swin_bias_fragments")
+    y2, g2, b2, eps2 = None, None, None, 0.0
+    if norm2 is not None:
+        g2, b2, eps2 = norm2
+        _chk(g2, "norm2.weight", dim=1)
+        _chk(b2, "norm2.bias", dim=1)
+        if g2.numel() != C or b2.numel() != C:
+            raise RbaHipError("norm2 weight / bias must have C elements")
+        y2 = torch.empty_like(x)
+    _lib.check(lib.rba_swin_attn_block_f32(_p(x), _p(y2), _p(g1), _p(b1), float(eps1), _p(image), _p(qkv_bias), _p(bias_frag), _p(proj_bias),
+                                           _p(g2), _p(b2), float(eps2), B, H, W, C, int(window_size), int(shift), _stream()),
+               "rba_swin_attn_block_f32")
+    return x, y2
+
+
 @_hip_op
 def group_norm(x, num_groups, weight, bias, eps=1e-5, relu=False):
     """GroupNorm (+ReLU) of x [B,C,h,w] -- the norm/activation of Detectron2's Conv2d wrapper

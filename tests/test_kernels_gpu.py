@@ -417,6 +417,80 @@ def test_k5_register_budgets_are_bit_identical(ops):
                     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+# ----------------------------------------------------------------------------------- K7
+def _k7_reference(x, n1, qkv_w, qkv_b, proj_w, proj_b, table, H, W, ws, nH, shift, n2):
+    """swin.py:235-293 up to norm2, in float64: norm1 -> pad -> roll -> partition -> window attention -> reverse -> un-roll -> crop -> + shortcut"""
+    B, L, C = x.shape
+    xd = x.double()
+    y = F.layer_norm(xd, (C,), n1[0].double(), n1[1].double(), n1[2]).view(B, H, W, C)
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    xp = F.pad(y, (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = xp.shape[1], xp.shape[2]
+    if shift:
+        xp = torch.roll(xp, (-shift, -shift), (1, 2))
+    xw = xp.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    mask = ref_ops.shift_attn_mask(H, W, ws, shift).double() if shift else None
+    aw = ref_ops.window_attention(xw, qkv_w.double(), qkv_b.double(), proj_w.double(), proj_b.double(), table.double(), ws, nH, mask)
+    o = aw.view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    xn = xd + o[:, :H, :W].reshape(B, L, C)
+    return xn, F.layer_norm(xn, (C,), n2[0].double(), n2[1].double(), n2[2])
+
+
+@pytest.mark.parametrize("B,H,W,shift", [(1, 24, 36, 0), (2, 30, 41, 6), (1, 7, 5, 6), (1, 12, 12, 0), (1, 50, 26, 6), (3, 13, 24, 0)])
+def test_k7_swin_attn_block(ops, B, H, W, shift):
+    """round 5: the attention half of a Swin block (norm1 -> qkv -> (shifted-)window attention -> proj -> + shortcut [-> norm2]) as ONE kernel,
+    against the float64 restatement of swin.py:235-293 and against the unfused sequence of this library (LN -> K6 -> K5 -> K6)."""
+    C, nH, ws = 128, 4, 12
+    assert ops.swin_attn_block_ok(C, nH, ws)
+    g = torch.Generator().manual_seed(H * W + shift)
+    x = torch.randn(B, H * W, C, generator=g) * 1.5 + 0.3
+    n1 = (torch.randn(C, generator=g) * 0.3 + 1.0, torch.randn(C, generator=g) * 0.2, 1e-5)
+    n2 = (torch.randn(C, generator=g) * 0.3 + 1.0, torch.randn(C, generator=g) * 0.2, 1e-5)
+    qkv_w, qkv_b = torch.randn(3 * C, C, generator=g) * C ** -0.5, torch.randn(3 * C, generator=g) * 0.2
+    proj_w, proj_b = torch.randn(C, C, generator=g) * C ** -0.5, torch.randn(C, generator=g) * 0.2
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g) * 0.5
+    want_x, want_y = _k7_reference(x, n1, qkv_w, qkv_b, proj_w, proj_b, table, H, W, ws, nH, shift, n2)
+    N = ws * ws
+    bias = table[ref_ops.relative_position_index(ws).view(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
+    frag = ops.swin_bias_fragments(dev(bias), ws)
+    img = ops.swin_attn_block_weights(dev(qkv_w), dev(proj_w))
+    d1, d2 = (dev(n1[0]), dev(n1[1]), n1[2]), (dev(n2[0]), dev(n2[1]), n2[2])
+    xg = dev(x)
+    out_x, out_y = ops.swin_attn_block(xg, d1, img, dev(qkv_b), frag, dev(proj_b), H, W, ws, shift, norm2=d2)
+    assert out_x.data_ptr() == xg.data_ptr()                                          # in place
+    assert maxerr(out_x, want_x) < 2e-5 and maxerr(out_y, want_y) < 3e-5
+    x2 = dev(x)
+    out2, none = ops.swin_attn_block(x2, d1, img, dev(qkv_b), frag, dev(proj_b), H, W, ws, shift)
+    assert none is None and torch.equal(out2, out_x)
+    # the unfused sequence on the same inputs: same arithmetic family (f16x3), different summation order
+    y1 = ops.add_layer_norm(dev(x), d1[0], d1[1], d1[2])[1]
+    qkv = F.linear(y1, dev(qkv_w), dev(qkv_b))
+    att = ops.swin_window_attn(qkv, dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag)
+    unf = dev(x) + F.linear(att, dev(proj_w), dev(proj_b))
+    assert maxerr(out_x, unf.double()) < 2e-5
+    with pytest.raises(ops.RbaHipError):
+        ops.swin_attn_block(dev(x[:, :, :96].contiguous()), d1, img, dev(qkv_b), frag, dev(proj_b), H, W, ws, shift)
+
+
+def test_k7_f16_range_is_loud(ops):
+    """like K5 / K6: a value beyond f16's range gives NaN rows, never a silently wrong finite result"""
+    C, nH, ws, H, W = 128, 4, 12, 12, 24
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, H * W, C, generator=g)
+    one, zero = torch.ones(C), torch.zeros(C)
+    b1 = zero.clone()
+    b1[5] = 1e5                                                                       # norm1 output beyond 65504 in channel 5
+    qkv_w, qkv_b = torch.randn(3 * C, C, generator=g) * C ** -0.5, torch.zeros(3 * C)
+    proj_w, proj_b = torch.randn(C, C, generator=g) * C ** -0.5, zero
+    bias = torch.zeros(nH, ws * ws, ws * ws)
+    frag = ops.swin_bias_fragments(dev(bias), ws)
+    img = ops.swin_attn_block_weights(dev(qkv_w), dev(proj_w))
+    out, _ = ops.swin_attn_block(dev(x), (dev(one), dev(b1), 1e-5), img, dev(qkv_b), frag, dev(proj_b), H, W, ws, 0)
+    assert torch.isnan(out).all()
+
+
 # ----------------------------------------------------------------------------------- GroupNorm
 @pytest.mark.parametrize("B,C,h,w,relu", [(1, 256, 32, 64, False), (1, 256, 64, 128, True), (2, 64, 15, 23, True),
                                            (1, 256, 256, 512, True)])
