@@ -9,9 +9,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["rba_reduce.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn.hip", "mask_logits.hip",
            "swin_window_attn.hip", "swin_attn_block.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "split_linear_dma.hip", "gaussian_blur.hip", "open_panoptic.hip", "dense_hybrid.hip", "patch_embed.hip", "token_linear.hip", "decoder_small.hip"]
-HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h",
+HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h", "swin_attn_block.h",
            os.path.join("..", "..", "include", "rba_hip.h")]
-TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip"), os.path.join("tune", "split_linear_ws.hip"), os.path.join("tune", "mlp_fused_h1.hip"), os.path.join("tune", "k5_timing.hip"), os.path.join("tune", "k5_wpe_ab.hip"), os.path.join("tune", "k5_wpe_plain.hip"), os.path.join("tune", "k5_persist.hip")]
+TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip"), os.path.join("tune", "split_linear_ws.hip"), os.path.join("tune", "mlp_fused_h1.hip"), os.path.join("tune", "k5_timing.hip"), os.path.join("tune", "k5_wpe_ab.hip"), os.path.join("tune", "k5_wpe_plain.hip"), os.path.join("tune", "k5_persist.hip"), os.path.join("tune", "k7_timing.hip")]
 TUNE_LIB = os.path.join(HERE, "tune", "librba_tune.so")
 LIB = os.path.join(HERE, "librba_hip.so")
 OBJ = os.path.join(HERE, "build")
