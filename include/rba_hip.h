@@ -257,6 +257,9 @@ int rba_conv3x3_nhwc_f16x3_split_in_f32(const void* x_frag, const void* weight_p
  *                                     one v_permlane32_swap); bit-identical to the two-kernel hand-over below. */
 int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
                                  const float* residual, float* out, int64_t M, int C, int HID, void* stream);
+/*   rba_swin_mlp_fused_ln_f16x3_f32 = the same kernel with norm2 in its prologue: x <- x + fc2(GELU(fc1(LayerNorm(x)))) in place (backbone/swin.py:293). */
+int rba_swin_mlp_fused_ln_f16x3_f32(float* x, const float* norm_weight, const float* norm_bias, float eps, const void* w1_packed, const float* b1,
+                                    const void* w2_packed, const float* b2, int64_t M, int C, int HID, void* stream);
 /*   rba_split_linear_f16x3_gelu_split_out = GELU(x W^T + bias) written as the split image of the NEXT Linear (Mlp.fc1 -> fc2,
  *                                     backbone/swin.py:35-41): the GEMM runs with its MFMA operands swapped (D^T = W x^T), so a lane ends
  *                                     up with consecutive output channels of one row and stores 16-byte pieces.  x: fp32 rows

@@ -48,6 +48,7 @@ SIGNATURES = {
     "rba_split_linear_f16x3_res_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_f16x3_frag_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_swin_mlp_fused_f16x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
+    "rba_swin_mlp_fused_ln_f16x3_f32": [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_f16x3_gelu_split_out": [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp],
     "rba_split_linear_nchw_out_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_split_linear_nchw_out_f16x3_f32": [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
@@ -88,7 +89,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 187        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 188        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

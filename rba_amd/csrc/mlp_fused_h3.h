@@ -19,10 +19,19 @@
 namespace {
 
 // PROBE (tune builds only, results wrong): 1 no GELU arithmetic, 2 no fc1 MFMAs, 4 no fc2 MFMAs, 8 no weight staging / barrier in the loop
-template <int PROBE = 0>
-__global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __restrict__ X, const u32x4_t* __restrict__ W1p,
+// LNIN (round 5): X holds the block's residual stream, not norm2's output: the wave normalises its rows itself (swin.py:293 `self.mlp(self.norm2(x))`; the
+// arithmetic of add_layer_norm_kernel: mean, centred variance, (v - mean) * rstd * gamma + beta) -- a lane already holds half of a row, the other half is one
+// xor-shuffle away -- so that neither the LayerNorm launch nor its output tensor exist (X is then also the residual R).
+struct MlpNorm {
+  const float* gamma;
+  const float* beta;
+  float eps;
+};
+template <int PROBE = 0, bool LNIN = false>
+__global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* X, const u32x4_t* __restrict__ W1p,
                                                               const float* __restrict__ b1, const u32x4_t* __restrict__ W2p,
-                                                              const float* __restrict__ b2, const float* R, float* C, int M, int HID) {
+                                                              const float* __restrict__ b2, const float* R, float* C, int M, int HID,
+                                                              MlpNorm ln = MlpNorm{nullptr, nullptr, 0.f}) {
   constexpr int K1 = 128, NB1 = K1 / 32, N2 = 128, CT = 4;
   constexpr int W1U = 1024, W2U = 1024;                                            // 16-byte units per W1 chunk / W2 block
   __shared__ __attribute__((aligned(16))) u32x4_t lds[2 * (W1U + W2U)];
@@ -45,6 +54,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
     for (int b = 0; b < NB1; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) xr[b][q] = *reinterpret_cast<const f32x4*>(xp + b * 128 + q * 16);
+    if (LNIN) {                                                                    // lane: channels 32 b + 16 lh + 4 q .. + 3 of row l31
+      float sum = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB1; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += (xr[b][q].x + xr[b][q].y) + (xr[b][q].z + xr[b][q].w);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum / (float)K1;
+      float sq = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB1; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 d = xr[b][q] - mean;
+          sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+      sq += __shfl_xor(sq, 32, 64);
+      const float rstd = 1.0f / sqrtf(sq / (float)K1 + ln.eps);
+      const char* gp = reinterpret_cast<const char*>(ln.gamma) + 64 * lh;
+      const char* bp = reinterpret_cast<const char*>(ln.beta) + 64 * lh;
+#pragma unroll
+      for (int b = 0; b < NB1; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(gp + b * 128 + q * 16), b4 = *reinterpret_cast<const f32x4*>(bp + b * 128 + q * 16);
+          xr[b][q] = (xr[b][q] - mean) * rstd * g4 + b4;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < NB1; ++b) {
       split_h3(xr[b][0], xr[b][1], xh[b][0], xl[b][0]);
@@ -226,10 +263,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* __res
 }
 
 inline int launch_mlp_fused(const float* x, const u32x4_t* w1p, const float* b1, const u32x4_t* w2p, const float* b2, const float* res, float* out,
-                            int64_t M, int HID, hipStream_t st) {
+                            int64_t M, int HID, hipStream_t st, const float* gamma = nullptr, const float* beta = nullptr, float eps = 0.f) {
   const int64_t MT = (M + 127) / 128;
   if (MT >= (int64_t)1 << 31) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL((mlp_fused_h3_kernel<0>), dim3((unsigned)MT), dim3(256), 0, st, x, w1p, b1, w2p, b2, res, out, (int)M, HID);
+  if (gamma)
+    hipLaunchKernelGGL((mlp_fused_h3_kernel<0, true>), dim3((unsigned)MT), dim3(256), 0, st, x, w1p, b1, w2p, b2, res, out, (int)M, HID, MlpNorm{gamma, beta, eps});
+  else
+    hipLaunchKernelGGL((mlp_fused_h3_kernel<0>), dim3((unsigned)MT), dim3(256), 0, st, x, w1p, b1, w2p, b2, res, out, (int)M, HID, MlpNorm{nullptr, nullptr, 0.f});
   return 0;
 }
 

@@ -254,6 +254,21 @@ extern "C" int rba_swin_mlp_fused_f16x3_f32(const float* x, const void* w1_packe
   return rba_launch_status();
 }
 
+// The same kernel from the block's residual stream: x <- x + fc2(GELU(fc1(norm2(x)))) in place, norm2 computed by the kernel itself from the rows it loads
+// anyway (backbone/swin.py:293 whole): neither the LayerNorm launch nor its output tensor exist.
+extern "C" int rba_swin_mlp_fused_ln_f16x3_f32(float* x, const float* norm_weight, const float* norm_bias, float eps, const void* w1_packed, const float* b1,
+                                               const void* w2_packed, const float* b2, int64_t M, int C, int HID, void* stream) {
+  RBA_CHECK_ARG(M >= 0 && C == 128 && HID >= 64 && (HID % 32) == 0);
+  if (M == 0) return 0;
+  RBA_CHECK_ARG(x && norm_weight && norm_bias && w1_packed && b1 && w2_packed && M < (int64_t)1 << 31);
+  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)b1 | (uintptr_t)norm_weight | (uintptr_t)norm_bias) & 15) == 0);
+  rba_begin();
+  const int rc = launch_mlp_fused(x, reinterpret_cast<const u32x4_t*>(w1_packed), b1, reinterpret_cast<const u32x4_t*>(w2_packed), b2, x, x, M, HID,
+                                  (hipStream_t)stream, norm_weight, norm_bias, eps);
+  if (rc) return rc;
+  return rba_launch_status();
+}
+
 // x [B * P, K] (NHWC rows) -> out [B, N, P] (NCHW) on the f16x3 kernel: the mask-feature projection (pixel_decoder/msdeformattn.py:362,
 // `self.mask_features(y)`), whose consumer K4 reads [C][pixels].  weight_packed = rba_split_weight_f16x2.  (The bf16x6 form of the same
 // operator is rba_split_linear_nchw_out_f32.)

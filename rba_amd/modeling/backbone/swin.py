@@ -84,11 +84,13 @@ class SwinTransformerBlock(nn.Module):
                 x = x + t + tb
             x = x.contiguous()
             bias_frag = a.gathered_bias()[1]
-            x, y = ops.swin_attn_block(x, (self.norm1.weight, self.norm1.bias, self.norm1.eps), a.block_image(), a.qkv.bias, bias_frag, a.proj.bias, H, W,
-                                       self.window_size, self.shift_size, norm2=(self.norm2.weight, self.norm2.bias, self.norm2.eps))
             hidden = self.mlp.fc1.out_features
-            if ops.mlp_fused_ok(M, C, hidden):
-                return ops.mlp_fused(y, self.mlp.fc1, self.mlp.fc2, x), None
+            n2 = (self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            fused_mlp = ops.mlp_fused_ok(M, C, hidden)               # the one-kernel MLP computes norm2 itself from the residual stream: K7 then writes x only
+            x, y = ops.swin_attn_block(x, (self.norm1.weight, self.norm1.bias, self.norm1.eps), a.block_image(), a.qkv.bias, bias_frag, a.proj.bias, H, W,
+                                       self.window_size, self.shift_size, norm2=None if fused_mlp else n2)
+            if fused_mlp:
+                return ops.mlp_fused_ln(x, n2, self.mlp.fc1, self.mlp.fc2), None
             if ops.linear_residual_fused(M, C, hidden):
                 y = ops.linear(y, self.mlp.fc1, gelu=True, split_out=ops.linear_takes_split(M, C, hidden))
                 return ops.linear(y, self.mlp.fc2, residual=x), None

@@ -722,6 +722,25 @@ def mlp_fused(x, fc1, fc2, residual):
     return residual
 
 
+@_hip_op
+def mlp_fused_ln(x, norm, fc1, fc2):
+    """x <- x + fc2(GELU(fc1(LayerNorm(x)))) IN PLACE in one kernel (swin.py:293): mlp_fused with norm2 computed in the kernel's prologue from the rows it
+    loads anyway.  norm = (weight, bias, eps).  Same conditions as mlp_fused (check mlp_fused_ok)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    g, b, eps = norm
+    _chk(g, "norm.weight", dim=1)
+    _chk(b, "norm.bias", dim=1)
+    C, hidden = fc1.weight.shape[1], fc1.weight.shape[0]
+    M = x.numel() // C
+    if (x.shape[-1] != C or tuple(fc2.weight.shape) != (C, hidden) or C != 128 or hidden % 32 or SPLIT_MODE != "f16x3" or g.numel() != C or b.numel() != C):
+        raise RbaHipError("mlp_fused_ln needs C == 128, hidden % 32 == 0, matching fc1 / fc2 / norm and the f16x3 mode")
+    _lib.check(lib.rba_swin_mlp_fused_ln_f16x3_f32(_p(x), _p(g), _p(b), float(eps), _p(_cached_planes(fc1, fc1.weight)), _p(fc1.bias),
+                                                   _p(_cached_planes(fc2, fc2.weight)), _p(fc2.bias), M, C, hidden, _stream()),
+               "rba_swin_mlp_fused_ln_f16x3_f32")
+    return x
+
+
 def linear_residual_fused(M, N, K):
     """True when linear(..., residual=r) runs as ONE kernel (the f16x3 GEMM with the residual add in its epilogue)."""
     return SPLIT_MODE == "f16x3" and split_linear_pays(M, N, K)

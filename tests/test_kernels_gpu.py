@@ -873,6 +873,33 @@ def test_swin_mlp_fused(ops, M, hidden):
     assert ops.mlp_fused_ok(131072, 128, 512) and not ops.mlp_fused_ok(131072, 192, 768) and not ops.mlp_fused_ok(8192, 128, 512)
 
 
+def test_swin_mlp_fused_with_norm2_in_its_prologue(ops):
+    """round 5: x <- x + fc2(GELU(fc1(norm2(x)))) with the LayerNorm computed by the MLP kernel itself, against float64 and against LN -> mlp_fused"""
+    from torch import nn
+    g = torch.Generator().manual_seed(11)
+    for M in (32768, 32768 + 77):
+        C, hidden = 128, 512
+        fc1, fc2 = nn.Linear(C, hidden), nn.Linear(hidden, C)
+        with torch.no_grad():
+            for p_ in (fc1.weight, fc2.weight):
+                p_.copy_(torch.randn(p_.shape, generator=g) * p_.shape[1] ** -0.5)
+            fc1.bias.copy_(torch.randn(hidden, generator=g) * 0.2)
+            fc2.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        fc1, fc2 = fc1.cuda(), fc2.cuda()
+        x = torch.randn(M, C, generator=g) * 2.0 + 0.5
+        gam, bet = torch.randn(C, generator=g) * 0.3 + 1.0, torch.randn(C, generator=g) * 0.2
+        xd = x.double()
+        y = F.layer_norm(xd, (C,), gam.double(), bet.double(), 1e-5)
+        want = xd + F.linear(F.gelu(F.linear(y, fc1.weight.double().cpu(), fc1.bias.double().cpu())), fc2.weight.double().cpu(), fc2.bias.double().cpu())
+        xg = dev(x)
+        out = ops.mlp_fused_ln(xg, (dev(gam), dev(bet), 1e-5), fc1, fc2)
+        assert out.data_ptr() == xg.data_ptr() and maxerr(out, want) < 3e-5
+        x2 = dev(x)
+        y2 = ops.add_layer_norm(x2, dev(gam), dev(bet), 1e-5)[1]
+        two = ops.mlp_fused(y2, fc1, fc2, x2)
+        assert maxerr(out, two.double()) < 5e-6
+
+
 @pytest.mark.parametrize("rows,C", [(8192, 512), (2048, 1024), (1000, 96), (33, 32), (4100, 1536), (70, 2048)])
 def test_add_layer_norm_split_output(ops, rows, C):
     """add_layer_norm(frag=True): the LayerNorm output written directly as SplitActivations == pack(fp32 output), bit for bit, with and
