@@ -62,6 +62,9 @@ def parse():
                     help="experiment (tools): 1 = every stream of a step gets its own share of the 8 XCDs through a CU-masked HIP stream "
                          "(hipExtStreamCreateWithCUMask; queue mask bit i -> XCD i %% 8), so concurrent forwards do not share CUs or L2s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="N = 1 only: initialise a ONE-rank RCCL process group and run the metric-exchange leg through its collectives (all_gather of sizes + "
+                         "all_gather_into_tensor of device tensors), so that a 1-GPU box executes the code an N > 1 run executes")
     ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
                     help="quick (default, <= ~15 s): ONE full-size forward of the oracle at the pre-chosen thread count + the isolated reduction; "
                          "full: BASELINE.md section 3's protocol with the thread sweep, C1's size and one-thread legs (~50 s; also tools/cpu_baseline_sweep.py)")
@@ -385,6 +388,10 @@ def main():
     share = os.environ.get("RBA_BENCH_SHARE_DEVICE") == "1"
     if share:                                    # ranks share device 0: gloo (RCCL refuses two ranks on one device)
         os.environ["LOCAL_RANK"] = "0"
+    if args.rccl_one_rank and "WORLD_SIZE" not in os.environ:      # 1-GPU box: a ONE-rank RCCL group, so that the exchange leg below runs its collectives on RCCL itself
+        os.environ["RBA_DIST_ONE_RANK_GROUP"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     rank, world, local = D.init_from_env(os.environ.get("RBA_BENCH_BACKEND", "gloo" if share else None))
     if world != args.gpus:
         if not share and "RBA_BENCH_BACKEND" not in os.environ:
@@ -393,7 +400,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = torch.distributed if world > 1 else None
+    dist = torch.distributed if (world > 1 or (args.rccl_one_rank and torch.distributed.is_initialized())) else None
     n_ranks_seen, backend_seen = 1, None
     if dist is not None:
         backend_seen = dist.get_backend()
@@ -406,30 +413,13 @@ def main():
         n_ranks_seen = int(ones.item())
         assert n_ranks_seen == world == dist.get_world_size(), (n_ranks_seen, world)
 
-    if os.environ.get("RBA_K6_OCC"):                          # tools: A/B of the single-resident K6 build (see csrc/split_linear_h3.h)
-        import ctypes
-        from rba_amd import _lib
-        ctypes.c_int.in_dll(_lib.load(), "rba_k6_occ").value = int(os.environ["RBA_K6_OCC"])
-    if os.environ.get("RBA_K5_WPE"):                          # tools: A/B of K5's register budget (6 = 80 VGPRs, two workgroups per CU; 5 = 96 VGPRs, one)
-        import ctypes
-        from rba_amd import _lib
-        ctypes.c_int.in_dll(_lib.load(), "rba_k5_wpe").value = int(os.environ["RBA_K5_WPE"])
-    if os.environ.get("RBA_K6_RS"):                           # tools: A/B of the 256 x 128 / 8-wave K6 form (0 = by tile count, 1 = never, 2 = always)
-        import ctypes
-        from rba_amd import _lib
-        ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs").value = int(os.environ["RBA_K6_RS"])
-    if os.environ.get("RBA_K6_KS"):                           # tools: A/B of the K-split 8-wave form of the single-resident launches (0 = rule, 1 = never, 2 = wherever legal)
-        import ctypes
-        from rba_amd import _lib
-        ctypes.c_int.in_dll(_lib.load(), "rba_k6_ks").value = int(os.environ["RBA_K6_KS"])
-    if os.environ.get("RBA_K6_RS_MIN_K"):                     # tools: the 256 x 128 form only for K >= this
-        import ctypes
-        from rba_amd import _lib
-        ctypes.c_int.in_dll(_lib.load(), "rba_k6_rs_min_k").value = int(os.environ["RBA_K6_RS_MIN_K"])
-    if os.environ.get("RBA_K6_STAGGER"):                      # tools: late start of every CU's second K6 workgroup (100 MHz ticks)
-        import ctypes
-        from rba_amd import _lib
-        ctypes.c_int.in_dll(_lib.load(), "rba_k6_stagger").value = int(os.environ["RBA_K6_STAGGER"])
+    # tools: A/B of kernel variants through the tuning knobs of csrc/knobs.h.  They exist only in the knobs build of the library: run with
+    # RBA_HIP_LIB=rba_amd/csrc/librba_hip_knobs.so (the product library has no writable state; _lib.knob() says so otherwise).
+    for env, name in (("RBA_K6_OCC", "rba_k6_occ"), ("RBA_K5_WPE", "rba_k5_wpe"), ("RBA_K6_RS", "rba_k6_rs"), ("RBA_K6_KS", "rba_k6_ks"),
+                      ("RBA_K6_RS_MIN_K", "rba_k6_rs_min_k"), ("RBA_K6_STAGGER", "rba_k6_stagger")):
+        if os.environ.get(env):
+            from rba_amd import _lib
+            _lib.knob(name).value = int(os.environ[env])
     if "RBA_K6_RS" not in os.environ:
         ops.set_concurrent_streams(max(1, args.streams))        # S images of a step run on S streams at once: launch-geometry hint (include/rba_hip.h)
     a = A.complete(A.ARCHS[args.arch])
@@ -689,11 +679,15 @@ def main():
 
     # ---- pooled OoD metric exchange over RCCL, outside the timed region
     exch_ms = None
-    if world > 1:
+    if dist is not None:
         lab, valid = exchange_inputs(rank, h, w, dev)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
-        m = D.pooled_ood_metrics(out[valid], lab[valid])
+        if world == 1:                       # --rccl-one-rank: the collectives run although there is nobody to exchange with
+            with D.force_collective():
+                m = D.pooled_ood_metrics(out[valid], lab[valid])
+        else:
+            m = D.pooled_ood_metrics(out[valid], lab[valid])
         torch.cuda.synchronize()
         exch_ms = (time.perf_counter() - t1) * 1e3
 

@@ -3,8 +3,10 @@
  *
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated; no environment variables are read and
- *     there is no mutable global state except the launch-geometry hint of rba_set_concurrent_streams (the only other process-wide side effect is that the first launch of a kernel that needs
- *     more than 64 KiB of LDS sets that kernel's hipFuncAttributeMaxDynamicSharedMemorySize once); re-entrant; tensors
+ *     there is no mutable global state except the launch-geometry hint of rba_set_concurrent_streams -- `nm -D librba_hip.so` shows no writable rba_ symbol:
+ *     the kernel-variant knobs of csrc/knobs.h are compile-time constants here and variables only in the tools' knobs build librba_hip_knobs.so (the
+ *     only other process-wide side effects: the first launch of a kernel that needs more than 64 KiB of LDS sets that kernel's
+ *     hipFuncAttributeMaxDynamicSharedMemorySize once, and the persistent kernels cache the device's CU count); re-entrant; tensors
  *     are dense row-major ("contiguous") in the index order written next to them;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are only enqueued;
  *   - return value is a hipError_t as int (0 = hipSuccess); argument errors return hipErrorInvalidValue (1);
@@ -55,7 +57,7 @@ int rba_hip_version(void);
 
 /* Launch-geometry hint, the library's only caller-set state: the number of streams of this process that launch forwards concurrently
  * (default 1).  With n >= 2 the K6 launches that fill only half the chip take whole CUs (8-wave 256 x 128 workgroups) and leave the rest to the
- * other streams' kernels.  Affects speed only: every kernel form gives bit-identical results.  Returns the previous setting (1 or 2).
+ * other streams' kernels.  Affects speed only: every kernel form gives bit-identical results.  Returns the previous setting (n < 1 counts as 1).
  * Not thread-safe against concurrent launches; set it before the streams start (bench.py, evaluate_ood.run_evaluations do). */
 int rba_set_concurrent_streams(int n);
 
@@ -92,6 +94,11 @@ int rba_resample_bilinear_f32(const float* in, const float* add, float* out, int
  * Sample position h = y*H_l - 0.5, w = x*W_l - 0.5; bilinear, taps outside the map contribute 0. */
 int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* sampling_loc, const float* attn_weight, float* out,
+                               int N, int S, int M, int D, int L, int Lq, int P, void* stream);
+/* The same op in double precision -- the reference FFI dispatches float and double (ops/src/cuda/ms_deform_attn_cuda.cu:69, AT_DISPATCH_FLOATING_TYPES;
+ * ops/test.py:35-47 checks the double path first).  Same shapes and checks; generic kernel. */
+int rba_ms_deform_attn_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const double* sampling_loc, const double* attn_weight, double* out,
                                int N, int S, int M, int D, int L, int Lq, int P, void* stream);
 
 /* The sampling parameters of MSDeformAttn.forward in one pass (pixel_decoder/ops/modules/ms_deform_attn.py:95-115):

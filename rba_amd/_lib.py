@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RBA_HIP_LIB") or os.path.join(_HERE, "csrc", "librba_hip.so")   # env override: A/B runs of two builds
+# the same sources built with -DRBA_TUNE_KNOBS (csrc/knobs.h): the tuning knobs as exported, writable ints.  Tests and tools only -- the product library
+# (LIB_PATH) has no writable state besides rba_set_concurrent_streams' hint.  `use_library(KNOBS_LIB_PATH)` swaps it in for a block.
+KNOBS_LIB_PATH = os.path.join(_HERE, "csrc", "librba_hip_knobs.so")
 
 _c_f32p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -23,6 +26,7 @@ SIGNATURES = {
     "rba_reduce_up4_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_resample_bilinear_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "rba_ms_deform_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "rba_ms_deform_attn_fwd_f64": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "rba_msda_prepare_f32": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "rba_resample_bilinear_nhwc_gn_f32": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _vp],
     "rba_group_norm_nhwc_stats_f32": [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp],
@@ -89,7 +93,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 188        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 189        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 
@@ -103,28 +107,66 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    _lib = _open(LIB_PATH)
+    return _lib
+
+
+_handles = {}
+
+
+def _open(path):
+    if path in _handles:
+        return _handles[path]
     # torch bundles its own libamdhip64; it must be the HIP runtime already resident when librba_hip.so's
     # DT_NEEDED libamdhip64.so.N is resolved, otherwise the process ends up with a second runtime (the system one)
     # that owns our code objects but not torch's device context -> launches fail with hipErrorNoDevice.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise RbaHipError(
-            f"{LIB_PATH} not found: build it with `python -m rba_amd.csrc.build` (hipcc --offload-arch=gfx950). "
+            f"{path} not found: build it with `python -m rba_amd.csrc.build` (hipcc --offload-arch=gfx950; --knobs for the knobs build). "
             "rba_amd has no CPU or PyTorch fallback for its HIP kernels.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise RbaHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            raise RbaHipError(f"{path} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int64 if name.endswith(("_bytes", "_elems")) else ctypes.c_int
     abi = int(lib.rba_hip_version())
     if abi != EXPECTED_ABI:               # same names, possibly different argument lists: calling it would corrupt memory
-        raise RbaHipError(f"{LIB_PATH} has ABI version {abi}, these bindings are written for {EXPECTED_ABI}; rebuild it "
+        raise RbaHipError(f"{path} has ABI version {abi}, these bindings are written for {EXPECTED_ABI}; rebuild it "
                           "(python -m rba_amd.csrc.build)")
-    _lib = lib
+    _handles[path] = lib
     return lib
+
+
+class use_library:
+    """with use_library(path): every rba_amd.ops call of the block runs on ANOTHER build of the kernel library (same ABI) -- the knobs build for tests and
+    tools that select a kernel variant.  Not thread-safe; not for product code."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        _lib = _open(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def knob(name):
+    """ctypes int of a tuning knob of the CURRENT library -- exists only in the knobs build (csrc/knobs.h)."""
+    try:
+        return ctypes.c_int.in_dll(load(), name)
+    except ValueError as e:
+        raise RbaHipError(f"{name} is a compile-time constant in the product library: run on the knobs build (RBA_HIP_LIB={KNOBS_LIB_PATH} or "
+                          "rba_amd._lib.use_library(KNOBS_LIB_PATH); python -m rba_amd.csrc.build --knobs)") from e
 
 
 def hip_error_string(code: int) -> str:

@@ -1,5 +1,6 @@
-"""Build librba_hip.so (gfx950) in-tree with hipcc.  `python -m rba_amd.csrc.build [--force] [--tune]`
-(--tune also builds tune/librba_tune.so, the tools-only library of probes and experimental kernel variants).
+"""Build librba_hip.so (gfx950) in-tree with hipcc.  `python -m rba_amd.csrc.build [--force] [--knobs] [--tune]`
+(--knobs also builds librba_hip_knobs.so = the same sources with -DRBA_TUNE_KNOBS: the tuning knobs of csrc/knobs.h as exported, writable ints, for tests and
+tools -- the product library has none; --tune also builds tune/librba_tune.so, the tools-only library of probes and experimental kernel variants).
 Each .hip file is compiled to an object in parallel (hipcc --offload-arch=gfx950 -c), then linked with hipcc -shared."""
 import os
 import subprocess
@@ -9,11 +10,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["rba_reduce.hip", "resample.hip", "ms_deform_attn.hip", "masked_xattn.hip", "mask_logits.hip",
            "swin_window_attn.hip", "swin_attn_block.hip", "group_norm.hip", "layer_norm.hip", "skinny_linear.hip", "split_linear.hip", "split_linear_dma.hip", "gaussian_blur.hip", "open_panoptic.hip", "dense_hybrid.hip", "patch_embed.hip", "token_linear.hip", "decoder_small.hip"]
-HEADERS = ["common.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h", "swin_attn_block.h",
+HEADERS = ["common.h", "knobs.h", "rba_reduce_kernels.h", "split_linear_dma.h", "split_linear_h3.h", "split_linear_h3q.h", "mlp_fused_h3.h", "swin_window_attn_h3.h", "swin_attn_block.h",
            os.path.join("..", "..", "include", "rba_hip.h")]
 TUNE_SOURCES = [os.path.join("tune", "rba_reduce_tune.hip"), os.path.join("tune", "split_linear_tune.hip"), os.path.join("tune", "split_linear_ws.hip"), os.path.join("tune", "mlp_fused_h1.hip"), os.path.join("tune", "k5_timing.hip"), os.path.join("tune", "k5_wpe_ab.hip"), os.path.join("tune", "k5_wpe_plain.hip"), os.path.join("tune", "k5_persist.hip"), os.path.join("tune", "k7_timing.hip")]
 TUNE_LIB = os.path.join(HERE, "tune", "librba_tune.so")
 LIB = os.path.join(HERE, "librba_hip.so")
+KNOBS_LIB = os.path.join(HERE, "librba_hip_knobs.so")
+KNOBS = ["-DRBA_TUNE_KNOBS"]
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
@@ -52,16 +55,19 @@ def stale() -> bool:
     return _stale(LIB, [os.path.join(HERE, f) for f in SOURCES + HEADERS])
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not stale():
-        return LIB
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, knobs: bool = False) -> str:
+    """knobs=False: the product library.  knobs=True: librba_hip_knobs.so (objects under build/knobs/)."""
+    lib = KNOBS_LIB if knobs else LIB
+    if not force and not _stale(lib, [os.path.join(HERE, f) for f in SOURCES + HEADERS]):
+        return lib
+    obj_dir = os.path.join(OBJ, "knobs") if knobs else OBJ
+    os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
 
     def compile_one(src):
-        s, o = os.path.join(HERE, src), os.path.join(OBJ, src.replace(".hip", ".o"))
+        s, o = os.path.join(HERE, src), os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if src in UNPACKED_SOURCES else []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + (KNOBS if knobs else []) + (NO_PACKED_FP32 if src in UNPACKED_SOURCES else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             _run(cmd)
@@ -69,11 +75,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)
-    return LIB
+    return lib
+
+
+def build_knobs(force: bool = False, verbose: bool = True) -> str:
+    return build(force=force, verbose=verbose, knobs=True)
 
 
 def build_tune(force: bool = False, verbose: bool = True) -> str:
@@ -86,7 +96,7 @@ def build_tune(force: bool = False, verbose: bool = True) -> str:
     for src in TUNE_SOURCES:
         o = os.path.join(OBJ, "tune_" + os.path.basename(src).replace(".hip", ".o"))
         # (the weights-stationary experiment is always built without packed fp32: its waves run epilogues beside other waves' MFMAs)
-        cmd = [HIPCC] + FLAGS + (NO_PACKED_FP32 if (MFMA_SOURCES and "split_linear" in src) or src.endswith("split_linear_ws.hip") or (src.endswith("mlp_fused_h1.hip") and os.environ.get("RBA_MLP1_UNPACKED") == "1") else []) + ["-c", os.path.join(HERE, src), "-o", o]
+        cmd = [HIPCC] + FLAGS + KNOBS + (NO_PACKED_FP32 if (MFMA_SOURCES and "split_linear" in src) or src.endswith("split_linear_ws.hip") or (src.endswith("mlp_fused_h1.hip") and os.environ.get("RBA_MLP1_UNPACKED") == "1") else []) + ["-c", os.path.join(HERE, src), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         _run(cmd)
@@ -100,5 +110,7 @@ def build_tune(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--knobs" in sys.argv:
+        print(build_knobs(force="--force" in sys.argv))
     if "--tune" in sys.argv:
         print(build_tune(force="--force" in sys.argv))

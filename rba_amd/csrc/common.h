@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "knobs.h"
 
 #define RBA_WAVE 64
 

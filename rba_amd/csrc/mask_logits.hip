@@ -376,8 +376,8 @@ extern "C" int rba_mask_logits_f32(const float* embed, const float* feat, float*
 }
 
 // tools / tests only: 0 = columns per lane chosen from N, 1 / 2 = forced; waves per workgroup 8 (product) or 4
-extern "C" __attribute__((visibility("default"))) int rba_k4_variant = 0;
-extern "C" __attribute__((visibility("default"))) int rba_k4_waves = 8;
+RBA_KNOB(rba_k4_variant, 0);
+RBA_KNOB(rba_k4_waves, 8);
 
 // The same contraction in f16x3 arithmetic (domain |x| < 65504 like every f16x3 entry point; beyond it the result is NaN, never a wrong number).
 // Shapes outside Q <= 112, C % 32 == 0, C <= 256 take the exact-fp32 path above.

@@ -10,28 +10,29 @@
 #include "../../include/rba_hip.h"
 
 // tools / tests only (not part of the ABI contract): 1 = rba_ms_deform_attn_fwd_f32 always runs the generic kernel
-extern "C" __attribute__((visibility("default"))) int rba_k2_variant = 0;
+RBA_KNOB(rba_k2_variant, 0);
 
 namespace {
 
-template <int VEC>
+// T = float (VEC 4 or 1) or double (VEC 1): the reference's native op dispatches both (ops/src/cuda/ms_deform_attn_cuda.cu:69, AT_DISPATCH_FLOATING_TYPES)
+template <typename T, int VEC>
 struct Ld;
 template <>
-struct Ld<4> {
+struct Ld<float, 4> {
   static __device__ __forceinline__ void acc(float (&a)[4], const float* p, float wgt) {
     const float4 v = *reinterpret_cast<const float4*>(p);
     a[0] = fmaf(wgt, v.x, a[0]); a[1] = fmaf(wgt, v.y, a[1]); a[2] = fmaf(wgt, v.z, a[2]); a[3] = fmaf(wgt, v.w, a[3]);
   }
 };
-template <>
-struct Ld<1> {
-  static __device__ __forceinline__ void acc(float (&a)[1], const float* p, float wgt) { a[0] = fmaf(wgt, *p, a[0]); }
+template <typename T>
+struct Ld<T, 1> {
+  static __device__ __forceinline__ void acc(T (&a)[1], const T* p, T wgt) { a[0] = fma(wgt, *p, a[0]); }
 };
 
-template <int VEC>
-__global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
-                                                       const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-                                                       const float* __restrict__ attw, float* __restrict__ out,
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lsi, const T* __restrict__ loc,
+                                                       const T* __restrict__ attw, T* __restrict__ out,
                                                        int S, int M, int D, int L, int Lq, int P, int64_t total) {
   const int dv = D / VEC;                         // lanes per (n,q,m)
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,41 +41,41 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float* __restrict__
   const int64_t nqm = idx / dv;                   // (n*Lq + q)*M + m
   const int m = (int)(nqm % M);
   const int64_t n = nqm / ((int64_t)M * Lq);
-  const float* vbase = value + (n * S * M + m) * (int64_t)D + c;   // + s*M*D per spatial position
-  const float* lp = loc + nqm * L * P * 2;
-  const float* wp = attw + nqm * L * P;
+  const T* vbase = value + (n * S * M + m) * (int64_t)D + c;   // + s*M*D per spatial position
+  const T* lp = loc + nqm * L * P * 2;
+  const T* wp = attw + nqm * L * P;
   const int64_t vstride = (int64_t)M * D;
-  float acc[VEC];
+  T acc[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int i = 0; i < VEC; ++i) acc[i] = (T)0;
   for (int l = 0; l < L; ++l) {
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    const float* vl = vbase + lsi[l] * vstride;
+    const T* vl = vbase + lsi[l] * vstride;
     for (int p = 0; p < P; ++p) {
-      const float x = lp[(l * P + p) * 2], y = lp[(l * P + p) * 2 + 1];
-      const float wgt = wp[l * P + p];
-      const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
-      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-        const float hf = floorf(h_im), wf = floorf(w_im);
+      const T x = lp[(l * P + p) * 2], y = lp[(l * P + p) * 2 + 1];
+      const T wgt = wp[l * P + p];
+      const T h_im = y * H - (T)0.5, w_im = x * W - (T)0.5;
+      if (h_im > (T)-1 && w_im > (T)-1 && h_im < (T)H && w_im < (T)W) {
+        const T hf = floor(h_im), wf = floor(w_im);
         const int h0 = (int)hf, w0 = (int)wf;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        float s[VEC];
+        const T lh = h_im - hf, lw = w_im - wf, hh = (T)1 - lh, hw = (T)1 - lw;
+        T s[VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+        for (int i = 0; i < VEC; ++i) s[i] = (T)0;
         const bool h0ok = h0 >= 0, h1ok = h0 + 1 <= H - 1, w0ok = w0 >= 0, w1ok = w0 + 1 <= W - 1;
-        const float* p00 = vl + ((int64_t)h0 * W + w0) * vstride;
-        if (h0ok && w0ok) Ld<VEC>::acc(s, p00, hh * hw);
-        if (h0ok && w1ok) Ld<VEC>::acc(s, p00 + vstride, hh * lw);
-        if (h1ok && w0ok) Ld<VEC>::acc(s, p00 + (int64_t)W * vstride, lh * hw);
-        if (h1ok && w1ok) Ld<VEC>::acc(s, p00 + (int64_t)(W + 1) * vstride, lh * lw);
+        const T* p00 = vl + ((int64_t)h0 * W + w0) * vstride;
+        if (h0ok && w0ok) Ld<T, VEC>::acc(s, p00, hh * hw);
+        if (h0ok && w1ok) Ld<T, VEC>::acc(s, p00 + vstride, hh * lw);
+        if (h1ok && w0ok) Ld<T, VEC>::acc(s, p00 + (int64_t)W * vstride, lh * hw);
+        if (h1ok && w1ok) Ld<T, VEC>::acc(s, p00 + (int64_t)(W + 1) * vstride, lh * lw);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wgt, s[i], acc[i]);
+        for (int i = 0; i < VEC; ++i) acc[i] = fma(wgt, s[i], acc[i]);
       }
     }
   }
-  float* o = out + nqm * D + c;
-  if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[VEC > 1 ? 1 : 0], acc[VEC > 2 ? 2 : 0], acc[VEC > 3 ? 3 : 0]);
-  else o[0] = acc[0];
+  T* o = out + nqm * D + c;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) o[i] = acc[i];                // (VEC = 4: four consecutive floats of a 16-byte-aligned address -> one 16-byte store)
 }
 
 // ---- round 3: the form the model runs (head_dim 32, P = 4, L = 1 or 3).  What the counters said about the kernel above at C5
@@ -287,11 +288,28 @@ extern "C" int rba_ms_deform_attn_fwd_f32(const float* value, const int64_t* spa
   const int64_t blocks = (total + threads - 1) / threads;
   RBA_CHECK_ARG(blocks <= 0x7fffffffLL);
   if (vec4)
-    hipLaunchKernelGGL((msda_fwd_kernel<4>), dim3((unsigned)blocks), dim3(threads), 0, st, value, spatial_shapes,
+    hipLaunchKernelGGL((msda_fwd_kernel<float, 4>), dim3((unsigned)blocks), dim3(threads), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, S, M, D, L, Lq, P, total);
   else
-    hipLaunchKernelGGL((msda_fwd_kernel<1>), dim3((unsigned)blocks), dim3(threads), 0, st, value, spatial_shapes,
+    hipLaunchKernelGGL((msda_fwd_kernel<float, 1>), dim3((unsigned)blocks), dim3(threads), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, S, M, D, L, Lq, P, total);
+  return rba_launch_status();
+}
+
+// The double-precision entry of the same op: the reference FFI dispatches float AND double (ops/src/cuda/ms_deform_attn_cuda.cu:69) and the first check of
+// its own test runs in double (ops/test.py:35-47).  Generic kernel, one thread per output element; not a tuned path (inference is fp32).
+extern "C" int rba_ms_deform_attn_fwd_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                          const double* sampling_loc, const double* attn_weight, double* out,
+                                          int N, int S, int M, int D, int L, int Lq, int P, void* stream) {
+  RBA_CHECK_ARG(N >= 0 && S >= 1 && M >= 1 && D >= 1 && L >= 1 && Lq >= 0 && P >= 1);
+  if (N == 0 || Lq == 0) return 0;
+  RBA_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out);
+  rba_begin();
+  const int64_t total = (int64_t)N * Lq * M * D;
+  const int64_t blocks = (total + 255) / 256;
+  RBA_CHECK_ARG(blocks <= 0x7fffffffLL);
+  hipLaunchKernelGGL((msda_fwd_kernel<double, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, value, spatial_shapes, level_start_index,
+                     sampling_loc, attn_weight, out, S, M, D, L, Lq, P, total);
   return rba_launch_status();
 }
 

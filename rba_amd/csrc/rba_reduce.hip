@@ -14,10 +14,10 @@
 
 using namespace rba_k1;
 
-extern "C" int rba_hip_version(void) { return 188; }
+extern "C" int rba_hip_version(void) { return 189; }
 
 // tools / tests only: 1 = rba_reduce_up4_f32 runs the generic (round 1-2) kernel for K = 19 / 20 too, 2 = always the packed VALU kernel (no MFMA form)
-extern "C" __attribute__((visibility("default"))) int rba_k1_up4_variant = 0;
+RBA_KNOB(rba_k1_up4_variant, 0);
 
 static int reduce_impl(const float* mask, const float* cls_prob, float* rba, float* sem_seg, int32_t* argmax, int Q, int K, int64_t HW,
                        int score_mode, unsigned int* counters, void* stream) {

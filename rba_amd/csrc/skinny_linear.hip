@@ -9,7 +9,7 @@
 #include "../../include/rba_hip.h"
 
 // tools / tests only: 1 = always the round 1-2 decomposition (one workgroup per 16 columns, all row tiles), 2 = always the per-row-tile one
-extern "C" __attribute__((visibility("default"))) int rba_skinny_variant = 0;
+RBA_KNOB(rba_skinny_variant, 0);
 
 namespace {
 

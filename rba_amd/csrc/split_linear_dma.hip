@@ -12,20 +12,21 @@
 
 // A/B switch for tools and tests (not part of the ABI contract): 0 = product dispatch, 1 = always the round-2 pipelined 128 x 128 kernel
 // (split_linear_h3p_kernel), 2 = the sub-tile kernel with the deferred epilogue (split_linear_h3q.h) wherever it applies, 100 + p = its ablation builds
-extern "C" __attribute__((visibility("default"))) int rba_k6_variant = 0;
-extern "C" __attribute__((visibility("default"))) int rba_k6_stagger = 0;
-extern "C" __attribute__((visibility("default"))) int rba_k6_occ = 2;
-extern "C" __attribute__((visibility("default"))) int rba_k6_rs_min_k = 512;  // the 256 x 128 form only from this K on (0: any K; see h3p_use_rs2)
-extern "C" __attribute__((visibility("default"))) int rba_k6_ks = 0;       // K-split 8-wave form of the single-resident launches: 0 = by rule (h3p_use_ks2), 1 = never, 2 = wherever legal
-extern "C" __attribute__((visibility("default"))) int rba_k6_rs = 0;       // 256 x 128 / 8-wave form: 0 = by tile count (split_linear_h3.h), 1 = never, 2 = always, 3 = from 64 tiles
+RBA_KNOB(rba_k6_variant, 0);
+RBA_KNOB_DEFINE(rba_k6_stagger, 0);
+RBA_KNOB_DEFINE(rba_k6_occ, 2);
+RBA_KNOB_DEFINE(rba_k6_rs_min_k, 512);  // the 256 x 128 form only from this K on (0: any K; see h3p_use_rs2)
+RBA_KNOB_DEFINE(rba_k6_ks, 0);          // K-split 8-wave form of the single-resident launches: 0 = by rule (h3p_use_ks2), 1 = never, 2 = wherever legal
+RBA_KNOB_DEFINE(rba_k6_rs, 0);          // 256 x 128 / 8-wave form: 0 = by tile count and stream hint (split_linear_h3.h), 1 = never, 2 = always, 3 = from 64 tiles
+extern "C" __attribute__((visibility("hidden"))) int rba_concurrent_streams_hint = 1;
 
 // The one piece of caller-set state of the library (include/rba_hip.h): how many streams of this process launch forwards CONCURRENTLY.  With two
 // or more, the half-chip K6 launches (128 tiles of 256 x 128: Swin-B stage-3 proj / fc2, and the 1.5-round qkv) run the 8-wave form too: its
 // workgroups own whole CUs, so such a launch takes 128 CUs and leaves the other 128 to the other streams' kernels instead of half of every CU
 // (3 streams: 136.3 -> 139.7 images/s; alone it is slower, 116.3 -> 112.0: profiles/r04_bench_*.json).  Results are bit-identical either way.
 extern "C" int rba_set_concurrent_streams(int n) {
-  const int prev = rba_k6_rs == 3 ? 2 : 1;
-  rba_k6_rs = n >= 2 ? 3 : 0;
+  const int prev = rba_concurrent_streams_hint;
+  rba_concurrent_streams_hint = n >= 1 ? n : 1;
   return prev;
 }
 

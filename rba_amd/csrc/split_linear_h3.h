@@ -26,7 +26,7 @@
 #include "split_linear_dma.h"
 
 // tools-only knobs (exported by split_linear_dma.hip; zero in the product): see the `stagger` parameter of split_linear_h3p_kernel
-extern "C" int rba_k6_stagger;
+RBA_KNOB_EXTERN(rba_k6_stagger, 0);
 
 namespace {
 
@@ -947,7 +947,7 @@ int launch_h3p(const float* x, const u32x4_t* wp, const float* bias, float* out,
 // leaves half of every SIMD's register file to ANOTHER stream's kernel; 1: such launches run the 364-register OCC = 1 build with its deeper
 // prefetch -- 4-9 % faster alone, but it monopolises the CU: 128.8 -> 132.7 images/s with three streams, single stream unchanged
 // (profiles/r03_k6_occ.txt)
-extern "C" int rba_k6_occ;
+RBA_KNOB_EXTERN(rba_k6_occ, 2);
 inline bool h3p_single_resident(int64_t M, int N) { return rba_k6_occ == 1 && ((M + 127) / 128) * ((N + 127) / 128) <= 256; }
 
 inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const float* bias, float* out, int64_t M, int N, int K, hipStream_t st) {
@@ -970,12 +970,16 @@ inline int launch_h3p_act(int act, const float* x, const u32x4_t* wp, const floa
 // bound by HBM and by their epilogues, and IN THE NETWORK (cold operands) two independent 128 x 128 workgroups per CU overlap one tile's stores with the
 // other's loads better than one 8-wave workgroup: per-dispatch rocprofv3 times of one image, stage-1 qkv 72-77 -> 65 us, stage-2 qkv 52-57 -> 47-51,
 // stage-2 fc1 83 -> 76-77 (profiles/r04_k6_rs2_min_k.txt; same-box bench A/B +0.7 % single stream, +0.2 % three streams).
-extern "C" int rba_k6_rs;
-extern "C" int rba_k6_rs_min_k;
+RBA_KNOB_EXTERN(rba_k6_rs, 0);
+RBA_KNOB_EXTERN(rba_k6_rs_min_k, 512);
+// The library's one piece of caller-set state (rba_set_concurrent_streams, include/rba_hip.h): how many streams of this process launch forwards concurrently.
+// Not exported; read by the two launch-geometry rules below, written by that entry point only.
+extern "C" int rba_concurrent_streams_hint;
+inline bool h3p_multi_stream() { return rba_k6_rs == 3 || (rba_k6_rs == 0 && rba_concurrent_streams_hint >= 2); }
 inline bool h3p_use_rs2(int64_t M, int N, int K) {
   if (rba_k6_rs == 1 || K < rba_k6_rs_min_k) return false;
   const int64_t t = ((M + 255) / 256) * ((N + 127) / 128);
-  if (rba_k6_rs == 3) return t >= 64;                                 // tools: also the half-chip launches (128 tiles: stage-3 proj / fc2 of Swin-B)
+  if (h3p_multi_stream()) return t >= 64;                                 // tools: also the half-chip launches (128 tiles: stage-3 proj / fc2 of Swin-B)
   if (t < 160) return false;
   if (rba_k6_rs == 2) return true;
   const int64_t last = t % 256;                                       // workgroups in the last round of the 256 CUs (0 = full)
@@ -988,12 +992,12 @@ inline bool h3p_use_rs2(int64_t M, int N, int K) {
 // fixed order (even blocks, odd blocks, then even + odd): deterministic, but not the one-set kernel's order -- results differ from it in the last bits
 // (tests/test_kernels_gpu.py::test_split_linear_k_split_form holds both to the same fp64 bound).  Not under several concurrent streams (rba_k6_rs == 3: there
 // these launches take whole CUs with the 256 x 128 form).  rba_k6_ks (tools / tests): 0 = this rule, 1 = never, 2 = wherever the form is legal.
-extern "C" int rba_k6_ks;
+RBA_KNOB_EXTERN(rba_k6_ks, 0);
 inline bool h3p_use_ks2(int64_t M, int N, int K) {
   if (rba_k6_ks == 1 || (K & 63) || K < 128) return false;
   if (rba_k6_ks == 2) return true;
   const int64_t t = ((M + 127) / 128) * ((N + 127) / 128);
-  return rba_k6_rs != 3 && t > 128 && t <= 256 && K >= 1024;
+  return !h3p_multi_stream() && t > 128 && t <= 256 && K >= 1024;
 }
 
 // A operand = the producer's split fragment image (PRE); residual may be null

@@ -346,7 +346,7 @@ __global__ void swin_bias_fragments_kernel(const float* __restrict__ bias, float
 // Register budget of the kernel (round 4, late): at 96 VGPRs a gfx950 CU holds ONE 9-wave workgroup although the occupancy API answers two (tools/micro/occ_probe.hip); at
 // amdgpu_waves_per_eu(6, 8) the same source compiles to 79 VGPRs without scratch, two workgroups are resident, outputs bit-identical.  Launch time: equal to 15 % shorter
 // depending on the box and the stage, 0-4 % with cold operands (profiles/r04_k5_wpe_ab.txt).  rba_k5_wpe (tools): 6 = default, 5 = the 96-VGPR build of rounds 2-4.
-extern "C" __attribute__((visibility("default"))) int rba_k5_wpe = 6;
+RBA_KNOB(rba_k5_wpe, 6);
 
 namespace {
 template <int NT, int WAVES>

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __r
 }
 
 // tools / tests: 0 = product rule (two row tiles per workgroup for K >= 512 and at least 4 096 rows), 1 = always one row tile, 2 = always two
-extern "C" __attribute__((visibility("default"))) int rba_token_rt = 0;
+RBA_KNOB(rba_token_rt, 0);
 
 template <bool LN>
 int launch_token_linear(const float* x, const TlProblems& ps, int nprob, const float* residual, const float* ln_w, const float* ln_b, float eps,

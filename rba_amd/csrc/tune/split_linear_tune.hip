@@ -3,11 +3,12 @@
 // library contains only the configurations rba_split_linear_f32 dispatches to.
 #include "split_linear_experiments.h"
 #include "../split_linear_h3.h"
-extern "C" int rba_k6_occ = 1;
+extern "C" int rba_k6_occ = 1;              // (this library is always built with -DRBA_TUNE_KNOBS: the knobs are variables here, with their own defaults)
 extern "C" int rba_k6_rs = 1;
 extern "C" int rba_k6_rs_min_k = 0;
 extern "C" int rba_k6_ks = 1;
-extern "C" int rba_k6_stagger = 0;          // the product library's tools-only knob, defined here for this separate library
+extern "C" int rba_k6_stagger = 0;
+extern "C" int rba_concurrent_streams_hint = 1;
 #include "../mlp_fused_h3.h"
 
 // Timing build of one v5 configuration (tools only): dbg[8 wg + {0..3}] = MFMA wave 0 {barrier wait, compute, epilogue, total}

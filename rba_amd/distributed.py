@@ -15,7 +15,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # RBA_DIST_ONE_RANK_GROUP=1: initialise the process group even for ONE rank, so that a 1-GPU box can run the collective code on RCCL itself
+    # (with force_collective() below); a normal single-process run never touches torch.distributed
+    if (world > 1 or os.environ.get("RBA_DIST_ONE_RANK_GROUP") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -39,15 +41,41 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+_FORCE_COLLECTIVE = False
+
+
+class force_collective:
+    """with force_collective(): the exchanges below run their collectives even in a ONE-rank group (normally a 1-rank world returns its own tensor
+    untouched) -- so that RCCL's all_gather / all_gather_into_tensor / all_reduce execute on a 1-GPU box (tests, `bench.py --rccl-one-rank`)."""
+
+    def __enter__(self):
+        global _FORCE_COLLECTIVE
+        self.prev, _FORCE_COLLECTIVE = _FORCE_COLLECTIVE, True
+
+    def __exit__(self, *exc):
+        global _FORCE_COLLECTIVE
+        _FORCE_COLLECTIVE = self.prev
+        return False
+
+
+def _skip_collective(world):
+    return world == 1 and not (_FORCE_COLLECTIVE and dist.is_available() and dist.is_initialized())
+
+
 @torch.no_grad()
 def all_gather_variable(t: torch.Tensor) -> torch.Tensor:
     """Concatenate 1-d tensors of different lengths from all ranks (rank order): all_gather the sizes, pad to the
     max, one all_gather_into_tensor, trim."""
     world = _world()
-    if world == 1:
+    if _skip_collective(world):
         return t
     if t.is_cuda and dist.get_backend() == "gloo":      # gloo has no device all_gather: stage through the host (tests only)
         return all_gather_variable(t.cpu()).to(t.device)
+    return _gather_padded(t, world)
+
+
+def _gather_padded(t, world):
+    """the collective body: sizes by all_gather, payload by ONE padded all_gather_into_tensor (device tensors on nccl = RCCL)"""
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
@@ -84,7 +112,7 @@ def histogram_ood_metrics(scores: torch.Tensor, labels: torch.Tensor, bits: int 
     nb = 1 << bits
     pos = labels.reshape(-1).to(torch.bool)
     hist = torch.stack([torch.bincount(key[~pos], minlength=nb), torch.bincount(key[pos], minlength=nb)])
-    if _world() > 1:
+    if not _skip_collective(_world()):
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     nz = torch.nonzero(hist.sum(0)).reshape(-1)
     cnt = hist[:, nz]

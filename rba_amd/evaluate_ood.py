@@ -177,6 +177,23 @@ class GraphedScore:
 
 
 def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, world=1, timing=None):
+    """(wrapper) the launch-geometry hint and the model's graph-replay flag are restored whatever happens inside the loop -- an exception must not leave the
+    process-wide hint of rba_set_concurrent_streams at the evaluator's value."""
+    from . import ops as _ops
+    dev = next(model.parameters()).device
+    on_gpu = dev.type == "cuda"
+    prev_streams = _ops.set_concurrent_streams(max(1, int(getattr(args, "streams", 3)))) if on_gpu else None   # speed only, bit-identical results
+    prev_replay = getattr(model, "graph_replay", None)
+    try:
+        return _run_evaluations(model, dataset, model_name, dataset_name, args, rank, world, timing)
+    finally:
+        if prev_replay is not None:
+            model.graph_replay = prev_replay
+        if prev_streams is not None:
+            _ops.set_concurrent_streams(prev_streams)
+
+
+def _run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, world=1, timing=None):
     """Score this rank's shard of `dataset` (image i -> rank i mod world), pool the labelled pixels of all ranks over
     RCCL and return {"auroc","aupr","fpr95"} (reference :195-235; single process there).
 
@@ -223,11 +240,7 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
     main_stream = torch.cuda.current_stream(dev) if on_gpu else None
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [main_stream]
     use_graphs = on_gpu and bool(int(getattr(args, "graph", 0)))
-    prev_streams = None
-    if on_gpu:
-        from . import ops as _ops
-        prev_streams = _ops.set_concurrent_streams(n_streams)   # launch-geometry hint (include/rba_hip.h): speed only, bit-identical results
-    prev_replay = getattr(model, "graph_replay", None)
+    prev_replay = getattr(model, "graph_replay", None)       # (the wrapper restores it, and the stream hint it set)
     if prev_replay is not None:
         model.graph_replay = use_graphs                         # MaskFormer.rba_scores replays per (image shape, stream)
     graphed = ({id(st_): GraphedScore(model, score_func, st_) for st_ in streams}
@@ -350,10 +363,6 @@ def run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, worl
                       host_thread={n: round(v, 3) for n, v in host.items()})
         if proc_stats.get("items"):
             timing["decode_processes_ms_per_sample"] = {n: round(v / proc_stats["items"] * 1e3, 2) for n, v in proc_stats.items() if n != "items"}
-    if prev_replay is not None:
-        model.graph_replay = prev_replay
-    if prev_streams is not None:
-        _ops.set_concurrent_streams(prev_streams)
     s_all = torch.cat(scores) if scores else torch.empty(0, device=dev)
     y_all = torch.cat(labels) if labels else torch.empty(0, dtype=torch.bool, device=dev)
     return D.pooled_ood_metrics(s_all, y_all)

@@ -220,7 +220,8 @@ class MaskFormer(nn.Module):
 
     def _graph_key(self, image, return_argmax, score):
         return (tuple(image.shape), image.dtype, image.device, torch.cuda.current_stream(image.device).cuda_stream, bool(return_argmax), score,
-                self.fused_upsample, self.fused_front_end, ops.SPLIT_MODE, ops.SPLIT_ACTIVATIONS, ops.TILES_MIN, ops.MLP_FUSED_MIN_ROWS,
+                self.fused_upsample, self.fused_front_end, ops.SPLIT_MODE, ops.SPLIT_ACTIVATIONS, ops.TILES_MIN, ops.MLP_FUSED_MIN_ROWS, ops.concurrent_streams(),
+                ops.SWIN_ATTN_FUSED,
                 getattr(self.sem_seg_head.predictor, "sparse_intermediate_heads", None), self._weights_version())
 
     def drop_graphs(self, release_constants=False):

@@ -167,11 +167,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     [N,Lq,M,L,P,2], attention_weights [N,Lq,M,L,P] -> [N,Lq,M*D].  `im2col_step` is accepted for signature
     compatibility and only validated (the kernel needs no batch chunking)."""
     lib = _lib.load()
-    _chk(value, "value", dim=4)
+    # float or double, like the reference op (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:69); all three tensors of one type
+    dt = value.dtype if isinstance(value, torch.Tensor) and value.dtype == torch.float64 else torch.float32
+    _chk(value, "value", dt, dim=4)
     _chk(spatial_shapes, "spatial_shapes", torch.int64, 2)
     _chk(level_start_index, "level_start_index", torch.int64, 1)
-    _chk(sampling_locations, "sampling_loc", dim=6)
-    _chk(attention_weights, "attn_weight", dim=5)
+    _chk(sampling_locations, "sampling_loc", dt, dim=6)
+    _chk(attention_weights, "attn_weight", dt, dim=5)
     N, S, M, D = value.shape
     _, Lq, M2, L, P, two = sampling_locations.shape
     if M2 != M or two != 2 or sampling_locations.shape[0] != N:
@@ -183,10 +185,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     step = min(N, int(im2col_step))
     if N > 0 and N % step != 0:
         raise RbaHipError(f"batch({N}) must divide im2col_step({step})")
-    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
-    _lib.check(lib.rba_ms_deform_attn_fwd_f32(_p(value), _p(spatial_shapes), _p(level_start_index),
-                                              _p(sampling_locations), _p(attention_weights), _p(out),
-                                              N, S, M, D, L, Lq, P, _stream()), "rba_ms_deform_attn_fwd_f32")
+    out = torch.empty((N, Lq, M * D), dtype=dt, device=value.device)
+    fn, name = ((lib.rba_ms_deform_attn_fwd_f64, "rba_ms_deform_attn_fwd_f64") if dt == torch.float64 else
+                (lib.rba_ms_deform_attn_fwd_f32, "rba_ms_deform_attn_fwd_f32"))
+    _lib.check(fn(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations), _p(attention_weights), _p(out),
+                  N, S, M, D, L, Lq, P, _stream()), name)
     return out
 
 
@@ -982,12 +985,24 @@ def conv3x3_nhwc(x, planes, bias=None, out_features=None):
     return out
 
 
+_CONCURRENT_STREAMS = {}        # library handle -> last value set (the hint is per loaded library)
+
+
 def set_concurrent_streams(n):
     """Tell the kernel library how many HIP streams of this process run forwards at the same time (default 1): with two or more, the K6 launches
     that would fill only half the chip use whole-CU workgroups and leave the other CUs to the other streams (include/rba_hip.h).  Speed only --
     results are bit-identical.  Returns the previous setting.  Call it before the streams start launching (and before capturing hipGraphs: a
-    graph replays the launch forms it was captured with)."""
-    return int(_lib.load().rba_set_concurrent_streams(int(n)))
+    graph replays the launch forms it was captured with; MaskFormer keys its graphs on concurrent_streams()).  Restore it in a `finally`."""
+    lib = _lib.load()
+    n = max(1, int(n))
+    prev = int(lib.rba_set_concurrent_streams(n))
+    _CONCURRENT_STREAMS[id(lib)] = n
+    return prev
+
+
+def concurrent_streams():
+    """The hint last given to set_concurrent_streams for the current library (1 if never set)."""
+    return _CONCURRENT_STREAMS.get(id(_lib.load()), 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------- small token Linears

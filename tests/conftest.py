@@ -25,3 +25,12 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture
+def knobs():
+    """The block of a test that selects a kernel VARIANT runs on the knobs build of the library (librba_hip_knobs.so: the same sources with the tuning knobs of
+    csrc/knobs.h as writable ints); the product library exports no such state.  `ctypes.c_int.in_dll(_lib.load(), name)` then finds the knob."""
+    from rba_amd import _lib
+    with _lib.use_library(_lib.KNOBS_LIB_PATH) as lib:
+        yield lib

@@ -33,6 +33,29 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.load().rba_hip_version() >= 100
 
 
+def test_product_library_has_no_writable_state_and_the_knobs_build_does():
+    """include/rba_hip.h: "no mutable global state except the launch-geometry hint".  The tuning knobs of csrc/knobs.h are compile-time constants in
+    librba_hip.so (no data symbol named rba_*) and exported ints only in librba_hip_knobs.so, which tests / tools load to select kernel variants."""
+    import subprocess
+    from rba_amd import _lib
+    from rba_amd._lib import RbaHipError
+
+    def data_symbols(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        return sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "BDbdGgSsCc" and ln.split()[2].startswith("rba_"))
+
+    assert data_symbols(_lib.LIB_PATH) == []
+    knobs = data_symbols(_lib.KNOBS_LIB_PATH)
+    assert {"rba_k1_up4_variant", "rba_k2_variant", "rba_k4_variant", "rba_k5_wpe", "rba_k6_rs", "rba_k6_ks", "rba_skinny_variant", "rba_token_rt"} <= set(knobs)
+    with pytest.raises(RbaHipError, match="compile-time constant"):
+        _lib.knob("rba_k6_rs")
+    with _lib.use_library(_lib.KNOBS_LIB_PATH) as lib:
+        assert _lib.load() is lib and _lib.knob("rba_k6_rs").value == 0 and lib.rba_hip_version() == _lib.EXPECTED_ABI
+        for n in header_functions():
+            assert hasattr(lib, n)
+    assert _lib.load() is not lib
+
+
 def test_ops_have_no_cpu_path():
     from rba_amd import ops
     from rba_amd._lib import RbaHipError

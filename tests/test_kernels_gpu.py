@@ -127,7 +127,7 @@ def test_k1_up4_shapes(ops, h, w, ch, cw):
 
 @pytest.mark.parametrize("Q,K,h,w,ch,cw", [(100, 19, 8, 16, 32, 64), (100, 20, 6, 9, 21, 36), (12, 19, 184, 320, 720, 1280), (5, 19, 3, 40, 12, 160),
                                           (33, 19, 7, 33, 26, 132), (100, 19, 1, 1, 4, 4)])
-def test_k1_up4_matrix_pipe_form(ops, Q, K, h, w, ch, cw):
+def test_k1_up4_matrix_pipe_form(ops, Q, K, h, w, ch, cw, knobs):
     """score-only rba_reduce_up4 runs the class contraction on the matrix pipe (f16 h + l pairs, three products): against the oracle at the K1
     budget, and against the packed VALU kernel (same taps, same interpolation: only the contraction's rounding differs); all three score modes"""
     import ctypes
@@ -165,7 +165,7 @@ def test_k1_up4_matrix_pipe_form(ops, Q, K, h, w, ch, cw):
                 assert torch.equal(sem.gather(0, arg.long()[None])[0], sem.max(0).values)     # a maximum of the kernel's own sem_seg
 
 
-def test_k1_up4_matrix_pipe_form_full_size_is_stable(ops):
+def test_k1_up4_matrix_pipe_form_full_size_is_stable(ops, knobs):
     """BASELINE C2's map: every pixel within the K1 budget of the packed VALU kernel, and two launches give the same bits (an earlier build of
     this kernel produced intermittently wrong 32-pixel tiles -- only visible at a size that keeps every CU busy with several workgroups)"""
     import ctypes
@@ -220,6 +220,12 @@ def test_k2_reference_test_set(ops, golden):
     out = ops.ms_deform_attn_forward(dev(T(g["a32_value"])), dev(shapes), dev(lsi), dev(T(g["a32_loc"])),
                                      dev(T(g["a32_w"])), 2)
     assert maxerr(out, T(g["a32_out"])) < 1e-8
+    # the double check comes FIRST in the reference's test (:35-47): its FFI dispatches float and double (ms_deform_attn_cuda.cu:69) -- rba_ms_deform_attn_fwd_f64
+    out64 = ops.ms_deform_attn_forward(dev(T(g["a64_value"]).double()), dev(shapes), dev(lsi), dev(T(g["a64_loc"]).double()),
+                                       dev(T(g["a64_w"]).double()), 2)
+    assert out64.dtype == torch.float64 and maxerr(out64, T(g["a64_out"])) <= 1e-12
+    with pytest.raises(ops.RbaHipError):                                              # mixed precisions are refused, as the reference op refuses them
+        ops.ms_deform_attn_forward(dev(T(g["a64_value"]).double()), dev(shapes), dev(lsi), dev(T(g["a64_loc"])), dev(T(g["a64_w"]).double()), 2)
 
 
 def test_k2_golden_3level(ops, golden):
@@ -298,7 +304,7 @@ def test_k4_mask_logits(ops, B, Q, C, h, w, mode):
     assert out.shape == (B, Q, h, w) and maxerr(out, ref) < 2e-4 * (C / 256) ** 0.5 + 1e-5
 
 
-def test_k4_f16x3_column_tiles_and_range(ops):
+def test_k4_f16x3_column_tiles_and_range(ops, knobs):
     """both column-tile widths of the f16x3 kernel give the same bits (the per-element arithmetic does not depend on it), the result is as close
     to fp64 as the exact-fp32 kernel's, and an out-of-range input is NaN, never a wrong number"""
     import ctypes
@@ -386,7 +392,7 @@ def test_k5_window_attn_core(ops, H, W, ws, nH, shift):
             ops.swin_window_attn(dev(qkv), dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag, split_out=True)
 
 
-def test_k5_register_budgets_are_bit_identical(ops):
+def test_k5_register_budgets_are_bit_identical(ops, knobs):
     """Round 4 (late): the f16x3 window-attention kernel at 80 VGPRs (two 9-wave workgroups resident per CU, the default) and at 96 (one: rba_k5_wpe = 5, the
     build of rounds 2-4) is the same arithmetic in the same order -- every output form bit for bit, shifted and unshifted, with window padding, one and two images."""
     import ctypes
@@ -531,7 +537,7 @@ def test_add_layer_norm(ops, rows, C):
 @pytest.mark.parametrize("M,N,K,relu,has_bias", [(100, 2048, 256, True, True), (100, 256, 2048, False, False), (100, 20, 256, False, True),
                                                   (16, 64, 64, False, True), (1, 5, 32, True, True), (128, 256, 256, False, True),
                                                   (37, 129, 96, True, False)])
-def test_skinny_linear(ops, M, N, K, relu, has_bias):
+def test_skinny_linear(ops, M, N, K, relu, has_bias, knobs):
     g = torch.Generator().manual_seed(M + N + K)
     x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
     b = torch.randn(N, generator=g) if has_bias else None
@@ -556,7 +562,7 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias):
 
 
 @pytest.mark.parametrize("M,E,K", [(100, 256, 256), (100, 64, 2048), (37, 32, 64), (128, 256, 256)])
-def test_skinny_linear_position_add_and_segments(ops, M, E, K):
+def test_skinny_linear_position_add_and_segments(ops, M, E, K, knobs):
     """the q / k / v projections of a decoder self-attention layer as ONE launch over the stacked in_proj weight: columns < 2E see x + x_add,
     the rest x; three separately contiguous outputs -- each bit-equal to its own launch on the separately added input (the add is the same
     fp32 add, the k blocks are reduced in the same order), in both decompositions"""
@@ -656,7 +662,7 @@ def test_token_linear_vs_fp64(ops, M, N, K, relu, has_bias, has_add):
 
 
 @pytest.mark.parametrize("M,C,K", [(2048, 256, 256), (2048, 256, 1024), (4830, 256, 256), (50, 64, 128), (999, 128, 96), (1001, 256, 544), (17, 64, 512)])
-def test_token_linear_residual_layer_norm(ops, M, C, K):
+def test_token_linear_residual_layer_norm(ops, M, C, K, knobs):
     """norm(residual + Linear(x)) in the Linear's epilogue (msdeformattn.py:134-138): against fp64, and against the unfused composition
     (the same Linear, then rba_add_layer_norm_f32) at fp32 round-off"""
     from types import SimpleNamespace
@@ -716,7 +722,7 @@ def test_token_linear_multi(ops):
 
 @pytest.mark.parametrize("M,N,K", [(8192, 512, 512), (3000, 1100, 544), (32768, 256, 256), (1000, 128, 128), (2048, 1024, 4096),
                                    (130, 200, 96)])
-def test_split_linear_residual_epilogue(ops, M, N, K):
+def test_split_linear_residual_epilogue(ops, M, N, K, knobs):
     """linear(..., residual=r): (r + x W^T) + bias in the GEMM epilogue, in place over r -- bit-identical to the unfused
     composition in the fused add + LayerNorm kernel's order ((r + t) + bias), on every kernel form (LDS-staged, pipelined, 64-column)."""
     g = torch.Generator().manual_seed(M + N + K)
@@ -731,8 +737,8 @@ def test_split_linear_residual_epilogue(ops, M, N, K):
 
 
 @pytest.fixture
-def k6_k_split_off():
-    """rba_k6_ks = 1 for the duration of a test that compares launch forms bit for bit."""
+def k6_k_split_off(knobs):
+    """rba_k6_ks = 1 (knobs build of the library) for the duration of a test that compares launch forms bit for bit."""
     import ctypes
     from rba_amd import _lib
     ks = ctypes.c_int.in_dll(_lib.load(), "rba_k6_ks")
@@ -762,7 +768,7 @@ def test_split_linear_from_split_activations(ops, M, N, K, k6_k_split_off):
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (8192, 512, 2048), (8100, 1536, 512), (3680, 2048, 512), (40000, 256, 288), (16500, 640, 544)])
-def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
+def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K, knobs):
     """Round 4: the 256 x 128 / eight-wave / shared-weight-ring form of the pipelined f16x3 kernel (rba_k6_rs: 1 = off, 3 = from 64 tiles -- what
     ops.set_concurrent_streams(n >= 2) selects) against the 128 x 128 form, on split-image operands: fp32 rows out (plain, GELU, ReLU), the
     residual epilogue, GELU + split image out; M not a multiple of 256 (a whole 128-row half beyond M), N not a multiple of 128."""
@@ -804,7 +810,7 @@ def test_split_linear_256x128_form_is_bit_identical(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(8192, 512, 2048), (8100, 500, 1024), (4224, 1024, 3072), (300, 200, 128), (8192, 512, 576)])
-def test_split_linear_k_split_form(ops, M, N, K):
+def test_split_linear_k_split_form(ops, M, N, K, knobs):
     """Round 4: the K-split 8-wave form of the pipelined f16x3 kernel (KS = 2: two wave sets on the even / odd 32-wide blocks of K, summed through LDS in a
     fixed order) that the single-resident launches with K >= 1024 run on one stream (Swin-B stage-3 fc2).  Not the one-set kernel's summation order, so not
     bit-identical to it: both are held to the same fp64 bound, agree to a few ulp, and the form is deterministic.  rba_k6_ks: 1 = off, 2 = wherever legal."""
@@ -1405,7 +1411,7 @@ def test_msda_prepare(ops, N, Lq, M, L, P):
 
 
 @pytest.mark.parametrize("N,Lq,L,edge", [(1, 2048, 1, False), (1, 19320, 3, False), (2, 333, 3, True), (1, 77, 1, True)])
-def test_msda_fused_equals_prepare_plus_forward(ops, N, Lq, L, edge):
+def test_msda_fused_equals_prepare_plus_forward(ops, N, Lq, L, edge, knobs):
     """round 3: the one-launch deformable attention core (sampling locations + softmax computed inside the locality-mapped gather kernel)
     is bit-identical to rba_msda_prepare_f32 + the generic rba_ms_deform_attn_fwd_f32 kernel, which the reference-generated K2 fixtures pin;
     `edge`: reference points and offsets that push samples across and beyond the image border (zero taps, skipped samples)"""

@@ -11,6 +11,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import _knobs  # noqa: F401  (knob-writing tool: run on librba_hip_knobs.so)
 from rba_amd import arch as A
 from rba_amd.checkpoint import load_checkpoint
 from rba_amd.maskformer_model import MaskFormer

@@ -5,6 +5,7 @@ python tools/k1_up4_ab.py"""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (knob-writing tool: run on librba_hip_knobs.so)
 from rba_amd import _lib, ops
 
 var = ctypes.c_int.in_dll(_lib.load(), "rba_k1_up4_variant")

@@ -7,6 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (knob-writing tool: run on librba_hip_knobs.so)
 from rba_amd import _lib, ops  # noqa: E402
 from rba_amd.seeded_weights import deform_ring_bias  # noqa: E402
 

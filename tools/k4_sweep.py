@@ -5,6 +5,7 @@ import ctypes
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (knob-writing tool: run on librba_hip_knobs.so)
 from rba_amd import _lib, ops
 lib = _lib.load()
 busy = torch.randn(8192, 8192, device="cuda")

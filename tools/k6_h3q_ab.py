@@ -9,6 +9,7 @@ import os
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (knob-writing tool: run on librba_hip_knobs.so)
 from rba_amd import _lib, ops  # noqa: E402
 
 

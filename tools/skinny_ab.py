@@ -3,6 +3,7 @@
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (knob-writing tool: run on librba_hip_knobs.so)
 from rba_amd import _lib, ops
 var = ctypes.c_int.in_dll(_lib.load(), "rba_skinny_variant")
 for name, N, K in (("q / out proj", 256, 256), ("class head", 20, 256), ("FFN linear1", 2048, 256), ("FFN linear2", 256, 2048)):
