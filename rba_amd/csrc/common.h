@@ -34,6 +34,11 @@ __device__ __forceinline__ f32x2 rba_sigmoid2(f32x2 x) {
   return (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
 
+// ReLU that PRESERVES NaN (fmaxf(NaN, 0) is 0): the f16x3 kernels answer an out-of-range operand with NaN, and that NaN must reach the score map, where
+// the evaluator's finiteness check sends the image to the full-range bf16x6 kernels -- a ReLU that swallowed it would turn a loud failure into a finite,
+// wrong score.  One compare + select.
+__device__ __forceinline__ float rba_relu(float x) { return x < 0.f ? 0.f : x; }
+
 // tanh(x) = sign(x) * (1 - 2 / (e^{2|x|} + 1)); e^{2|x|} -> inf gives exactly 1.
 __device__ __forceinline__ float rba_tanh(float x) {
   float ax = fabsf(x);

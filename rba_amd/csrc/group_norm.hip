@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       const float a = gamma[c] * rstd, b = beta[c] - mean * a;
       float4 v = *reinterpret_cast<const float4*>(p + i);
       v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
-      if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (RELU) { v.x = rba_relu(v.x); v.y = rba_relu(v.y); v.z = rba_relu(v.z); v.w = rba_relu(v.w); }
       *reinterpret_cast<float4*>(q + i) = v;
     }
   } else {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       const int c = c0 + (int)(i / HW);
       const float a = gamma[c] * rstd, b = beta[c] - mean * a;
       float v = fmaf(p[i], a, b);
-      q[i] = RELU ? fmaxf(v, 0.f) : v;
+      q[i] = RELU ? rba_relu(v) : v;
     }
   }
 }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const float* __restr
   for (int p = lo + pl; p < hi; p += lanes) {
     float4 v = xp[(int64_t)p * C4];
     v.x = fmaf(v.x, a0, b0); v.y = fmaf(v.y, a1, b1); v.z = fmaf(v.z, a2, b2); v.w = fmaf(v.w, a3, b3);
-    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (RELU) { v.x = rba_relu(v.x); v.y = rba_relu(v.y); v.z = rba_relu(v.z); v.w = rba_relu(v.w); }
     yp[(int64_t)p * C4] = v;
   }
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void store_tile(const f32x16_t (&acc)[2][2], const fl
       for (int r = 0; r < 16; ++r) {
         v[r] += bv;
         if (ACT == 1) v[r] = gelu_erf(v[r]);
-        if (ACT == 2) v[r] = fmaxf(v[r], 0.f);
+        if (ACT == 2) v[r] = rba_relu(v[r]);
       }
       const int rbase = row0 + 32 * i + 4 * lh;
       float* dst = C + (int64_t)rbase * N + col;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void store_tile_transposed(const f32x16_t (&acc)[2][2
         const int n = nbase + 8 * (r >> 2) + (r & 3);
         v[r] += (bias && n < N) ? bias[n] : 0.f;
         if (ACT == 1) v[r] = gelu_erf(v[r]);
-        if (ACT == 2) v[r] = fmaxf(v[r], 0.f);
+        if (ACT == 2) v[r] = rba_relu(v[r]);
       }
       if (m < M) {
         if (nrow0 + 64 <= N) {                                     // wave-uniform: branch-free stores (see store_tile)

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256 + 64 * L) void split_linear_v4_kernel(const flo
       for (int r = 0; r < 16; ++r) {
         v[r] += bv;
         if (ACT == 1) v[r] = gelu_erf(v[r]);
-        if (ACT == 2) v[r] = fmaxf(v[r], 0.f);
+        if (ACT == 2) v[r] = rba_relu(v[r]);
       }
       const int rbase = m0 + 32 * (RT * wave + t) + 4 * lh;
       float* dst = C + (int64_t)rbase * N + col;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * (MW + L)) void split_linear_v5_kernel(const fl
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (ACT == 1) v[k] = gelu_erf(v[k]);
-              if (ACT == 2) v[k] = fmaxf(v[k], 0.f);
+              if (ACT == 2) v[k] = rba_relu(v[k]);
             }
             const int row = rbase + 8 * g4;
             if (interior || (row < M && col < N)) *reinterpret_cast<f32x4*>(C + (int64_t)row * N + col) = v;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * (MW + L)) void split_linear_v5_kernel(const fl
         for (int r = 0; r < 16; ++r) {
           v[r] += bv;
           if (ACT == 1) v[r] = gelu_erf(v[r]);
-          if (ACT == 2) v[r] = fmaxf(v[r], 0.f);
+          if (ACT == 2) v[r] = rba_relu(v[r]);
         }
         const int rbase = m0 + 32 * (RT * wave + t) + 4 * lh;
         float* dst = C + (int64_t)rbase * N + col;

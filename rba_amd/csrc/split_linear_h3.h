@@ -140,7 +140,7 @@ __device__ __forceinline__ void h3_epilogue(const f32x16_t (&accm)[CT], const f3
       if (RES) y = (f32x2){res[r], res[r + 1]} + y;
       y = y + bv;
       if (ACT == 1) y = gelu_erf2(y);
-      if (ACT == 2) y = (f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+      if (ACT == 2) y = (f32x2){rba_relu(y.x), rba_relu(y.y)};
       v[r] = y.x;
       v[r + 1] = y.y;
     }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float y = fmaf(xr[q][i], a[i], b[i]);
-          xr[q][i] = gn.relu ? fmaxf(y, 0.f) : y;
+          xr[q][i] = gn.relu ? rba_relu(y) : y;
         }
     }
 #pragma unroll
@@ -604,8 +604,8 @@ __device__ __forceinline__ void h3_epilogue_split(const f32x16_t (&accm)[CT], co
         y1 = gelu_erf2(y1);
       }
       if (ACT == 2) {
-        y0 = (f32x2){fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f)};
-        y1 = (f32x2){fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f)};
+        y0 = (f32x2){rba_relu(y0.x), rba_relu(y0.y)};
+        y1 = (f32x2){rba_relu(y1.x), rba_relu(y1.y)};
       }
       uint32_t h0, l0, h1, l1;
       rba_split_f16x2(y0.x, y0.y, h0, l0);

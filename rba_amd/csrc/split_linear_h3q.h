@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3q_kernel(const char* __
     if (MODE == H3Q_RES) y0 = (f32x2){ures.x, ures.y} + y0;
     y0 = y0 + (f32x2){ubias.x, ubias.y};
     if (ACT == 1) y0 = gelu_erf2(y0);
-    if (ACT == 2) y0 = (f32x2){fmaxf(y0.x, 0.f), fmaxf(y0.y, 0.f)};
+    if (ACT == 2) y0 = (f32x2){rba_relu(y0.x), rba_relu(y0.y)};
   };
   auto unit_math1 = [&](int u) {                                                     // second pair
     const int j = u >> 2, q = u & 3;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3q_kernel(const char* __
     if (MODE == H3Q_RES) y1 = (f32x2){ures.z, ures.w} + y1;
     y1 = y1 + (f32x2){ubias.z, ubias.w};
     if (ACT == 1) y1 = gelu_erf2(y1);
-    if (ACT == 2) y1 = (f32x2){fmaxf(y1.x, 0.f), fmaxf(y1.y, 0.f)};
+    if (ACT == 2) y1 = (f32x2){rba_relu(y1.x), rba_relu(y1.y)};
   };
   auto unit_store = [&](int u) {
     const int j = u >> 2, q = u & 3;

@@ -180,12 +180,14 @@ class ProcessDecoder:
         which then reads the answer file and page-locks it (file read and memcpy run without the interpreter lock)"""
         import itertools
         import queue
+        import threading
         import time
         free = queue.Queue()
         for p in self.procs:
             free.put(p)
         tags = itertools.count()
         st = self.stats
+        st_lock = threading.Lock()                          # several helper threads finish samples at once
 
         spec = decode_spec_of(dataset)
         if spec is None:
@@ -215,12 +217,13 @@ class ProcessDecoder:
                 return self._take(path, n, h, w, pin, i)
             finally:
                 t3 = time.perf_counter()
-                st["items"] += 1
-                st["wait_worker_s"] += t1 - t0
-                st["round_trip_s"] += t2 - t1
-                st["child_decode_s"] += float(f[4]) * 1e-3
-                st["child_write_s"] += float(f[5]) * 1e-3
-                st["take_s"] += t3 - t2
+                with st_lock:
+                    st["items"] += 1
+                    st["wait_worker_s"] += t1 - t0
+                    st["round_trip_s"] += t2 - t1
+                    st["child_decode_s"] += float(f[4]) * 1e-3
+                    st["child_write_s"] += float(f[5]) * 1e-3
+                    st["take_s"] += t3 - t2
 
         n = len(self.procs)
         yield from _ahead(get, indices, n + max(2, n // 2), depth or 3 * n)
@@ -230,8 +233,13 @@ class ProcessDecoder:
         """the answer file's bytes as (image [H,W,3], label [H,W]) uint8 views of one buffer (page-locked when `pin`); the file is removed"""
         if pin:
             buf = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            view, got = memoryview(buf.numpy()), 0
             with open(path, "rb", buffering=0) as fh:
-                got = fh.readinto(buf.numpy())
+                while got < n:                              # a raw read may return early (a signal, a disk-backed temp directory): loop until n bytes or EOF
+                    k = fh.readinto(view[got:])
+                    if not k:
+                        break
+                    got += k
             if got != n:
                 raise RuntimeError(f"decode worker: sample {i}: short answer file ({got} of {n} bytes)")
         else:

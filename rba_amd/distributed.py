@@ -81,6 +81,8 @@ def _gather_padded(t, world):
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
     mx = max(sizes)
+    if mx == 0:                                  # nobody has anything (every rank sees the same sizes, so every rank returns here)
+        return t.new_empty(0)
     buf = t.new_zeros(mx)
     buf[: t.numel()] = t
     out = t.new_empty(world * mx)

@@ -938,6 +938,27 @@ def test_split_linear_relu_epilogue(ops):
         assert maxerr(ops.linear(xx, lin, relu=True), F.relu(F.linear(xx.double(), lin.weight.double(), lin.bias.double()))) < 3e-5
 
 
+def test_relu_epilogues_keep_nan(ops):
+    """the f16x3 kernels answer an operand beyond f16's range with NaN, and the evaluator re-scores an image on bf16x6 when its score map holds a
+    NaN -- so no ReLU on the way may turn NaN into 0 (fmaxf does).  Every ReLU form: K6 epilogue, token / skinny Linear, GroupNorm(+ReLU) both layouts."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(256, 128, generator=g)
+    x[7, 5] = 7e4                                                                     # beyond 65504: row 7 of every f16x3 product is NaN
+    w = torch.randn(128, 128, generator=g) * 0.1
+    y = ops.split_linear(dev(x), ops.split_weight(dev(w), mode="f16x3"), None, relu=True, out_features=128)
+    assert torch.isnan(y[7]).all() and torch.isfinite(y[8]).all() and (y[8] >= 0).all()
+    lin = torch.nn.Linear(128, 128).cuda()
+    t = ops.token_linear(dev(x), lin, relu=True)
+    assert torch.isnan(t[7]).all() and torch.isfinite(t[6]).all()
+    xn = torch.randn(1, 64, 32, generator=g)
+    xn[0, 3, 9] = float("nan")
+    one, zero = dev(torch.ones(32)), dev(torch.zeros(32))
+    assert torch.isnan(ops.group_norm_nhwc(dev(xn), 4, one, zero, relu=True)[0, :, 8:16]).all()          # the NaN's group: statistics and outputs NaN
+    assert torch.isnan(ops.group_norm(dev(xn.permute(0, 2, 1).reshape(1, 32, 8, 8).contiguous()), 4, one, zero, relu=True)[0, 8:16]).all()
+    sk = ops.skinny_linear(dev(torch.full((4, 128), float("nan"))), dev(w), None, relu=True)
+    assert torch.isnan(sk).all()
+
+
 def test_split_linear_extreme_values(ops):
     """Exactness of the split over the exponent range, zeros, and values whose low planes vanish."""
     g = torch.Generator().manual_seed(5)

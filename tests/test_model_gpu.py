@@ -446,7 +446,7 @@ def test_open_panoptic_inference_vs_oracle():
     assert sorted(s["id"] for s in info_g) == list(range(1, len(info_g) + 1)) and int(pan_g.max()) <= len(info_g)
 
 
-def test_rccl_executes_the_metric_exchange_in_a_one_rank_group(tmp_path):
+def test_rccl_executes_the_metric_exchange_in_a_one_rank_group():
     """round 5: no gpurun box has two GPUs, so RCCL never saw this repository's collectives.  A ONE-rank `nccl` process group on device 0 runs them for real:
     all_gather of the sizes + padded all_gather_into_tensor on ragged DEVICE tensors (distributed._gather_padded), the histogram all_reduce, and the
     pooled metrics -- equal to the single-process values; then bench.py's exchange leg through the same group (--rccl-one-rank: dist_backend nccl)."""
@@ -454,43 +454,16 @@ def test_rccl_executes_the_metric_exchange_in_a_one_rank_group(tmp_path):
     import subprocess
     import sys
     REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "one_rank.py"
-    script.write_text('''
-import os, sys, json
-sys.path.insert(0, os.environ["RBA_REPO"])
-import torch, torch.distributed as dist
-from rba_amd import distributed as D
-from rba_amd.metrics import ood_metrics
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), RBA_DIST_ONE_RANK_GROUP="1")
-rank, world, local = D.init_from_env()
-assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
-g = torch.Generator(device="cuda").manual_seed(3)
-out = {"backend": dist.get_backend()}
-for n in (0, 1, 1000, 123457):
-    t = torch.randn(n, device="cuda", generator=g)
-    assert D.all_gather_variable(t) is t                       # a 1-rank world returns early ...
-    with D.force_collective():
-        got = D.all_gather_variable(t)                         # ... unless told to run RCCL anyway
-    assert got.is_cuda and got.data_ptr() != t.data_ptr() and torch.equal(got, t)
-s = torch.randn(200000, device="cuda", generator=g)
-l = (torch.rand(200000, device="cuda", generator=g) < 0.05)
-want = ood_metrics(s, l.to(torch.uint8))
-with D.force_collective():
-    pooled = D.pooled_ood_metrics(s, l)
-    hist = D.histogram_ood_metrics(s, l)
-assert pooled == want, (pooled, want)
-assert all(abs(hist[k] - want[k]) < 2e-3 for k in want), (hist, want)
-out["pooled"] = pooled
-dist.barrier(); dist.destroy_process_group()
-print("RESULT " + json.dumps(out))
-''')
-    env = dict(os.environ, RBA_REPO=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(REPO, "tools", "rccl_one_rank.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k_, None)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["backend"] == "nccl"
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--rccl-one-rank", "--steps", "2", "--warmup", "1", "--height", "256", "--width", "512",
-                        "--arch", "tiny3", "--no-cpu-baseline", "--sustain", "0"], capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--rccl-one-rank", "--steps", "2", "--warmup", "1", "--height", "512", "--width", "1024",
+                        "--streams", "1", "--n-images", "2", "--no-cpu-baseline", "--sustain", "0.5"], capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["dist_backend"] == "nccl" and line["n_gpus"] == 1 and line["metric_exchange_ms"] > 0 and set(line["pooled_metrics"]) == {"auroc", "aupr", "fpr95"}
