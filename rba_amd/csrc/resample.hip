@@ -86,7 +86,7 @@ __device__ __forceinline__ f32x4 gn_fold_apply(f32x4 v, const f32x4 a, const f32
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     v[k] = fmaf(v[k], a[k], b[k]);
-    if (relu) v[k] = rba_relu(v[k]);
+    v[k] = rba_clamp_below(v[k], rba_relu_floor(relu));
   }
   return v;
 }

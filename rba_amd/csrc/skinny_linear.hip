@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_kernel(const float* __r
     for (int w = 0; w < SW; ++w) sum += red[(w * MT * 16 + m) * 16 + n];
     if (m < M && n0 + n < N) {
       if (bias) sum += bias[n0 + n];
-      if (relu) sum = rba_relu(sum);
+      sum = rba_clamp_below(sum, rba_relu_floor(relu));
       const int nn = n0 + n;
       out[seg_n ? ((int64_t)(nn / seg_n) * M + m) * seg_n + nn % seg_n : (int64_t)m * N + nn] = sum;
     }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * SW) void skinny_linear_tile_kernel(const float
     for (int w = 0; w < SW; ++w) sum += red[(w * 16 + m) * 16 + n];
     if (m0 + m < M && n0 + n < N) {
       if (bias) sum += bias[n0 + n];
-      if (relu) sum = rba_relu(sum);
+      sum = rba_clamp_below(sum, rba_relu_floor(relu));
       const int nn = n0 + n, mm = m0 + m;
       out[seg_n ? ((int64_t)(nn / seg_n) * M + mm) * seg_n + nn % seg_n : (int64_t)mm * N + nn] = sum;
     }

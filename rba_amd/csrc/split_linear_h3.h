@@ -498,11 +498,19 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
       for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(xs + xoff[q]);
     }
   };
+  // GNF: the normalised rows (GroupNorm [+ ReLU] applied to the block in registers) go to LDS instead of the raw ones
+  f32x4 xst[4];
   auto lstore = [&](u32x4_t* buf) {
 #pragma unroll
     for (int q = 0; q < UPL; ++q) buf[tid + 256 * q] = wr[q];
     if (GNF) {
       f32x4 a, b;
+      // NaN must stay NaN through the ReLU (common.h: rba_relu): fmaxf(NaN, 0) is 0.  A NaN / inf anywhere in a group makes the group's statistics NaN,
+      // so `poison` (0, or NaN when they are) added after the max keeps every value of such a group loud -- one v_add per value, and the normalised value
+      // is used ONCE: the forms that read it twice (`y < f ? f : y`, `max(y, f) + (y - y)`) went wrong in this loop on MI355X for reasons round 5 did not
+      // find (tools/gnfold_probe.py, profiles/r05_gnfold_select.txt), while max, max + add and an integer mask are exact in every run.
+      const float relu_floor = gn.relu ? 0.f : -INFINITY;
+      const float poison = (grstd - grstd) + (gmean - gmean);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         a[i] = gga[i] * grstd;
@@ -511,13 +519,13 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float y = fmaf(xr[q][i], a[i], b[i]);
-          xr[q][i] = gn.relu ? rba_relu(y) : y;
-        }
-    }
+        for (int i = 0; i < 4; ++i) xst[q][i] = fmaxf(fmaf(xr[q][i], a[i], b[i]), relu_floor) + poison;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) buf[xdst + 256 * q] = __builtin_bit_cast(u32x4_t, xr[q]);
+      for (int q = 0; q < 4; ++q) buf[xdst + 256 * q] = __builtin_bit_cast(u32x4_t, xst[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) buf[xdst + 256 * q] = __builtin_bit_cast(u32x4_t, xr[q]);
+    }
   };
   gload(0);
   lstore(lds);

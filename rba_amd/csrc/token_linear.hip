@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * TLW) void token_linear_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = fmaf(accl[rt][i][r], 0.00048828125f, accm[rt][i][r]) + bv[r];
-        if (p.act == 2) v = rba_relu(v);
+        v = rba_clamp_below(v, rba_relu_floor(p.act == 2));
         val[rt][i][r] = ok ? v : 0.f;
       }
   }

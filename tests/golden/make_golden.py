@@ -493,6 +493,38 @@ def g_end_to_end(R, arch, h, w, seed, img_seed, full_outputs, name, npix=4096, r
     save(name, **arrs)
 
 
+def g_stage_samples(R, arch, h, w, seed, img_seed, name, recipe=None):
+    """Round 5 (error attribution): strided samples of the reference's INTERMEDIATES of a full-size forward -- res2..res5, mask_features, pred_masks, class
+    logits, sem_seg, rba -- so that a product-side error can be assigned to a stage (tests/test_model_gpu.py::test_error_attribution_by_stage).  A few
+    hundred KB: every channel at a 4 x 8 grid of positions for the backbone maps, an 8 x 8 grid for the mask features, 512 random positions of the mask logits,
+    4096 random pixels of the outputs."""
+    model = _ref_model(R, arch, seed, recipe)
+    image = rand_image(h, w, img_seed)
+    taps = {}
+    o = ref_forward(model, image, taps)
+    arrs = dict(arch=np.array(arch), hw=np.array([h, w]), seed=np.array(seed), img_seed=np.array(img_seed), recipe=np.array(recipe or "base"),
+                pred_logits=np_(o["pred_logits"]))
+    for k, v in taps["feats"].items():
+        fh, fw = v.shape[-2:]
+        fy = torch.arange(4) * (fh // 4) + fh // 8
+        fx = torch.arange(8) * (fw // 8) + fw // 16
+        arrs.update({f"fy_{k}": np_(fy), f"fx_{k}": np_(fx), f"feat_{k}_s": np_(v[0][:, fy][:, :, fx])})
+    mf = taps["mask_features"][0]
+    my = torch.arange(8) * (mf.shape[1] // 8) + mf.shape[1] // 16
+    mx = torch.arange(8) * (mf.shape[2] // 8) + mf.shape[2] // 16
+    arrs.update(my=np_(my), mx=np_(mx), mask_features_s=np_(mf[:, my][:, :, mx]))
+    g = torch.Generator().manual_seed(321)
+    pm = o["pred_masks"]
+    ys4 = torch.randint(0, pm.shape[1], (512,), generator=g)
+    xs4 = torch.randint(0, pm.shape[2], (512,), generator=g)
+    ys = torch.randint(0, h, (4096,), generator=g)
+    xs = torch.randint(0, w, (4096,), generator=g)
+    arrs.update(ys4=np_(ys4), xs4=np_(xs4), pred_masks_s=np_(pm[:, ys4, xs4]), ys=np_(ys), xs=np_(xs), rba_s=np_(o["rba"][ys, xs]),
+                sem_s=np_(o["sem_seg"][:, ys[:512], xs[:512]]))
+    print(f"  {name}: " + ", ".join(f"{k} {tuple(v.shape)}" for k, v in arrs.items() if hasattr(v, "shape") and v.ndim > 1))
+    save(name, **arrs)
+
+
 def g_metrics(R):
     """G6: AUROC / AuPRC / FPR95 exactly as support.py:247-303 computes them (sklearn roc_curve with its
     default drop_intermediate=True, auc, average_precision_score; FPR at the first tpr > 0.95)."""
@@ -562,6 +594,9 @@ def main():
         # metric parity (BASELINE configs[4] "AuPRC/FPR95 parity check" and its configs[1] twin): 4 images each
         jobs["g7c5"] = lambda: g_metric_parity(R, "swin_b_9dl", 720, 1280, 0, [1234, 1235, 1236, 1237], "g7_metrics_swin_b_9dl_720x1280")
         jobs["g7c2"] = lambda: g_metric_parity(R, "swin_b_1dl", 1024, 2048, 0, [1234, 1235, 1236, 1237], "g7_metrics_swin_b_1dl_1024x2048")
+        # round 5: strided samples of the reference's intermediates (error attribution by stage) for C2 and the heavy recipe
+        jobs["g8c2"] = lambda: g_stage_samples(R, "swin_b_1dl", 1024, 2048, 0, 1234, "g8_stages_swin_b_1dl_1024x2048")
+        jobs["g8heavy"] = lambda: g_stage_samples(R, "swin_b_1dl", 512, 1024, 0, 1234, "g8_stages_swin_b_1dl_heavy_512x1024", recipe="heavy")
     for k, fn in jobs.items():
         if args.only and k != args.only:
             continue

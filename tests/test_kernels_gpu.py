@@ -957,6 +957,14 @@ def test_relu_epilogues_keep_nan(ops):
     assert torch.isnan(ops.group_norm(dev(xn.permute(0, 2, 1).reshape(1, 32, 8, 8).contiguous()), 4, one, zero, relu=True)[0, 8:16]).all()
     sk = ops.skinny_linear(dev(torch.full((4, 128), float("nan"))), dev(w), None, relu=True)
     assert torch.isnan(sk).all()
+    # the GroupNorm + ReLU folded into the mask-feature projection's loads (FPN: an overflowed convolution output must not come out as zeros)
+    B, P, K, N, G = 2, 256, 256, 128, 32
+    xf = torch.randn(B, P, K, generator=g)
+    xf[1, 17, 40] = float("nan")
+    p3 = ops.split_weight(dev(torch.randn(N, K, generator=g) * K ** -0.5), mode="f16x3")
+    mr = ops.group_norm_nhwc_stats(dev(xf), G, 1e-5)
+    o = ops.split_linear_nchw_out_gn(dev(xf).view(B * P, K), mr, dev(torch.ones(K)), dev(torch.zeros(K)), G, True, p3, None, P, out_features=N)
+    assert torch.isfinite(o[0]).all() and torch.isnan(o[1]).all()
 
 
 def test_split_linear_extreme_values(ops):
