@@ -201,6 +201,78 @@ def test_heavy_tailed_weights_swin_b_512x1024(golden):
     _full_size(golden, "g5_swin_b_1dl_heavy_512x1024", "swin_b_1dl", 1e-4)
 
 
+@pytest.mark.parametrize("fixture", ["g8_stages_swin_b_1dl_1024x2048", "g8_stages_swin_b_1dl_heavy_512x1024"])
+def test_error_attribution_by_stage(golden, fixture):
+    """what does the default arithmetic cost, and where?  The reference's INTERMEDIATES of a full-size forward (strided samples generated by
+    make_golden.py --full from the reference's own modules: res2..res5, mask_features, mask logits, class logits, sem_seg, rba) against the product's, stage by
+    stage, in three arithmetic configurations: the default (f16x3 everywhere, fused stage-1 attention), the same without the fused attention kernel (is the
+    fusion's summation order visible?) and bf16x6 GEMMs (2^-24 products: is the error f16x3's 22-bit operands or re-association?).  Per-stage bounds are
+    asserted; the table goes to gpurun_out/ (docs/measurements.md quotes it)."""
+    import json
+    from rba_amd import ops
+    g = golden(fixture)
+    g5 = golden(fixture.replace("g8_stages", "g5"))                                     # the complete argmax map + near-tie set of the same forward
+    recipe = str(g["recipe"])
+    h, w = (int(v) for v in g["hw"])
+    model, a, sd = build(str(g["arch"]), int(g["seed"]), None if recipe == "base" else recipe)
+    model.graph_replay = False
+    gen = torch.Generator().manual_seed(int(g["img_seed"]))
+    image = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
+    ref_arg = T(g5["argmax_full"].astype(np.int64))
+    tie = torch.zeros(h * w, dtype=torch.bool)
+    tie[T(g5["neartie_idx"])] = True
+    tie = tie.view(h, w)
+    ys, xs, ys4, xs4 = (T(g[k]).long() for k in ("ys", "xs", "ys4", "xs4"))
+
+    def run():
+        r = {}
+        feats = model.backbone(model.preprocess([{"image": image}])[0])
+        for k in ("res2", "res3", "res4", "res5"):
+            fy, fx = T(g["fy_" + k]).long(), T(g["fx_" + k]).long()
+            ref = T(g["feat_" + k + "_s"])
+            got = feats[k][0].cpu()[:, fy][:, :, fx]
+            r[k] = ((got - ref).abs().max().item(), ref.abs().max().item())
+        mf = model.sem_seg_head.pixel_decoder.forward_features(feats)[0][0].cpu()
+        ref = T(g["mask_features_s"])
+        r["mask_features"] = ((mf[:, T(g["my"]).long()][:, :, T(g["mx"]).long()] - ref).abs().max().item(), ref.abs().max().item())
+        mask_cls, mask_pred, _, _ = model.predict([{"image": image}])
+        ref = T(g["pred_masks_s"])
+        r["pred_masks"] = ((mask_pred[0].cpu()[:, ys4, xs4] - ref).abs().max().item(), ref.abs().max().item())
+        r["pred_logits"] = (maxerr(mask_cls[0], g["pred_logits"]), float(np.abs(g["pred_logits"]).max()))
+        out = model([{"image": image}], return_argmax=True)[0]
+        ref = T(g["sem_s"])
+        r["sem_seg"] = ((out["sem_seg"].cpu()[:, ys[:512], xs[:512]] - ref).abs().max().item(), ref.abs().max().item())
+        ref = T(g["rba_s"])
+        r["rba"] = ((out["rba"].cpu()[ys, xs] - ref).abs().max().item(), ref.abs().max().item())
+        flips = out["argmax"].cpu().long() != ref_arg
+        r["argmax_flips"] = (int(flips.sum()), int((flips & ~tie).sum()))
+        return r
+
+    table = {"default (f16x3, fused stage-1 attention)": run()}
+    prev = ops.SWIN_ATTN_FUSED
+    try:
+        ops.SWIN_ATTN_FUSED = False
+        table["f16x3, unfused attention (LN -> K6 -> K5 -> K6)"] = run()
+    finally:
+        ops.SWIN_ATTN_FUSED = prev
+    with ops.split_mode("bf16x6"):
+        table["bf16x6 GEMMs (2^-24 products; K5 / K4 / K1 stay f16x3)"] = run()
+    stages = ["res2", "res3", "res4", "res5", "mask_features", "pred_masks", "pred_logits", "sem_seg", "rba"]
+    print(f"\n{fixture} ({recipe} weights, {h}x{w}): max |product - reference| per stage (reference magnitude in brackets), near-tie pixels {int(tie.sum())}")
+    for mode, r in table.items():
+        print(f"  {mode}")
+        print("    " + "  ".join(f"{k} {r[k][0]:.1e} [{r[k][1]:.1f}]" for k in stages) + f"  argmax flips {r['argmax_flips'][0]} (outside near-ties {r['argmax_flips'][1]})")
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"r05_attribution_{recipe}.json"), "w") as f:
+        json.dump({"fixture": fixture, "near_tie_pixels": int(tie.sum()), "pixels": h * w, "table": table}, f, indent=1)
+    for mode, r in table.items():
+        for k in ("res2", "res3", "res4", "res5", "mask_features"):
+            assert r[k][0] <= 3e-5 * max(1.0, r[k][1]), (mode, k, r[k])                   # relative to the stage's own range (heavy: residual outliers to 1e3)
+        assert r["pred_logits"][0] < 1e-4 and r["pred_masks"][0] <= 5e-4 * max(1.0, r["pred_masks"][1] / 10.0), (mode, r)
+        assert r["sem_seg"][0] < 1e-4 and r["rba"][0] < 1e-4, (mode, r)                    # north star: scores within 1e-4
+        assert r["argmax_flips"][1] == 0 and r["argmax_flips"][0] <= int(tie.sum()), (mode, r)
+
+
 @pytest.mark.parametrize("fixture, arch_name", [("g7_metrics_swin_b_9dl_720x1280", "swin_b_9dl"),
                                                 ("g7_metrics_swin_b_1dl_1024x2048", "swin_b_1dl")])
 def test_metric_parity_full_size(golden, fixture, arch_name):
