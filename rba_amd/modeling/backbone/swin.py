@@ -159,9 +159,18 @@ class PatchEmbed(nn.Module):
         _, _, H, W = x.shape
         if W % ps or H % ps:
             x = F.pad(x, (0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
-        x = F.conv2d(x, self.proj.weight, self.proj.bias, stride=ps)
-        Wh, Ww = x.shape[2], x.shape[3]
-        x = x.flatten(2).transpose(1, 2).contiguous()
+        # the stride-ps, ps x ps convolution of non-overlapping patches IS a Linear over the patch's 3 ps^2 values (k = (c, dy, dx), the weight's own order):
+        # one gather + the library's GEMM (ops.linear pads K = 48 to 64) -- no MIOpen call on this path either (round 5)
+        B, Cin, H, W = x.shape
+        Wh, Ww = H // ps, W // ps
+        cols = x.view(B, Cin, Wh, ps, Ww, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, Wh * Ww, Cin * ps * ps).contiguous()
+        w = self.proj.weight
+        key = (w.data_ptr(), w._version, w.device)
+        c = getattr(self, "_rba_lin", None)
+        if c is None or c[0] != key:
+            from types import SimpleNamespace
+            c = self._rba_lin = (key, SimpleNamespace(weight=w.detach().reshape(w.shape[0], -1), bias=self.proj.bias))
+        x = ops.linear(cols, c[1])
         return ops.add_layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)[1], Wh, Ww
 
     def fused_ok(self):

@@ -58,7 +58,20 @@ class ConvNorm(nn.Module):
         self.padding, self.relu = k // 2, relu
 
     def forward(self, x):
-        x = _conv1x1_nchw(x, self) if self.padding == 0 else F.conv2d(x, self.weight, self.bias, padding=self.padding)
+        if self.padding == 0:
+            x = _conv1x1_nchw(x, self)
+        elif self.weight.shape[1] % 32 == 0:
+            # round 5: the NCHW fallback layout's 3 x 3 convolutions run the library's own implicit-GEMM kernel too (one transpose in, one out): MIOpen -- the
+            # one component that ever returned different bits from one call to the next (profiles/r04_flake_cause.txt) -- is out of the product
+            w = self.weight
+            key = (w.data_ptr(), w._version, w.device, ops.SPLIT_MODE)
+            c = getattr(self, "_rba_conv3", None)
+            if c is None or c[0] != key:
+                c = self._rba_conv3 = (key, ops.conv3x3_weight(w.detach()))
+            y = ops.conv3x3_nhwc(x.permute(0, 2, 3, 1).contiguous(), c[1], self.bias, out_features=w.shape[0])
+            x = y.permute(0, 3, 1, 2).contiguous()
+        else:                                                                    # (no released configuration: conv_dim is 256)
+            x = F.conv2d(x, self.weight, self.bias, padding=self.padding)
         if self.norm is not None:
             return ops.group_norm(x.contiguous(), 32, self.norm.weight, self.norm.bias, self.norm.eps, relu=self.relu)
         return F.relu(x) if self.relu else x

@@ -17,12 +17,21 @@ from .position_encoding import PositionEmbeddingSine
 
 
 def _qlinear(x, weight, bias=None, relu=False, x_add=None):
-    """Linear layer on the query tensor [B, Q, C] (<= 128 rows): the skinny MFMA kernel; anything larger -> library GEMM.
+    """Linear layer on the query tensor [B, Q, C]: the skinny exact-fp32 MFMA kernel, over blocks of at most 128 rows (one launch for a single image's
+    100 queries; a batch of B images takes ceil(100 B / 128) launches -- round 5: no library GEMM for B >= 2 either).
     x_add: the Linear runs on x + x_add (the query position embedding), added inside the kernel."""
-    if x.numel() // x.shape[-1] <= 128 and x.shape[-1] % 32 == 0:
-        return ops.skinny_linear(x.contiguous(), weight, bias, relu, x_add=None if x_add is None else x_add.contiguous())
-    y = F.linear(x if x_add is None else x + x_add, weight, bias)
-    return F.relu(y) if relu else y
+    K = x.shape[-1]
+    if K % 32:
+        raise ops.RbaHipError("query Linears need K % 32 == 0 (hidden_dim 256 in every released architecture)")
+    M = x.numel() // K
+    x2 = x.contiguous().view(M, K)
+    a2 = None if x_add is None else x_add.contiguous().view(M, K)
+    if M <= 128:
+        return ops.skinny_linear(x2, weight, bias, relu, x_add=a2).view(tuple(x.shape[:-1]) + (weight.shape[0],))
+    out = torch.empty((M, weight.shape[0]), dtype=torch.float32, device=x.device)
+    for r0 in range(0, M, 128):
+        out[r0:r0 + 128] = ops.skinny_linear(x2[r0:r0 + 128], weight, bias, relu, x_add=None if a2 is None else a2[r0:r0 + 128])
+    return out.view(tuple(x.shape[:-1]) + (weight.shape[0],))
 
 
 class _MHAParams(nn.Module):

@@ -7,6 +7,7 @@ no fallback path.
 """
 import contextlib
 import ctypes
+import threading
 import functools
 import math
 import os
@@ -223,7 +224,7 @@ def masked_xattn(q, k, v, mask_logits=None, split_keys=None):
 
 @_hip_op
 def mask_logits(embed, feat, mode=None):
-    """K4.  einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479): embed [B,Q,C], feat [B,C,h,w].  `mode` (default: SPLIT_MODE)
+    """K4.  einsum("bqc,bchw->bqhw") (mask2former_transformer_decoder.py:479): embed [B,Q,C], feat [B,C,h,w].  `mode` (default: _split_mode())
     "f16x3" = three f16 matrix-pipe products per fp32 product (|x| < 65504), anything else = the exact-fp32 MFMA kernel."""
     lib = _lib.load()
     _chk(embed, "embed", dim=3)
@@ -238,7 +239,7 @@ def mask_logits(embed, feat, mode=None):
     for s in sp:
         N *= int(s)
     out = torch.empty((B, Q) + sp, dtype=torch.float32, device=embed.device)
-    if (SPLIT_MODE if mode is None else mode) == "f16x3":
+    if (_split_mode() if mode is None else mode) == "f16x3":
         _lib.check(lib.rba_mask_logits_f16x3_f32(_p(embed), _p(feat), _p(out), B, Q, C, N, _stream()), "rba_mask_logits_f16x3_f32")
     else:
         _lib.check(lib.rba_mask_logits_f32(_p(embed), _p(feat), _p(out), B, Q, C, N, _stream()), "rba_mask_logits_f32")
@@ -301,7 +302,7 @@ SWIN_ATTN_FUSED = os.environ.get("RBA_SWIN_ATTN_FUSED", "1") != "0"      # A/B s
 
 def swin_attn_block_ok(C, num_heads, window_size):
     """True when swin_attn_block() has a kernel for this geometry (K7: head_dim 32, 12 x 12 windows, f16x3 mode)."""
-    return (SWIN_ATTN_FUSED and SPLIT_MODE == "f16x3" and num_heads * 32 == C
+    return (SWIN_ATTN_FUSED and _split_mode() == "f16x3" and num_heads * 32 == C
             and bool(_lib.load().rba_swin_attn_block_supported(int(C), int(window_size))))
 
 
@@ -566,10 +567,22 @@ class SplitActivations:
         return (hl[0] + hl[1] / 2048.0)[:M].reshape(self.shape)
 
 
-SPLIT_MODE = "f16x3"
-"""Arithmetic of the token Linear (K6).  "f16x3": two f16 pieces per operand, three f16 MFMAs per product -- as accurate as an
+_SPLIT = threading.local()
+_SPLIT_DEFAULT = "f16x3"
+"""ops.SPLIT_MODE: arithmetic of the token Linear (K6), PER THREAD (round 5: it was a process global; a re-score on another thread, or a tool
+flipping it, changed the kernels of every forward in flight).  Read it as `ops.SPLIT_MODE`, set it for a block with `ops.split_mode(mode)`.  "f16x3": two f16 pieces per operand, three f16 MFMAs per product -- as accurate as an
 fp32 GEMM for |x|, |w| < 65504 (beyond f16's range the output is NaN, never silently wrong), twice the speed of "bf16x6": three
 bf16 pieces, six MFMAs, fp32's full range."""
+
+
+def _split_mode():
+    return getattr(_SPLIT, "mode", _SPLIT_DEFAULT)
+
+
+def __getattr__(name):                     # module attribute: ops.SPLIT_MODE = the calling thread's mode
+    if name == "SPLIT_MODE":
+        return _split_mode()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 @_hip_op
@@ -583,7 +596,7 @@ def split_weight(weight, mode=None):
     N, K = weight.shape
     if not split_linear_supported(N, K):
         raise RbaHipError("split_weight needs weight [N,K] with K % 32 == 0")
-    mode = SPLIT_MODE if mode is None else mode
+    mode = _split_mode() if mode is None else mode
     if mode == "f16x3":
         packed = torch.empty(((N + 127) // 128, K // 16, 2, 128, 2, 8), dtype=torch.float16, device=weight.device)
         _lib.check(lib.rba_split_weight_f16x2(_p(weight), _p(packed), N, K, _stream()), "rba_split_weight_f16x2")
@@ -629,7 +642,7 @@ def split_linear_pays(M, N, K, gelu=False):
 @_hip_op
 def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None, split_out=False):
     """``F.linear(x, lin.weight, lin.bias)`` [+ exact GELU | ReLU] for an ``nn.Linear`` on a token tensor, through the split
-    kernel where it pays (weight planes are split once per weight load and cached on the module), hipBLASLt otherwise.
+    kernel of the current ops.SPLIT_MODE (weight planes are split once per weight load and cached on the module) -- no library GEMM for any shape.
     ``residual`` (f16x3 form only, see linear_residual_fused): returns ``(residual + x W^T) + bias`` written IN PLACE over `residual`.
     ``split_out`` (f16x3, with gelu): the result is returned as SplitActivations for the next linear() (fc1 -> fc2)."""
     w = lin.weight
@@ -637,48 +650,56 @@ def linear(x, lin, use_bias=True, gelu=False, relu=False, residual=None, split_o
     M = x.numel() // K if K else 0
     bias = lin.bias if use_bias else None
     if isinstance(x, SplitActivations):
-        if SPLIT_MODE != "f16x3" or x.shape[-1] != K:
+        if _split_mode() != "f16x3" or x.shape[-1] != K:
             raise RbaHipError("SplitActivations feed the f16x3 Linear only (check linear_takes_split(M, N, K) before producing them)")
         return split_linear(x, _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual, split_out=split_out)
     _chk(x, "x") if x.is_contiguous() else _chk(x.contiguous(), "x")          # HIP fp32 tensors only: no CPU path here either
     if split_out:
-        if SPLIT_MODE != "f16x3" or not split_linear_supported(N, K):
+        if _split_mode() != "f16x3" or not split_linear_supported(N, K):
             raise RbaHipError("linear(split_out=True) needs the f16x3 mode and K % 32 == 0")
         return split_linear(x.contiguous(), _cached_planes(lin, w), bias, gelu=gelu, out_features=N, split_out=True)
-    if split_linear_pays(M, N, K, gelu):
-        return split_linear(x.contiguous(), _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
-    if residual is not None:
+    if residual is not None and not linear_residual_fused(M, N, K):
         raise RbaHipError("linear(residual=...) needs the fused f16x3 path: check linear_residual_fused(M, N, K) first")
-    y = torch.nn.functional.linear(x, w, bias)
-    return torch.nn.functional.gelu(y) if gelu else (torch.relu(y) if relu else y)
+    if split_linear_supported(N, K):
+        # round 5: every shape runs the library's own GEMM (the f16x3 / bf16x6 kernels take any M and N); `split_linear_pays` only says where they beat
+        # hipBLASLt, and the small launches it used to send there (tiny test nets, the bf16x6 re-score of the encoder / decoder Linears) are latency-bound anyway
+        return split_linear(x.contiguous(), _cached_planes(lin, w), bias, gelu=gelu, out_features=N, relu=relu, residual=residual)
+    # K not a multiple of 32 (no layer of the released architectures): zero-pad K once per weight load and per call -- still no library GEMM
+    Kp = (K + 31) // 32 * 32
+    xp = torch.zeros(tuple(x.shape[:-1]) + (Kp,), dtype=torch.float32, device=x.device)
+    xp[..., :K] = x
+    return split_linear(xp, _cached_planes(lin, w, pad_k=Kp), bias, gelu=gelu, out_features=N, relu=relu)
 
 
-def _cached_planes(lin, w):
-    """split_weight(w) of the current SPLIT_MODE, cached on the module per mode (the bf16x6 planes of the non-finite fallback stay
-    beside the f16x3 ones: switching modes does not re-split)."""
-    key = (w.data_ptr(), w._version, w.device)
+def _cached_planes(lin, w, pad_k=None):
+    """split_weight(w) of the current split mode, cached on the module per mode (the bf16x6 planes of the non-finite fallback stay
+    beside the f16x3 ones: switching modes does not re-split).  pad_k: w zero-padded to that many columns first."""
+    key = (w.data_ptr(), w._version, w.device, pad_k)
     caches = getattr(lin, "_rba_planes", None)
     if not isinstance(caches, dict):
         caches = lin._rba_planes = {}
-    cache = caches.get(SPLIT_MODE)
+    cache = caches.get(_split_mode())
     if cache is None or cache[0] != key:
-        cache = caches[SPLIT_MODE] = (key, split_weight(w.detach().contiguous()))
+        w2 = w.detach().contiguous()
+        if pad_k is not None:
+            w2 = torch.nn.functional.pad(w2, (0, pad_k - w2.shape[1]))
+        cache = caches[_split_mode()] = (key, split_weight(w2))
     return cache[1]
 
 
 @contextlib.contextmanager
 def split_mode(mode):
-    """Run a block with ops.SPLIT_MODE = mode ("f16x3" | "bf16x6"), e.g. to re-score an image whose f16x3 result is NaN
-    (an activation or weight beyond f16's range) on the full-range kernels.  NOT thread-safe: SPLIT_MODE is a process global that every
-    ops.linear() call reads -- no other thread of the process may issue forwards while a block runs (the evaluator loops are single-threaded)."""
-    global SPLIT_MODE
+    """Run a block with ops.SPLIT_MODE = mode ("f16x3" | "bf16x6") ON THE CALLING THREAD, e.g. to re-score an image whose f16x3 result is NaN
+    (an activation or weight beyond f16's range) on the full-range kernels.  Other threads of the process keep their own mode; launches already
+    enqueued on any stream are not affected (the mode selects kernels at launch time)."""
     if mode not in ("f16x3", "bf16x6"):
         raise RbaHipError(f"unknown split mode {mode!r}")
-    prev, SPLIT_MODE = SPLIT_MODE, mode
+    prev = _split_mode()
+    _SPLIT.mode = mode
     try:
         yield
     finally:
-        SPLIT_MODE = prev
+        _SPLIT.mode = prev
 
 
 SPLIT_ACTIVATIONS = os.environ.get("RBA_SPLIT_ACTIVATIONS", "1") != "0"      # A/B switch (tools): producers keep writing fp32 rows
@@ -693,7 +714,7 @@ def linear_takes_split(M, N, K):
     """True when linear() on this shape runs a kernel whose A operand a producer can hand over as SplitActivations: the pipelined
     128-column f16x3 kernel (K >= SPLIT_MIN_K, at least 160 tiles of 128 x 128) or, for smaller launches, the sub-tile kernel of
     csrc/split_linear_h3q.h (K % 64 == 0, K >= 256, N % 32 == 0, at least 32 tiles: Swin stage 4's proj / fc2 with 128 tiles)."""
-    if not (SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and K >= SPLIT_MIN_K and K % 32 == 0):
+    if not (SPLIT_ACTIVATIONS and _split_mode() == "f16x3" and K >= SPLIT_MIN_K and K % 32 == 0):
         return False
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     return tiles >= 160 or (tiles >= 32 and K % 64 == 0 and K >= 256 and N % 32 == 0)
@@ -704,7 +725,7 @@ MLP_FUSED_MIN_ROWS = 32768          # 256 workgroups of 128 rows: below that the
 
 def mlp_fused_ok(M, C, hidden):
     """True when mlp_fused() applies: the one-kernel Swin MLP exists for C = 128 (Swin-B stage 1), f16x3 mode."""
-    return SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and C == 128 and hidden % 32 == 0 and hidden >= 64 and M >= MLP_FUSED_MIN_ROWS
+    return SPLIT_ACTIVATIONS and _split_mode() == "f16x3" and C == 128 and hidden % 32 == 0 and hidden >= 64 and M >= MLP_FUSED_MIN_ROWS
 
 
 @_hip_op
@@ -717,7 +738,7 @@ def mlp_fused(x, fc1, fc2, residual):
     C, hidden = fc1.weight.shape[1], fc1.weight.shape[0]
     M = x.numel() // C
     if (x.shape[-1] != C or tuple(fc2.weight.shape) != (C, hidden) or tuple(residual.shape) != tuple(x.shape) or C != 128 or hidden % 32
-            or SPLIT_MODE != "f16x3"):
+            or _split_mode() != "f16x3"):
         raise RbaHipError("mlp_fused needs C == 128, hidden % 32 == 0, matching fc1 / fc2 and the f16x3 mode")
     _lib.check(lib.rba_swin_mlp_fused_f16x3_f32(_p(x), _p(_cached_planes(fc1, fc1.weight)), _p(fc1.bias), _p(_cached_planes(fc2, fc2.weight)),
                                                 _p(fc2.bias), _p(residual), _p(residual), M, C, hidden, _stream()),
@@ -736,7 +757,7 @@ def mlp_fused_ln(x, norm, fc1, fc2):
     _chk(b, "norm.bias", dim=1)
     C, hidden = fc1.weight.shape[1], fc1.weight.shape[0]
     M = x.numel() // C
-    if (x.shape[-1] != C or tuple(fc2.weight.shape) != (C, hidden) or C != 128 or hidden % 32 or SPLIT_MODE != "f16x3" or g.numel() != C or b.numel() != C):
+    if (x.shape[-1] != C or tuple(fc2.weight.shape) != (C, hidden) or C != 128 or hidden % 32 or _split_mode() != "f16x3" or g.numel() != C or b.numel() != C):
         raise RbaHipError("mlp_fused_ln needs C == 128, hidden % 32 == 0, matching fc1 / fc2 / norm and the f16x3 mode")
     _lib.check(lib.rba_swin_mlp_fused_ln_f16x3_f32(_p(x), _p(g), _p(b), float(eps), _p(_cached_planes(fc1, fc1.weight)), _p(fc1.bias),
                                                    _p(_cached_planes(fc2, fc2.weight)), _p(fc2.bias), M, C, hidden, _stream()),
@@ -746,7 +767,7 @@ def mlp_fused_ln(x, norm, fc1, fc2):
 
 def linear_residual_fused(M, N, K):
     """True when linear(..., residual=r) runs as ONE kernel (the f16x3 GEMM with the residual add in its epilogue)."""
-    return SPLIT_MODE == "f16x3" and split_linear_pays(M, N, K)
+    return _split_mode() == "f16x3" and split_linear_pays(M, N, K)
 
 
 @_hip_op
@@ -833,7 +854,7 @@ GN_MOMENTS = os.environ.get("RBA_GN_MOMENTS", "1") != "0"      # A/B switch (too
 
 
 def _gn_moments_ok(rows_per_image, N, num_groups):
-    return (GN_MOMENTS and SPLIT_MODE == "f16x3" and rows_per_image % 128 == 0 and N % 128 == 0 and N % num_groups == 0
+    return (GN_MOMENTS and _split_mode() == "f16x3" and rows_per_image % 128 == 0 and N % 128 == 0 and N % num_groups == 0
             and (N // num_groups) in (4, 8, 16, 32))
 
 
@@ -947,7 +968,7 @@ def conv3x3_weight(weight, mode=None):
 
 def conv3x3_takes_split(M, N):
     """True when conv3x3_nhwc can read its input as SplitActivations (the pipelined f16x3 kernel: at least 256 tiles of 128 x 128)."""
-    return SPLIT_ACTIVATIONS and SPLIT_MODE == "f16x3" and ((M + 127) // 128) * ((N + 127) // 128) >= 256
+    return SPLIT_ACTIVATIONS and _split_mode() == "f16x3" and ((M + 127) // 128) * ((N + 127) // 128) >= 256
 
 
 @_hip_op
@@ -1012,7 +1033,7 @@ TOKEN_LINEAR = os.environ.get("RBA_TOKEN_LINEAR", "1") != "0"      # A/B switch 
 def token_linear_ok(N, K):
     """Shapes the row-complete token Linear serves (csrc/token_linear.hip): N <= 256 outputs, K a multiple of 32; f16x3 arithmetic only
     (ops.SPLIT_MODE == "bf16x6", the full-range fallback, keeps the library GEMM)."""
-    return TOKEN_LINEAR and SPLIT_MODE == "f16x3" and 1 <= N <= 256 and K >= 32 and K % 32 == 0
+    return TOKEN_LINEAR and _split_mode() == "f16x3" and 1 <= N <= 256 and K >= 32 and K % 32 == 0
 
 
 TOKEN_MAX_ROWS = 8192      # beyond that a 128 x 128-tiled GEMM re-reads the weight far less often than one workgroup per 16 rows does

@@ -308,16 +308,20 @@ def test_split_activations_layout_and_predicate():
         assert img[base] == h[row, k].numpy() and img[base + 512] == l[row, k].numpy()
     un = sa.unpack()
     assert un.shape == (M, K) and float((un - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -21
-    old = ops.SPLIT_MODE
-    try:
+    assert ops.SPLIT_MODE == "f16x3"
+    if True:
         assert ops.linear_takes_split(8192, 2048, 512) and ops.linear_takes_split(8192, 512, 2048)
         assert ops.linear_takes_split(32768, 768, 256) and ops.linear_takes_split(131072, 384, 128)          # from K = 128 since round 3
         assert not ops.linear_takes_split(131072, 384, 96) and not ops.linear_takes_split(256, 1024, 1024)      # K below SPLIT_MIN_K / too few tiles
         assert ops.linear_takes_split(2048, 1024, 1024) and not ops.linear_takes_split(2048, 1024, 160)           # 128 tiles: the sub-tile kernel (K % 64, K >= 256)
-        ops.SPLIT_MODE = "bf16x6"
-        assert not ops.linear_takes_split(8192, 2048, 512)
-    finally:
-        ops.SPLIT_MODE = old
+        with ops.split_mode("bf16x6"):
+            assert ops.SPLIT_MODE == "bf16x6" and not ops.linear_takes_split(8192, 2048, 512)
+            import threading
+            seen = []
+            th = threading.Thread(target=lambda: seen.append(ops.SPLIT_MODE))           # round 5: the mode is per thread -- another thread keeps the default
+            th.start(); th.join()
+            assert seen == ["f16x3"]
+        assert ops.SPLIT_MODE == "f16x3"
 
 
 def test_shape_cache_pins_what_a_capture_reads(monkeypatch):
