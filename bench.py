@@ -710,14 +710,14 @@ def main():
                 # steady-state protocol (round 5): >= 1 s of back-to-back launches of the probed kernel first (the chip settles at the clock it
                 # sustains under dense MFMA load -- a cold probe reads the boost clock of an idle chip), then 200 timed launches with the shader
                 # clock sampled beside them; the reported time is the mean, the spread and the clock go into the record
-                with torch.no_grad():
+                with torch.no_grad(), ClockSampler(local, period=0.05) as gcs:      # (the clock is sampled over the warm-up too: the same back-to-back load)
                     t_w = time.perf_counter()
                     while time.perf_counter() - t_w < 1.0:
                         for _ in range(50):
                             ops.linear(xg, lin, gelu=True, split_out=s_out)
                         torch.cuda.synchronize()
                     evs = []
-                    with ClockSampler(local, period=0.02) as gcs:
+                    if True:
                         for _ in range(200):
                             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                             e0.record(); ops.linear(xg, lin, gelu=True, split_out=s_out); e1.record()
