@@ -40,6 +40,8 @@ SIGNATURES = {
     "rba_swin_bias_fragments_elems": [_i, _i],
     "rba_swin_attn_block_supported": [_i, _i],
     "rba_swin_attn_block_weight_bytes": [_i],
+    "rba_swin_attn_qkv_supported": [_i, _i],
+    "rba_swin_attn_qkv_split_out_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_attn_block_pack_f32": [_vp, _vp, _vp, _i, _vp],
     "rba_swin_attn_block_f32": [_vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i, _i, _i, _i, _i, _i, _vp],
     "rba_swin_bias_fragments_f32": [_vp, _vp, _i, _i, _vp],
@@ -93,7 +95,7 @@ class TokenLinearProblem(ctypes.Structure):
                 ("N", ctypes.c_int), ("ld_out", ctypes.c_int), ("act", ctypes.c_int)]
 
 
-EXPECTED_ABI = 189        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
+EXPECTED_ABI = 190        # rba_hip_version() the argtypes above were written for (include/rba_hip.h)
 
 _lib = None
 

@@ -14,7 +14,7 @@
 
 using namespace rba_k1;
 
-extern "C" int rba_hip_version(void) { return 189; }
+extern "C" int rba_hip_version(void) { return 190; }
 
 // tools / tests only: 1 = rba_reduce_up4_f32 runs the generic (round 1-2) kernel for K = 19 / 20 too, 2 = always the packed VALU kernel (no MFMA form)
 RBA_KNOB(rba_k1_up4_variant, 0);

@@ -61,7 +61,7 @@ constexpr int K7_WS = 12, K7_N = 144, K7_NT = 9, K7_WAVES = 9, K7_PL = K7_N * 64
 __host__ __device__ constexpr int k7_wq_bytes(int C) { return 3 * (C / 32) * 4 * 1024; }       // (part, block, tile, plane) x 1 KiB
 __host__ __device__ constexpr int k7_wp_bytes(int C) { return (C / 16) * 2 * 1024; }            // (tile, plane) x 1 KiB
 __host__ __device__ constexpr int k7_head_bytes(int C) { return k7_wq_bytes(C) + k7_wp_bytes(C); }
-__host__ __device__ constexpr int k7_lds_bytes(int C) { return k7_wq_bytes(C) + 2 * k7_wp_bytes(C) + 4 * K7_PL + K7_N * 4; }
+__host__ __device__ constexpr int k7_lds_bytes(int C, bool proj = true) { return k7_wq_bytes(C) + (proj ? 2 * k7_wp_bytes(C) : 0) + 4 * K7_PL + K7_N * 4; }
 
 // (a, b) -> packed f16 h and the packed f16 residual l = f16((x - h) * SC), SC = 1 (unscaled) or 2048 (swin_window_attn_h3.h)
 template <bool SCALED>
@@ -130,19 +130,19 @@ __device__ __forceinline__ k7_f16x8 k7_lds16(const unsigned char* p) {
   return __builtin_bit_cast(k7_f16x8, *reinterpret_cast<const k7_u32x4*>(p));
 }
 
-template <int C, bool LN2>
+template <int C, bool LN2, bool PROJ = true>
 __global__ __launch_bounds__(64 * K7_WAVES) void swin_attn_block_kernel(
     float* x, float* __restrict__ y2, const float* __restrict__ g1, const float* __restrict__ b1, float eps1,
     const unsigned char* __restrict__ img, const float* __restrict__ qkv_bias, const float* __restrict__ bias_frag,
     const float* __restrict__ proj_bias, const float* __restrict__ g2, const float* __restrict__ b2, float eps2, int H, int W, int Hp,
-    int Wp, int shift, float scale K7_DBG_PARAM) {
+    int Wp, int shift, float scale, void* __restrict__ ofrag K7_DBG_PARAM) {
   K7_STAMP(0);
   constexpr int NH = C / 32, NB = C / 32, NJ = C / 16, NT = K7_NT, PL = K7_PL;
   constexpr int WQ = k7_wq_bytes(C), WP = k7_wp_bytes(C), HEADB = k7_head_bytes(C);
   extern __shared__ __attribute__((aligned(16))) unsigned char k7_lds[];
   unsigned char* const wq = k7_lds;
-  unsigned char* const wp = k7_lds + WQ;                                          // two buffers
-  unsigned char* const Kh = wp + 2 * WP;                                          // + PL: Kl; + 2 PL: Vh; + 3 PL: Vl
+  unsigned char* const wp = k7_lds + WQ;                                          // two buffers (PROJ only)
+  unsigned char* const Kh = wp + (PROJ ? 2 * WP : 0);                             // + PL: Kl; + 2 PL: Vh; + 3 PL: Vl
   int* const rid = reinterpret_cast<int*>(Kh + 4 * PL);
 
   const int lane = threadIdx.x & 63;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * K7_WAVES) void swin_attn_block_kernel(
   auto issue_dma = [&](int h) {
     const unsigned char* src = img + (int64_t)h * HEADB + lane * 16;
     unsigned char* pdst = wp + (h & 1) * WP;
-    constexpr int NPIECE = HEADB / 1024, NQ = WQ / 1024;
+    constexpr int NQ = WQ / 1024, NPIECE = PROJ ? HEADB / 1024 : NQ;           // (without PROJ the proj fragments of the image stay where they are)
 #pragma unroll
     for (int p0 = 0; p0 < NPIECE; p0 += K7_WAVES) {
       const int p = p0 + wave;
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(64 * K7_WAVES) void swin_attn_block_kernel(
   }
 
   K7_STAMP(1);                                                                   // norm1 + split done
-  k7_f32x4 acc[NJ];                                                              // proj output of the strip, all heads: tile j rows 4 kk + r
+  k7_f32x4 acc[PROJ ? NJ : 1];                                                   // proj output of the strip, all heads: tile j rows 4 kk + r
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) acc[j] = (k7_f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < (PROJ ? NJ : 1); ++j) acc[j] = (k7_f32x4){0.f, 0.f, 0.f, 0.f};
 
   // K fragment of key tile c: key c * 16 + l15, chunk kk; V transposing read of key tile c, d tile dt (swin_window_attn_h3.h)
   const int kperm = (0x1320 >> (4 * ((l15 >> 2) & 3))) & 3;                       // P = {0, 2, 3, 1}[(key >> 2) & 3]; key = 16 w + l15
@@ -389,22 +389,41 @@ __global__ __launch_bounds__(64 * K7_WAVES) void swin_attn_block_kernel(
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[4 * dt + e] = fmaf(Ol[dt][e], 0.00048828125f, Om[dt][e]) * inv;
-    k7_f16x8 oh, ol;
-    k7_split8<true>(o, oh, ol);
-    const unsigned char* pf = wp + (h & 1) * WP + lane * 16;
+    if (PROJ) {
+      k7_f16x8 oh, ol;
+      k7_split8<true>(o, oh, ol);
+      const unsigned char* pf = wp + (h & 1) * WP + lane * 16;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const k7_f16x8 wh = k7_lds16(pf + j * 2048), wl = k7_lds16(pf + j * 2048 + 1024);
-      k7_f32x4 lo = {0.f, 0.f, 0.f, 0.f};
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, oh, acc[j], 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ol, lo, 0, 0, 0);
-      lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, oh, lo, 0, 0, 0);
+      for (int j = 0; j < (PROJ ? NJ : 0); ++j) {
+        const k7_f16x8 wh = k7_lds16(pf + j * 2048), wl = k7_lds16(pf + j * 2048 + 1024);
+        k7_f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, oh, acc[j], 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ol, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, oh, lo, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(lo[e], 0.00048828125f, acc[j][e]);
+        for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(lo[e], 0.00048828125f, acc[j][e]);
+      }
+    } else {
+      // attention output of (token, head) as the proj Linear's split A operand (split_linear_h3.h "PRE"; K5's split_out epilogue): channel
+      // c = 32 h + 16 dt + 4 kk + r -> block h, piece (g = kk / 2, h | l), k-half dt; the 8-channel piece is completed by the lane of the
+      // neighbouring kk (lane ^ 16): v_permlane16_swap(h, l) leaves an even-kk lane with (its h, the partner's h), an odd one with (the partner's l, its l)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        uint32_t h0, l0, h1, l1;
+        rba_split_f16x2(o[4 * dt], o[4 * dt + 1], h0, l0);
+        rba_split_f16x2(o[4 * dt + 2], o[4 * dt + 3], h1, l1);
+        const auto p0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false), p1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
+        const rba_u32x4 piece = {p0[0], p1[0], p0[1], p1[1]};
+        if (valid) {
+          char* dst = reinterpret_cast<char*>(ofrag) + ((row >> 5) * NH + h) * 4096 + ((kk >> 1) * 2 + (kk & 1)) * 1024 + (dt * 32 + (int)(row & 31)) * 16;
+          *reinterpret_cast<rba_u32x4*>(dst) = piece;
+        }
+      }
     }
     K7_STAMP(6 + 5 * h);                                                         // proj done
   }
 
+  if constexpr (PROJ) {
   // ---- x = (x + out) + proj.bias; tile j rows 4 kk + e <-> channel 32 (j / 2) + 8 kk + 4 (j % 2) + e: the layout of the first load
   float* xr = x + row * C + 8 * kk;
   float sum = 0.f;
@@ -442,6 +461,7 @@ __global__ __launch_bounds__(64 * K7_WAVES) void swin_attn_block_kernel(
       if (valid) *reinterpret_cast<k7_f32x4*>(yr + ch) = yv;
     }
   }
+  }  // PROJ
   K7_STAMP(31);
 }
 

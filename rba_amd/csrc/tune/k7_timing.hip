@@ -18,6 +18,6 @@ extern "C" int rba_k7_timing(float* x, float* y2, const float* g1, const float* 
   hipError_t e = hipFuncSetAttribute((const void*)swin_attn_block_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((swin_attn_block_kernel<128, true>), grid, block, shm, (hipStream_t)stream, x, y2, g1, b1, eps1,
-                     reinterpret_cast<const unsigned char*>(img), qkv_bias, bias_frag, proj_bias, g2, b2, eps2, H, W, Hp, Wp, shift, scale, dbg);
+                     reinterpret_cast<const unsigned char*>(img), qkv_bias, bias_frag, proj_bias, g2, b2, eps2, H, W, Hp, Wp, shift, scale, nullptr, dbg);
   return (int)hipGetLastError();
 }

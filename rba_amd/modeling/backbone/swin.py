@@ -96,6 +96,18 @@ class SwinTransformerBlock(nn.Module):
                 return ops.linear(y, self.mlp.fc2, residual=x), None
             y = ops.linear(y, self.mlp.fc1, gelu=True)
             return x, (ops.linear(y, self.mlp.fc2, use_bias=False), self.mlp.fc2.bias)
+        if (x.is_cuda and x.dim() == 3 and pending is None and ops.swin_attn_qkv_ok(C, self.num_heads, self.window_size)
+                and ops.linear_residual_fused(M, C, C) and ops.linear_takes_split(M, C, C)):
+            # K7 without proj (C = 256, Swin-B stage 2): norm1 -> qkv -> window attention in ONE kernel, its output the proj GEMM's split operand; the residual
+            # add rides in that GEMM's epilogue as before
+            x = x.contiguous()
+            y = ops.swin_attn_qkv(x, (self.norm1.weight, self.norm1.bias, self.norm1.eps), a.block_image(), a.qkv.bias, a.gathered_bias()[1], H, W,
+                                  self.window_size, self.shift_size)
+            x = ops.linear(y, a.proj, residual=x)
+            hidden = self.mlp.fc1.out_features
+            y = ops.add_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, frag=ops.linear_takes_split(M, hidden, C))[1]
+            y = ops.linear(y, self.mlp.fc1, gelu=True, split_out=ops.linear_takes_split(M, C, hidden))
+            return ops.linear(y, self.mlp.fc2, residual=x), None
         # where the consumer is the pipelined f16x3 GEMM, the LayerNorm hands its output over already split and in MFMA fragment
         # order (ops.SplitActivations): one split per element instead of one per column tile, contiguous operand loads
         x, y = ops.add_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, t, tb, inplace_sum=True,

@@ -306,6 +306,38 @@ def swin_attn_block_ok(C, num_heads, window_size):
             and bool(_lib.load().rba_swin_attn_block_supported(int(C), int(window_size))))
 
 
+def swin_attn_qkv_ok(C, num_heads, window_size):
+    """True when swin_attn_qkv() has a kernel for this geometry (K7 without proj: C = 128 / 256, head_dim 32, 12 x 12 windows, f16x3 mode)."""
+    return (SWIN_ATTN_FUSED and _split_mode() == "f16x3" and num_heads * 32 == C
+            and bool(_lib.load().rba_swin_attn_qkv_supported(int(C), int(window_size))))
+
+
+@_hip_op
+def swin_attn_qkv(x, norm1, image, qkv_bias, bias_frag, H, W, window_size, shift):
+    """K7 without proj: window_attention(qkv(norm1(x))) before the output projection (swin.py:235-168), returned as SplitActivations -- the proj Linear's A
+    operand: ``x = ops.linear(y, attn.proj, residual=x)`` finishes the half block.  x [B, H*W, C] is only read.  Check swin_attn_qkv_ok first."""
+    lib = _lib.load()
+    _chk(x, "x", dim=3)
+    B, L, C = x.shape
+    if L != H * W or not lib.rba_swin_attn_qkv_supported(int(C), int(window_size)):
+        raise RbaHipError("swin_attn_qkv: check swin_attn_qkv_ok(C, num_heads, window_size) first; x must be [B, H*W, C]")
+    g1, b1, eps1 = norm1
+    for t, name in ((g1, "norm1.weight"), (b1, "norm1.bias")):
+        _chk(t, name, dim=1)
+        if t.numel() != C:
+            raise RbaHipError(f"{name} must have C elements")
+    _chk(qkv_bias, "qkv_bias", dim=1)
+    _chk(bias_frag, "bias_frag", dim=1)
+    _chk(image, "image", dtype=torch.uint8, dim=1)
+    if (qkv_bias.numel() != 3 * C or image.numel() != lib.rba_swin_attn_block_weight_bytes(int(C))
+            or bias_frag.numel() != lib.rba_swin_bias_fragments_elems(C // 32, int(window_size))):
+        raise RbaHipError("qkv_bias must be [3C]; image / bias_frag must come from swin_attn_block_weights / swin_bias_fragments")
+    out = SplitActivations.empty((B, L, C), x.device)
+    _lib.check(lib.rba_swin_attn_qkv_split_out_f32(_p(x), _p(out.data), _p(g1), _p(b1), float(eps1), _p(image), _p(qkv_bias), _p(bias_frag), B, H, W, C,
+                                                   int(window_size), int(shift), _stream()), "rba_swin_attn_qkv_split_out_f32")
+    return out
+
+
 @_hip_op
 def swin_attn_block_weights(qkv_weight, proj_weight):
     """qkv.weight [3C, C] + proj.weight [C, C] -> K7's per-head image of MFMA operand fragments (uint8; once per weight load)."""

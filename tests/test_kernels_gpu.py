@@ -480,6 +480,36 @@ def test_k7_swin_attn_block(ops, B, H, W, shift):
         ops.swin_attn_block(dev(x[:, :, :96].contiguous()), d1, img, dev(qkv_b), frag, dev(proj_b), H, W, ws, shift)
 
 
+@pytest.mark.parametrize("C,B,H,W,shift", [(256, 1, 24, 36, 0), (256, 2, 30, 41, 6), (128, 1, 13, 24, 6), (256, 1, 128, 256, 6)])
+def test_k7_attention_only_split_output(ops, C, B, H, W, shift):
+    """K7 without proj (Swin-B stage 2, C = 256): norm1 -> qkv -> window attention as one kernel whose output is the proj Linear's split operand --
+    against LN -> K6 -> K5(split_out) of this library (same arithmetic family) and, through the proj GEMM, against the float64 half block."""
+    nH, ws = C // 32, 12
+    assert ops.swin_attn_qkv_ok(C, nH, ws)
+    g = torch.Generator().manual_seed(C + H * W + shift)
+    x = torch.randn(B, H * W, C, generator=g) * 1.5 + 0.3
+    n1 = (torch.randn(C, generator=g) * 0.3 + 1.0, torch.randn(C, generator=g) * 0.2, 1e-5)
+    n2 = (torch.ones(C), torch.zeros(C), 1e-5)
+    qkv_w, qkv_b = torch.randn(3 * C, C, generator=g) * C ** -0.5, torch.randn(3 * C, generator=g) * 0.2
+    proj_w, proj_b = torch.randn(C, C, generator=g) * C ** -0.5, torch.randn(C, generator=g) * 0.2
+    table = torch.randn((2 * ws - 1) ** 2, nH, generator=g) * 0.5
+    N = ws * ws
+    bias = table[ref_ops.relative_position_index(ws).view(-1)].view(N, N, nH).permute(2, 0, 1).contiguous()
+    frag = ops.swin_bias_fragments(dev(bias), ws)
+    img = ops.swin_attn_block_weights(dev(qkv_w), dev(proj_w))
+    d1 = (dev(n1[0]), dev(n1[1]), n1[2])
+    xg = dev(x)
+    so = ops.swin_attn_qkv(xg, d1, img, dev(qkv_b), frag, H, W, ws, shift)
+    assert torch.equal(xg.cpu(), x) and so.shape == (B, H * W, C)                      # x is only read
+    y1 = ops.add_layer_norm(dev(x), d1[0], d1[1], d1[2])[1]
+    qkv = F.linear(y1, dev(qkv_w), dev(qkv_b))
+    att = ops.swin_window_attn(qkv, dev(qkv_b), dev(bias), H, W, nH, ws, shift, bias_frag=frag)
+    assert maxerr(so.unpack(), att.double()) < 1e-5
+    want_x, _ = _k7_reference(x, n1, qkv_w, qkv_b, proj_w, proj_b, table, H, W, ws, nH, shift, n2)
+    got = dev(x) + F.linear(so.unpack(), dev(proj_w), dev(proj_b))
+    assert maxerr(got, want_x) < 3e-5
+
+
 def test_k7_f16_range_is_loud(ops):
     """like K5 / K6: a value beyond f16's range gives NaN rows, never a silently wrong finite result"""
     C, nH, ws, H, W = 128, 4, 12, 12, 24

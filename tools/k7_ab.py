@@ -35,6 +35,27 @@ def timed(fn, reps=7, inner=10):
 for (H, W, nH) in ((256, 512, 4), (128, 256, 8), (64, 128, 16)):
     C = nH * 32
     if not ops.swin_attn_block_ok(C, nH, ws):
+        if ops.swin_attn_qkv_ok(C, nH, ws):                     # attention-only form (no proj): against add_layer_norm -> K6 qkv -> K5
+            torch.manual_seed(0)
+            for shift in (0, 6):
+                blk = SwinTransformerBlock(C, nH, ws, shift, 4.0).cuda().eval()
+                x = torch.randn(B, H * W, C, device="cuda")
+                a = blk.attn
+                bias, frag = a.gathered_bias()
+                img = a.block_image()
+                n1 = (blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+                M = B * H * W
+
+                def fq():
+                    return ops.swin_attn_qkv(x, n1, img, a.qkv.bias, frag, H, W, ws, shift)
+
+                def uq():
+                    y = ops.add_layer_norm(x, *n1, frag=ops.linear_takes_split(M, 3 * C, C))[1]
+                    return ops.swin_window_attn(ops.linear(y, a.qkv), a.qkv.bias, bias, H, W, nH, ws, shift, bias_frag=frag, split_out=True)
+                with torch.no_grad():
+                    e = (fq().unpack() - uq().unpack()).abs().max().item()
+                    tf, tu = timed(fq), timed(uq)
+                print(f"B={B} {H}x{W} C={C} shift={shift}: attention-only fused {tf:7.1f} us   LN + qkv + K5 {tu:7.1f} us   ({tu / tf:.2f}x)   max diff {e:.2e}", flush=True)
         continue
     torch.manual_seed(0)
     for shift in (0, 6):
