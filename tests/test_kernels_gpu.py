@@ -510,6 +510,37 @@ def test_k7_attention_only_split_output(ops, C, B, H, W, shift):
     assert maxerr(got, want_x) < 3e-5
 
 
+def test_k7_soak_bit_stable_across_launches_and_streams(ops):
+    """K7 shares LDS buffers between waves under two barriers per head and streams its weights with LDS-DMA: 3 x 100 launches of both forms, alternating over
+    three HIP streams that run concurrently, must reproduce the first result bit for bit (no floating-point atomics, fixed summation orders)."""
+    ws = 12
+    g = torch.Generator().manual_seed(99)
+    for C, H, W, shift in ((128, 60, 90, 6), (256, 40, 70, 6)):
+        nH = C // 32
+        x0 = dev(torch.randn(1, H * W, C, generator=g))
+        n1 = (dev(torch.randn(C, generator=g) * 0.3 + 1.0), dev(torch.randn(C, generator=g) * 0.2), 1e-5)
+        qkv_w, qkv_b = dev(torch.randn(3 * C, C, generator=g) * C ** -0.5), dev(torch.randn(3 * C, generator=g) * 0.2)
+        proj_w, proj_b = dev(torch.randn(C, C, generator=g) * C ** -0.5), dev(torch.randn(C, generator=g) * 0.2)
+        frag = ops.swin_bias_fragments(dev(torch.randn(nH, ws * ws, ws * ws, generator=g) * 0.5), ws)
+        img = ops.swin_attn_block_weights(qkv_w, proj_w)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        outs = [[] for _ in streams]
+        for it in range(100):
+            for si, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    if C == 128:
+                        xx = x0.clone()
+                        ops.swin_attn_block(xx, n1, img, qkv_b, frag, proj_b, H, W, ws, shift)
+                        outs[si].append(xx)
+                    else:
+                        outs[si].append(ops.swin_attn_qkv(x0, n1, img, qkv_b, frag, H, W, ws, shift).data)
+        torch.cuda.synchronize()
+        first = outs[0][0]
+        bad = sum(int(not torch.equal(o, first)) for per in outs for o in per)
+        assert bad == 0, (C, bad)
+
+
 def test_k7_f16_range_is_loud(ops):
     """like K5 / K6: a value beyond f16's range gives NaN rows, never a silently wrong finite result"""
     C, nH, ws, H, W = 128, 4, 12, 12, 24
