@@ -244,7 +244,7 @@ int rba_swin_attn_block_f32(float* x, float* y2, const float* norm1_weight, cons
                             const float* norm2_bias, float eps2, int B, int H, int W, int C, int ws, int shift, void* stream);
 /* K7, attention only: the same kernel without proj / residual -- norm1 -> qkv -> (shifted-)window attention, its output written as the proj Linear's split
  * image (rba_split_linear_f16x3_frag_f32 reads it; layout of rba_swin_window_attn_split_out_f32): the qkv tensor and norm1's output never exist.  For the
- * widths whose proj accumulators do not fit beside the resident rows (C = 256: Swin-B stage 2); x is only read.  out_frag: ceil(B H W / 32) * 32 * C * 4 bytes. */
+ * widths whose proj accumulators do not fit beside the resident rows (C = 256: Swin-B stage 2; C = 192: Swin-L stage 1); x is only read.  out_frag: ceil(B H W / 32) * 32 * C * 4 bytes. */
 int rba_swin_attn_qkv_supported(int C, int ws);
 int rba_swin_attn_qkv_split_out_f32(const float* x, void* out_frag, const float* norm1_weight, const float* norm1_bias, float eps1,
                                     const void* weight_image, const float* qkv_bias, const float* bias_frag, int B, int H, int W, int C, int ws,

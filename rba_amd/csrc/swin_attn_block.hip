@@ -61,7 +61,7 @@ int k7_launch_qkv(const float* x, void* out_frag, const float* g1, const float* 
 }  // namespace
 
 extern "C" int rba_swin_attn_block_supported(int C, int ws) { return (C == 128 && ws == K7_WS) ? 1 : 0; }
-extern "C" int rba_swin_attn_qkv_supported(int C, int ws) { return ((C == 128 || C == 256) && ws == K7_WS) ? 1 : 0; }
+extern "C" int rba_swin_attn_qkv_supported(int C, int ws) { return ((C == 128 || C == 192 || C == 256) && ws == K7_WS) ? 1 : 0; }
 
 extern "C" int rba_swin_attn_qkv_split_out_f32(const float* x, void* out_frag, const float* norm1_weight, const float* norm1_bias, float eps1,
                                                const void* weight_image, const float* qkv_bias, const float* bias_frag, int B, int H, int W, int C, int ws,
@@ -73,6 +73,7 @@ extern "C" int rba_swin_attn_qkv_split_out_f32(const float* x, void* out_frag, c
                   (uintptr_t)bias_frag) & 15) == 0);
   rba_begin();
   hipStream_t st = (hipStream_t)stream;
+  if (C == 192) return k7_launch_qkv<192>(x, out_frag, norm1_weight, norm1_bias, eps1, weight_image, qkv_bias, bias_frag, B, H, W, shift, st);   // Swin-L stage 1
   if (C == 256) return k7_launch_qkv<256>(x, out_frag, norm1_weight, norm1_bias, eps1, weight_image, qkv_bias, bias_frag, B, H, W, shift, st);
   return k7_launch_qkv<128>(x, out_frag, norm1_weight, norm1_bias, eps1, weight_image, qkv_bias, bias_frag, B, H, W, shift, st);
 }

@@ -480,7 +480,7 @@ def test_k7_swin_attn_block(ops, B, H, W, shift):
         ops.swin_attn_block(dev(x[:, :, :96].contiguous()), d1, img, dev(qkv_b), frag, dev(proj_b), H, W, ws, shift)
 
 
-@pytest.mark.parametrize("C,B,H,W,shift", [(256, 1, 24, 36, 0), (256, 2, 30, 41, 6), (128, 1, 13, 24, 6), (256, 1, 128, 256, 6)])
+@pytest.mark.parametrize("C,B,H,W,shift", [(256, 1, 24, 36, 0), (256, 2, 30, 41, 6), (128, 1, 13, 24, 6), (256, 1, 128, 256, 6), (192, 1, 30, 41, 6), (192, 2, 24, 24, 0)])
 def test_k7_attention_only_split_output(ops, C, B, H, W, shift):
     """K7 without proj (Swin-B stage 2, C = 256): norm1 -> qkv -> window attention as one kernel whose output is the proj Linear's split operand --
     against LN -> K6 -> K5(split_out) of this library (same arithmetic family) and, through the proj GEMM, against the float64 half block."""
