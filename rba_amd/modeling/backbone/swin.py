@@ -4,7 +4,9 @@ Same parameter tree (hence state-dict keys) as the reference's ``D2SwinTransform
 (mask2former/modeling/backbone/swin.py:498-770) but a different dataflow: the token map stays [B, H*W, C]
 for the whole stage; the zero-pad to a multiple of the window, the cyclic shift, window partition / reverse,
 relative-position bias, shift mask, softmax and P@V of a block are ONE HIP kernel (``ops.swin_window_attn``,
-K5) reading the un-padded qkv tensor; dense projections are MFMA GEMMs through rocBLAS/hipBLASLt.
+K5) reading the un-padded qkv tensor; dense projections are the repository's f16x3 MFMA GEMMs (K6).  Round 5: where K7 has a kernel
+(``ops.swin_attn_block``: C = 128; ``ops.swin_attn_qkv``: C = 128 / 192 / 256) the attention half of a block -- norm1, qkv, attention[, proj, residual] --
+is one launch per block, and the C = 128 MLP computes norm2 itself (``ops.mlp_fused_ln``).
 """
 import torch
 import torch.nn as nn

@@ -1,6 +1,6 @@
 """MSDeformAttn pixel decoder, inference only (reference: pixel_decoder/msdeformattn.py:32-367).
-Same parameter names; K2 (deformable attention) and the bilinear FPN top-down sum are HIP kernels, 1x1/3x3
-convolutions and the encoder FFN are MFMA GEMMs/convs through rocBLAS/MIOpen."""
+Same parameter names; K2 (deformable attention) and the bilinear FPN top-down sum are HIP kernels, the 1x1 / 3x3
+convolutions and the encoder FFN are this library's split-precision MFMA GEMMs / implicit GEMM (K6, conv3x3.hip) -- no rocBLAS / MIOpen call on any path (round 5)."""
 import os
 
 import torch

@@ -664,7 +664,7 @@ TILES_MIN = 64
 def split_linear_pays(M, N, K, gelu=False):
     """Where the bf16x6 kernel beats hipBLASLt's fp32 GEMM on MI355X (tools/gemm_v4_sweep.py, profiles/r02_split_linear.txt):
     1.3-1.7x whenever there are at least 64 tiles of 128 x 128 (below 256 tiles the library switches to 128 x 64 tiles so that
-    every CU still gets work) and K >= 64.  Smaller problems (the single-level encoder at one image: 32 tiles) stay on hipBLASLt."""
+    every CU still gets work) and K >= 64.  Since round 5 this is a statement about speed only: linear() runs the library's own kernels for every shape."""
     if not split_linear_supported(N, K) or K < 64:
         return False
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
