@@ -39,12 +39,10 @@ __device__ __forceinline__ f32x2 rba_sigmoid2(f32x2 x) {
 // wrong score.  Arithmetic form: max(x, 0) + (x - x); x - x is +0 for every finite x and NaN for NaN (and for +-inf, which no kernel of this library
 // produces legitimately: an infinity is an overflow and becomes just as loud).  Two VALU instructions, no lane mask.
 //
-// Why not `x < 0 ? 0 : x`: round 5 tried it.  Inside the GroupNorm fold of split_linear_h3l_kernel (sixteen selects between the LDS stores and the MFMAs of
-// a k block) every compare + select form -- also `x < floor ? floor : x` with no scalar instruction touching VCC -- produced wrong values in rows of lanes
-// 48-63 of a run-to-run varying set of tiles on MI355X, with the flag off as well as on, while v_max_f32 and an integer-mask form were exact in every
-// run (tools/gnfold_probe.py, profiles/r05_gnfold_select.txt).  The cause was not found: the emitted ISA respects every wait-state rule this repository knows
-// (tools/isa_hazards.py), and neither the data nor the address registers of a ds_write_b128 can be rewritten early (tools/micro/ds_write_war.hip).  Until it
-// is, no kernel of this library selects on VCC next to its MFMAs where an arithmetic form exists.
+// Why not `x < 0 ? 0 : x`: no reason left.  Round 5 first blamed compare + select forms for wrong rows in the GroupNorm fold of split_linear_h3l_kernel; the
+// ReLU's form only moved the compiler's register allocation.  What went wrong was one packed multiply of that fold, `v_pk_mul_f32 ... op_sel:[0,1]` (cross select
+// on source 1), found by editing the failing build's assembly one instruction at a time (tools/gnf_asm_probe.py, profiles/r05_gnfold_select.txt,
+// csrc/split_linear_gnf.hip).  The arithmetic form stays: it is two instructions and needs no lane mask.
 __device__ __forceinline__ float rba_relu(float x) { return fmaxf(x, 0.f) + (x - x); }
 // The same under a run-time (workgroup-uniform) switch: floor = rba_relu_floor(on) once, then rba_clamp_below(x, floor) per value.
 __device__ __forceinline__ float rba_relu_floor(bool on) { return on ? 0.f : -INFINITY; }

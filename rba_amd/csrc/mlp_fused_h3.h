@@ -55,21 +55,27 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_h3_kernel(const float* X, co
 #pragma unroll
       for (int q = 0; q < 4; ++q) xr[b][q] = *reinterpret_cast<const f32x4*>(xp + b * 128 + q * 16);
     if (LNIN) {                                                                    // lane: channels 32 b + 16 lh + 4 q .. + 3 of row l31
-      float sum = 0.f;
+      // The sums run over (even, odd) channel PAIRS and are folded once at the end: written as (x + y) + (z + w) per quad the compiler emits the horizontal
+      // packed add `v_pk_add_f32 v, v, v op_sel:[0,1] op_sel_hi:[1,0]` -- a cross select on source 1, the instruction form that went wrong in the
+      // GroupNorm fold (split_linear_gnf.hip); tests/test_host_cpu.py keeps the library free of it.
+      f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < NB1; ++b)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sum += (xr[b][q].x + xr[b][q].y) + (xr[b][q].z + xr[b][q].w);
+        for (int q = 0; q < 4; ++q) sum2 += (f32x2){xr[b][q].x, xr[b][q].y} + (f32x2){xr[b][q].z, xr[b][q].w};
+      float sum = sum2.x + sum2.y;
       sum += __shfl_xor(sum, 32, 64);
       const float mean = sum / (float)K1;
-      float sq = 0.f;
+      f32x2 sq2 = {0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < NB1; ++b)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 d = xr[b][q] - mean;
-          sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+          const f32x2 d01 = {d.x, d.y}, d23 = {d.z, d.w};
+          sq2 += d01 * d01 + d23 * d23;
         }
+      float sq = sq2.x + sq2.y;
       sq += __shfl_xor(sq, 32, 64);
       const float rstd = 1.0f / sqrtf(sq / (float)K1 + ln.eps);
       const char* gp = reinterpret_cast<const char*>(ln.gamma) + 64 * lh;

@@ -288,22 +288,4 @@ extern "C" int rba_split_linear_nchw_out_f16x3_f32(const float* x, const void* w
   return rba_launch_status();
 }
 
-// The same projection reading a RAW convolution output: GroupNorm(G groups, statistics mr [B][G][2] from rba_group_norm_nhwc_stats_f32) (+ ReLU) is applied
-// while the rows are staged -- `mask_features(output_conv(y))` (pixel_decoder/msdeformattn.py:357-362) without ever writing the normalised 1/4-resolution map
-// (268 MB of traffic at 1024 x 2048).  Same arithmetic as rba_group_norm_nhwc_f32 followed by the entry above: bit-identical.  rows_per_image % 128 == 0.
-extern "C" int rba_split_linear_nchw_out_gn_f16x3_f32(const float* x, const float* mr, const float* gamma, const float* beta, int G, int relu,
-                                                      const void* weight_packed, const float* bias, float* out, int64_t M, int N, int K,
-                                                      int rows_per_image, void* stream) {
-  RBA_CHECK_ARG(M >= 0 && N >= 1 && K >= 32 && (K % 32) == 0 && rows_per_image >= 1 && G >= 1 && (K % G) == 0 && ((K / G) % 4) == 0);
-  if (M == 0) return 0;
-  RBA_CHECK_ARG(x && mr && gamma && beta && weight_packed && out && (M % rows_per_image) == 0 && (rows_per_image % 128) == 0 && M < (int64_t)1 << 31);
-  RBA_CHECK_ARG((((uintptr_t)x | (uintptr_t)weight_packed | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
-  rba_begin();
-  const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(weight_packed);
-  const GnFold gn{mr, gamma, beta, G, K / G, relu ? 1 : 0};
-  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-  const int rc = (tiles128 >= 160 || N <= 64) ? launch_h3l_nchw_gn<4>(x, gn, wp, bias, out, M, N, K, rows_per_image, (hipStream_t)stream)
-                                              : launch_h3l_nchw_gn<2>(x, gn, wp, bias, out, M, N, K, rows_per_image, (hipStream_t)stream);
-  if (rc) return rc;
-  return rba_launch_status();
-}
+// (rba_split_linear_nchw_out_gn_f16x3_f32, the GroupNorm-folded form, lives in split_linear_gnf.hip: a translation unit compiled WITHOUT packed fp32 instructions)

@@ -500,15 +500,18 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
   };
   // GNF: the normalised rows (GroupNorm [+ ReLU] applied to the block in registers) go to LDS instead of the raw ones
   f32x4 xst[4];
+#if defined(RBA_GNF_DEBUG)
+  int gnf_blk = 0;
+#endif
   auto lstore = [&](u32x4_t* buf) {
 #pragma unroll
     for (int q = 0; q < UPL; ++q) buf[tid + 256 * q] = wr[q];
     if (GNF) {
       f32x4 a, b;
       // NaN must stay NaN through the ReLU (common.h: rba_relu): fmaxf(NaN, 0) is 0.  A NaN / inf anywhere in a group makes the group's statistics NaN,
-      // so `poison` (0, or NaN when they are) added after the max keeps every value of such a group loud -- one v_add per value, and the normalised value
-      // is used ONCE: the forms that read it twice (`y < f ? f : y`, `max(y, f) + (y - y)`) went wrong in this loop on MI355X for reasons round 5 did not
-      // find (tools/gnfold_probe.py, profiles/r05_gnfold_select.txt), while max, max + add and an integer mask are exact in every run.
+      // so `poison` (0, or NaN when they are) added after the max keeps every value of such a group loud -- one v_add per value.
+      // This arithmetic is compiled WITHOUT packed fp32 in the product (split_linear_gnf.hip): as `v_pk_mul_f32 a[0:1], gamma[0:1], (mean, rstd) op_sel:[0,1]`
+      // the coefficient a came out 0 in lanes 48-63 now and then (profiles/r05_gnfold_select.txt).
       const float relu_floor = gn.relu ? 0.f : -INFINITY;
       const float poison = (grstd - grstd) + (gmean - gmean);
 #pragma unroll
@@ -519,7 +522,27 @@ __global__ __launch_bounds__(256, 2) void split_linear_h3l_kernel(const float* _
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xst[q][i] = fmaxf(fmaf(xr[q][i], a[i], b[i]), relu_floor) + poison;
+        for (int i = 0; i < 4; ++i) {
+#if defined(RBA_GNF_FORM) && RBA_GNF_FORM == 1                                        // tools (tune/gnf_forms.hip): the form that goes wrong, for the probe
+          const float y = fmaf(xr[q][i], a[i], b[i]);
+          xst[q][i] = fmaxf(y, relu_floor) + (y - y);
+#else
+          xst[q][i] = fmaxf(fmaf(xr[q][i], a[i], b[i]), relu_floor) + poison;
+#endif
+        }
+#if defined(RBA_GNF_DEBUG)
+      if (dbg && gnf_blk < NB) {                                                       // [tile][block][thread][40]: xr (16), xst (16), a (4), b (4)
+        float* d = reinterpret_cast<float*>(dbg) + (((int64_t)(mt * NT + nt) * NB + gnf_blk) * 256 + tid) * 40;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<f32x4*>(d + 4 * q) = xr[q];
+          *reinterpret_cast<f32x4*>(d + 16 + 4 * q) = xst[q];
+        }
+        *reinterpret_cast<f32x4*>(d + 32) = a;
+        *reinterpret_cast<f32x4*>(d + 36) = b;
+      }
+      ++gnf_blk;
+#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) buf[xdst + 256 * q] = __builtin_bit_cast(u32x4_t, xst[q]);
     } else {

@@ -402,6 +402,9 @@ def test_emitted_isa_has_no_unfenced_16bit_destination_hazards():
     assert r["code_objects"] >= 15 and r["mix"] > 3000, r["code_objects"]      # the scan saw the library's kernels (3 452 v_fma_mix* in round 4)
     assert not r["D"], r["D"][:3]
     assert not r["T"], r["T"][:3]
+    # round 5: no packed fp32 instruction with the cross select on source 1 (`op_sel:[x,1]`): the form that produced zero products in the GroupNorm fold
+    # (csrc/split_linear_gnf.hip, profiles/r05_gnfold_select.txt)
+    assert not r["P"], r["P"][:3]
     # the scanner itself: the round-3 pattern must be flagged, the fenced forms must pass
     mk = lambda *ins: [("label", "k")] + [(i, "k") for i in ins]
     lo, hi = "v_fma_mixlo_f16 v24, v20, v9, v11 op_sel_hi:[1,0,0]", "v_fma_mixhi_f16 v24, v20, v9, v14 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -412,6 +415,10 @@ def test_emitted_isa_has_no_unfenced_16bit_destination_hazards():
     assert not isa_hazards.scan(mk(hi, "ds_write_b128 v2, v[24:27]"))["D"]        # not a VALU reader
     assert len(isa_hazards.scan(mk("v_rcp_f32_e32 v4, v1", "v_mul_f32_e32 v5, v4, v4"))["T"]) == 1
     assert not isa_hazards.scan(mk("v_rcp_f32_e32 v4, v1", "v_exp_f32_e32 v5, v4"))["T"]
+    assert len(isa_hazards.scan(mk("v_pk_mul_f32 v[166:167], v[130:131], v[182:183] op_sel:[0,1]"))["P"]) == 1
+    assert len(isa_hazards.scan(mk("v_pk_add_f32 v[68:69], v[68:69], v[68:69] op_sel:[0,1] op_sel_hi:[1,0]"))["P"]) == 1
+    assert not isa_hazards.scan(mk("v_pk_mul_f32 v[166:167], v[182:183], v[130:131] op_sel:[1,0]", "v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[0,1]",
+                                   "v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[0,0,1] op_sel_hi:[1,1,0]"))["P"]
 
 
 def test_bench_names_its_workload_and_configs2_flag():

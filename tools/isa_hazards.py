@@ -9,8 +9,14 @@ the text of an `asm` statement, so a hand-written instruction can end up back to
      register count as readers (they keep the other half).  Round 3's rba_reduce_up4_mx_kernel had 40 of these (mixlo, mixhi back to back).
   T  a transcendental (v_rcp/v_rsq/v_sqrt/v_exp/v_log/v_sin/v_cos) followed IMMEDIATELY by a non-transcendental VALU that reads its result.
 
+  P  (round 5, not a documented rule: an observation) a packed fp32 VALU (v_pk_mul/add/fma_f32) whose LOW lane takes the HIGH register of source 1 (`op_sel:[x,1,...]`).
+     In the GroupNorm-folded projection `v_pk_mul_f32 vD, v_gamma, v_(mean,rstd) op_sel:[0,1]` gave a LOW product of exactly 0 in lanes 48-63 a few hundred times per
+     launch; the same products as v_mul_f32, as a packed multiply on a broadcast pair, or with the select on source 0 (`op_sel:[1,0]`) never did
+     (tools/gnf_asm_probe.py, profiles/r05_gnfold_select.txt).  The library is kept free of the form: split_linear_gnf.hip is compiled without packed fp32, the one other
+     producer (the LayerNorm prologue of mlp_fused_h3.h) sums channel pairs instead of quads.
+
 Usage: python tools/isa_hazards.py [lib.so | file.o ...]   (default: rba_amd/csrc/librba_hip.so); exit status 1 if anything is found.
-`scan_library(path)` returns {"code_objects": n, "mix": n, "D": [...], "T": [...]} for tests/test_host_cpu.py."""
+`scan_library(path)` returns {"code_objects": n, "mix": n, "D": [...], "T": [...], "P": [...]} for tests/test_host_cpu.py."""
 import os
 import re
 import shutil
@@ -20,6 +26,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PK_SRC1_CROSS = re.compile(r"^v_pk_(mul|add|fma)_f32\b.*\bop_sel:\[[01],1[,\]]")
 TRANS = re.compile(r"^v_(rcp|rsq|sqrt|exp|log|sin|cos)(_iflag)?_(f32|f16|legacy_f32)")
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
@@ -101,7 +108,7 @@ def _reads(mnem, ops, text):
 
 
 def scan(ins):
-    found = {"D": [], "T": [], "mix": 0}
+    found = {"D": [], "T": [], "P": [], "mix": 0}
     prev = None
     for text, kernel in ins:
         if text == "label":
@@ -110,6 +117,8 @@ def scan(ins):
         mnem, ops = _split(text)
         if mnem.startswith("v_fma_mix"):
             found["mix"] += 1
+        if PK_SRC1_CROSS.match(text):
+            found["P"].append((kernel, text, ""))
         if prev is not None and mnem.startswith("v_") and ops:
             pm, pops, ptext = prev
             rd = _reads(mnem, ops, text)
@@ -122,13 +131,14 @@ def scan(ins):
 
 
 def scan_library(path):
-    total = {"code_objects": 0, "mix": 0, "D": [], "T": []}
+    total = {"code_objects": 0, "mix": 0, "D": [], "T": [], "P": []}
     for name, ins in disassemble(path):
         r = scan(ins)
         total["code_objects"] += 1
         total["mix"] += r["mix"]
         total["D"] += [(name,) + x for x in r["D"]]
         total["T"] += [(name,) + x for x in r["T"]]
+        total["P"] += [(name,) + x for x in r["P"]]
     return total
 
 
@@ -138,9 +148,9 @@ if __name__ == "__main__":
     for p in paths:
         r = scan_library(p)
         print(f"{p}: {r['code_objects']} code objects, {r['mix']} v_fma_mix*; hazards: 16-bit destination -> reader {len(r['D'])}, "
-              f"transcendental -> reader {len(r['T'])}")
-        for kind in ("D", "T"):
+              f"transcendental -> reader {len(r['T'])}, packed fp32 with the cross select on source 1 {len(r['P'])}")
+        for kind in ("D", "T", "P"):
             for name, kernel, a, b in r[kind][:20]:
                 print(f"  [{kind}] {kernel[:90]}\n        {a}\n        {b}")
-        bad += len(r["D"]) + len(r["T"])
+        bad += len(r["D"]) + len(r["T"]) + len(r["P"])
     sys.exit(1 if bad else 0)

@@ -1,0 +1,103 @@
+// Round 5, GroupNorm-fold failures (profiles/r05_gnfold_select.txt), second micro-probe.  What the failing builds of split_linear_h3l_kernel<GNF> have in common and the
+// passing ones do not: `v_pk_mul_f32 vD[0:1], vA[0:1], vB[0:1] op_sel:[0,1]` -- the LOW product takes the HIGH register of a pair that a global_load_dwordx2 delivered
+// (mean, rstd), issued right behind the s_waitcnt that covers that load, with matrix instructions of the previous loop iteration still in the pipe and further loads
+// outstanding.  The wrong values were always the LOW products of lanes 48-63.  Here: MF x 4 v_mfma_f32_32x32x16_f16, one global_load_dwordx2 into v[106:107] followed by
+// EXTRA more loads (left outstanding), s_waitcnt vmcnt(EXTRA), then the packed multiply in the form under test; the products are compared with plain v_mul_f32 of values
+// fetched again later.  Counted per lane quarter.
+// hipcc --offload-arch=gfx950 -O3 tools/micro/pk_opsel_after_load.hip -o tools/micro/bin/pk_opsel_after_load && tools/micro/bin/pk_opsel_after_load
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// FORM 0: v_pk_mul_f32 d, x, y op_sel:[0,1]      (low = x.lo * y.hi, high = x.hi * y.hi)     <- the failing builds
+// FORM 1: v_pk_mul_f32 d, x, y                    (low = x.lo * y.lo, high = x.hi * y.hi)
+// FORM 2: v_mov t, y.hi ; v_pk_mul_f32 d, t, x op_sel_hi:[0,1]   (the passing builds)
+template <int FORM, int MF, int EXTRA>
+__global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf, unsigned long long* __restrict__ bad, int iters) {
+  const int tid = threadIdx.x, quarter = (tid & 63) >> 4;
+  unsigned long long bad_lo = 0, bad_hi = 0;
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  f16x8 fa, fb;
+  for (int e = 0; e < 8; ++e) {
+    fa[e] = (_Float16)(0.001f * (tid + e));
+    fb[e] = (_Float16)(0.002f * (tid - e));
+  }
+  f32x4 sinkv = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t s = (uint32_t)(it * 2654435761u) ^ (uint32_t)(tid * 40503u + blockIdx.x * 977u);
+    const float* src = buf + 2 * (s % (uint32_t)(nbuf / 2 - 8));                       // 8-byte aligned pair (y.lo, y.hi), different lines per lane: the returns straggle
+    const float* oth = buf + 4 * ((s >> 3) % (uint32_t)(nbuf / 4 - 64));
+    const float x0 = 1.0f + (float)(s & 1023) * 0.001f, x1 = 2.0f + (float)((s >> 10) & 1023) * 0.001f;
+    float lo, hi;
+    f32x4 e0, e1, e2, e3;
+    if (MF)
+      asm volatile(".rept %c6\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\t"
+                   "v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\t.endr"
+                   : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb), "n"(MF));
+#define LOADS                                                                                                                                   \
+  "v_mov_b32 v104, %6\n\tv_mov_b32 v105, %7\n\t"                                                                                               \
+  "global_load_dwordx2 v[106:107], %8, off\n\t"                                                                                                \
+  ".if %c10 >= 1\n\tglobal_load_dwordx4 %2, %9, off\n\t.endif\n\t"                                                                             \
+  ".if %c10 >= 2\n\tglobal_load_dwordx4 %3, %9, off offset:64\n\t.endif\n\t"                                                                   \
+  ".if %c10 >= 3\n\tglobal_load_dwordx4 %4, %9, off offset:128\n\t.endif\n\t"                                                                  \
+  ".if %c10 >= 4\n\tglobal_load_dwordx4 %5, %9, off offset:192\n\t.endif\n\t"                                                                  \
+  "s_waitcnt vmcnt(%c10)\n\t"
+#define TAIL "s_nop 7\n\ts_nop 7\n\tv_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\ts_waitcnt vmcnt(0)"
+#define OPS : "=v"(lo), "=v"(hi), "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(x0), "v"(x1), "v"(src), "v"(oth), "n"(EXTRA) : "memory", "v100", "v101", "v104", "v105", "v106", "v107", "v108"
+    if (FORM == 0) asm volatile(LOADS "v_pk_mul_f32 v[100:101], v[104:105], v[106:107] op_sel:[0,1]\n\t" TAIL OPS);
+    if (FORM == 1) asm volatile(LOADS "v_pk_mul_f32 v[100:101], v[104:105], v[106:107]\n\t" TAIL OPS);
+    if (FORM == 2) asm volatile(LOADS "v_mov_b32 v108, v107\n\tv_pk_mul_f32 v[100:101], v[108:109], v[104:105] op_sel_hi:[0,1]\n\t" TAIL OPS);
+    const float y0 = src[0], y1 = src[1];
+    const float want_lo = FORM == 1 ? x0 * y0 : x0 * y1, want_hi = x1 * y1;
+    bad_lo += lo != want_lo;
+    bad_hi += hi != want_hi;
+    if (EXTRA >= 1) sinkv += e0;
+    if (EXTRA >= 2) sinkv += e1;
+    if (EXTRA >= 3) sinkv += e2;
+    if (EXTRA >= 4) sinkv += e3;
+  }
+  float sink = sinkv.x + sinkv.y + sinkv.z + sinkv.w;
+  for (int j = 0; j < 4; ++j) sink += acc[j][0] + acc[j][7];
+  if (sink == 1234.5f) bad_lo += 1;
+  if (bad_lo) atomicAdd(bad + quarter, bad_lo);
+  if (bad_hi) atomicAdd(bad + 4 + quarter, bad_hi);
+}
+
+static float* g_buf;
+static const int NBUF = 1 << 24;                                                      // 64 MB of floats: most loads miss the caches
+
+template <int FORM, int MF, int EXTRA, int THREADS>
+void run(unsigned long long* bad, int blocks, int iters) {
+  (void)hipMemset(bad, 0, 64);
+  hipLaunchKernelGGL((k<FORM, MF, EXTRA>), dim3(blocks), dim3(THREADS), 0, 0, g_buf, NBUF, bad, iters);
+  (void)hipDeviceSynchronize();
+  unsigned long long h[8];
+  (void)hipMemcpy(h, bad, 64, hipMemcpyDeviceToHost);
+  static const char* names[3] = {"pk_mul op_sel:[0,1]        ", "pk_mul (no op_sel)         ", "v_mov hi; pk_mul op_sel_hi "};
+  printf("  %s  %d x 4 MFMA in flight, %d loads left outstanding, %d waves / workgroup, %d workgroups: %.3g products | wrong LOW by lane quarter: %llu %llu %llu %llu | wrong HIGH: %llu %llu %llu %llu\n",
+         names[FORM], MF, EXTRA, THREADS / 64, blocks, (double)blocks * THREADS * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+}
+
+__global__ void fill(float* b, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b[i] = 0.5f + (float)((i * 2654435761u) >> 20) * 0.001f;
+}
+
+int main() {
+  unsigned long long* bad;
+  (void)hipMalloc(&bad, 64);
+  (void)hipMalloc(&g_buf, (size_t)NBUF * 4);
+  hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, g_buf, NBUF);
+  const int iters = 4000;
+  for (int blocks : {256, 512}) {
+    run<0, 0, 0, 256>(bad, blocks, iters); run<0, 0, 4, 256>(bad, blocks, iters); run<0, 2, 0, 256>(bad, blocks, iters); run<0, 2, 4, 256>(bad, blocks, iters);
+    run<0, 2, 4, 512>(bad, blocks, iters); run<0, 4, 4, 512>(bad, blocks, iters); run<0, 1, 4, 512>(bad, blocks, iters); run<0, 2, 2, 512>(bad, blocks, iters);
+    run<1, 2, 4, 256>(bad, blocks, iters); run<1, 2, 4, 512>(bad, blocks, iters); run<2, 2, 4, 256>(bad, blocks, iters); run<2, 2, 4, 512>(bad, blocks, iters);
+  }
+  return 0;
+}
