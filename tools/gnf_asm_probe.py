@@ -51,6 +51,13 @@ def variants(head):
     v["swapped_op_sel_10"] = head.replace(PK1, "\tv_pk_mul_f32 v[166:167], v[182:183], v[130:131] op_sel:[1,0]\n").replace(PK2, "\tv_pk_mul_f32 v[168:169], v[182:183], v[132:133] op_sel:[1,0]\n")
     # rstd moved into the LOW half of a pair by plain VALU, broadcast with op_sel_hi (low register for both products): the form the passing builds use
     v["op_sel_hi_broadcast"] = head.replace(PK1, "\tv_mov_b32 v220, v183\n\tv_pk_mul_f32 v[166:167], v[220:221], v[130:131] op_sel_hi:[0,1]\n").replace(PK2, "\tv_pk_mul_f32 v[168:169], v[220:221], v[132:133] op_sel_hi:[0,1]\n")
+    # ---- what else does it need?  Parts of the loop removed (the GEMM's result is then garbage; the dumped coefficient a does not depend on it)
+    drop = lambda pat: "".join(l for l in head.splitlines(True) if not re.search(pat, l))
+    v["loop_without_mfma"] = drop(r"^\tv_mfma_")
+    v["loop_without_ds_read"] = drop(r"^\tds_read_b128")
+    v["loop_without_ds_write"] = drop(r"^\tds_write_b128")
+    v["loop_without_barrier"] = drop(r"^\ts_barrier")
+    v["loop_without_mfma_ds"] = drop(r"^\tv_mfma_|^\tds_read_b128|^\tds_write_b128|^\ts_barrier")
     # ---- where does the zero come from?  The dump's `a` slot (v[166:169], stored at offset:128) is replaced by a SNAPSHOT of gamma (v[130:133]) ...
     GLOAD = "\tglobal_load_dwordx4 v[130:133], v[136:137], off\n"
     DUMP_A = "\tglobal_store_dwordx4 v[180:181], v[166:169], off offset:128\n"

@@ -1,9 +1,10 @@
 // Round 5, GroupNorm-fold failures (profiles/r05_gnfold_select.txt), second micro-probe.  What the failing builds of split_linear_h3l_kernel<GNF> have in common and the
 // passing ones do not: `v_pk_mul_f32 vD[0:1], vA[0:1], vB[0:1] op_sel:[0,1]` -- the LOW product takes the HIGH register of a pair that a global_load_dwordx2 delivered
 // (mean, rstd), issued right behind the s_waitcnt that covers that load, with matrix instructions of the previous loop iteration still in the pipe and further loads
-// outstanding.  The wrong values were always the LOW products of lanes 48-63.  Here: MF x 4 v_mfma_f32_32x32x16_f16, one global_load_dwordx2 into v[106:107] followed by
+// outstanding.  The wrong values were always the LOW products of lanes 48-63.  Here: MF x 4 v_mfma_f32_32x32x16_f16, one global_load_dwordx2 into v[182:183] followed by
 // EXTRA more loads (left outstanding), s_waitcnt vmcnt(EXTRA), then the packed multiply in the form under test; the products are compared with plain v_mul_f32 of values
 // fetched again later.  Counted per lane quarter.
+// The registers are the failing kernel's own (destination v[166:167], source 0 v[130:131], source 1 v[182:183]): the kernel then allocates > 184 registers, two waves per SIMD.
 // hipcc --offload-arch=gfx950 -O3 tools/micro/pk_opsel_after_load.hip -o tools/micro/bin/pk_opsel_after_load && tools/micro/bin/pk_opsel_after_load
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,18 +42,18 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
                    "v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\t.endr"
                    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb), "n"(MF));
 #define LOADS                                                                                                                                   \
-  "v_mov_b32 v104, %6\n\tv_mov_b32 v105, %7\n\t"                                                                                               \
-  "global_load_dwordx2 v[106:107], %8, off\n\t"                                                                                                \
+  "v_mov_b32 v130, %6\n\tv_mov_b32 v131, %7\n\t"                                                                                               \
+  "global_load_dwordx2 v[182:183], %8, off\n\t"                                                                                                \
   ".if %c10 >= 1\n\tglobal_load_dwordx4 %2, %9, off\n\t.endif\n\t"                                                                             \
   ".if %c10 >= 2\n\tglobal_load_dwordx4 %3, %9, off offset:64\n\t.endif\n\t"                                                                   \
   ".if %c10 >= 3\n\tglobal_load_dwordx4 %4, %9, off offset:128\n\t.endif\n\t"                                                                  \
   ".if %c10 >= 4\n\tglobal_load_dwordx4 %5, %9, off offset:192\n\t.endif\n\t"                                                                  \
   "s_waitcnt vmcnt(%c10)\n\t"
-#define TAIL "s_nop 7\n\ts_nop 7\n\tv_mov_b32 %0, v100\n\tv_mov_b32 %1, v101\n\ts_waitcnt vmcnt(0)"
-#define OPS : "=v"(lo), "=v"(hi), "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(x0), "v"(x1), "v"(src), "v"(oth), "n"(EXTRA) : "memory", "v100", "v101", "v104", "v105", "v106", "v107", "v108"
-    if (FORM == 0) asm volatile(LOADS "v_pk_mul_f32 v[100:101], v[104:105], v[106:107] op_sel:[0,1]\n\t" TAIL OPS);
-    if (FORM == 1) asm volatile(LOADS "v_pk_mul_f32 v[100:101], v[104:105], v[106:107]\n\t" TAIL OPS);
-    if (FORM == 2) asm volatile(LOADS "v_mov_b32 v108, v107\n\tv_pk_mul_f32 v[100:101], v[108:109], v[104:105] op_sel_hi:[0,1]\n\t" TAIL OPS);
+#define TAIL "s_nop 7\n\ts_nop 7\n\tv_mov_b32 %0, v166\n\tv_mov_b32 %1, v167\n\ts_waitcnt vmcnt(0)"
+#define OPS : "=v"(lo), "=v"(hi), "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(x0), "v"(x1), "v"(src), "v"(oth), "n"(EXTRA) : "memory", "v166", "v167", "v130", "v131", "v182", "v183", "v220"
+    if (FORM == 0) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[130:131], v[182:183] op_sel:[0,1]\n\t" TAIL OPS);
+    if (FORM == 1) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[130:131], v[182:183]\n\t" TAIL OPS);
+    if (FORM == 2) asm volatile(LOADS "v_mov_b32 v220, v183\n\tv_pk_mul_f32 v[166:167], v[220:221], v[130:131] op_sel_hi:[0,1]\n\t" TAIL OPS);
     const float y0 = src[0], y1 = src[1];
     const float want_lo = FORM == 1 ? x0 * y0 : x0 * y1, want_hi = x1 * y1;
     bad_lo += lo != want_lo;
