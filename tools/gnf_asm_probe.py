@@ -58,6 +58,21 @@ def variants(head):
     v["loop_without_ds_write"] = drop(r"^\tds_write_b128")
     v["loop_without_barrier"] = drop(r"^\ts_barrier")
     v["loop_without_mfma_ds"] = drop(r"^\tv_mfma_|^\tds_read_b128|^\tds_write_b128|^\ts_barrier")
+    # ---- towards a minimal loop: MFMAs kept, everything else that can go removed step by step (every s_waitcnt vmcnt(n) becomes vmcnt(0) once loads are dropped)
+    DS = r"^\tds_read_b128|^\tds_write_b128|^\ts_barrier"
+    ROWLOADS = r"^\tglobal_load_dwordx4 v\[(146:149|162:165|150:153|166:169|138:141|142:145|158:161|154:157)\]"
+    SPLIT = r"^\tv_cvt_pk_f16_f32|^\tv_fma_mix(lo|hi)_f16"
+    vm0 = lambda t: re.sub(r"s_waitcnt vmcnt\(\d+\)", "s_waitcnt vmcnt(0)", t)
+    v["min_A_no_lds"] = drop(DS)
+    v["min_B_no_lds_no_row_weight_loads"] = vm0(drop(DS + "|" + ROWLOADS))
+    v["min_C_B_no_split_arith"] = vm0(drop(DS + "|" + ROWLOADS + "|" + SPLIT))
+    keep = [0]
+    def sixth(l):
+        if re.search(r"^\tv_mfma_", l):
+            keep[0] += 1
+            return keep[0] % 6 == 1
+        return True
+    v["min_D_every_6th_mfma"] = "".join(l for l in head.splitlines(True) if sixth(l))
     # ---- where does the zero come from?  The dump's `a` slot (v[166:169], stored at offset:128) is replaced by a SNAPSHOT of gamma (v[130:133]) ...
     GLOAD = "\tglobal_load_dwordx4 v[130:133], v[136:137], off\n"
     DUMP_A = "\tglobal_store_dwordx4 v[180:181], v[166:169], off offset:128\n"

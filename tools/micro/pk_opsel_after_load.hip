@@ -17,7 +17,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // FORM 0: v_pk_mul_f32 d, x, y op_sel:[0,1]      (low = x.lo * y.hi, high = x.hi * y.hi)     <- the failing builds
 // FORM 1: v_pk_mul_f32 d, x, y                    (low = x.lo * y.lo, high = x.hi * y.hi)
 // FORM 2: v_mov t, y.hi ; v_pk_mul_f32 d, t, x op_sel_hi:[0,1]   (the passing builds)
-template <int FORM, int MF, int EXTRA>
+template <int FORM, int MF, int EXTRA, int SPLIT = 0>
 __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf, unsigned long long* __restrict__ bad, int iters) {
   const int tid = threadIdx.x, quarter = (tid & 63) >> 4;
   unsigned long long bad_lo = 0, bad_hi = 0;
@@ -30,6 +30,16 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
     fb[e] = (_Float16)(0.002f * (tid - e));
   }
   f32x4 sinkv = {0.f, 0.f, 0.f, 0.f};
+  if (SPLIT && tid >= 256) {                                                         // SPLIT: waves 4-7 (the SIMDs' second waves) only run MFMAs, for the whole launch
+    for (int it = 0; it < iters * 4; ++it)
+      asm volatile(".rept 8\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\t"
+                   "v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\t.endr"
+                   : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb));
+    float sk = 0.f;
+    for (int j = 0; j < 4; ++j) sk += acc[j][0] + acc[j][7];
+    if (sk == 1234.5f) atomicAdd(bad, 1ull);
+    return;
+  }
   for (int it = 0; it < iters; ++it) {
     const uint32_t s = (uint32_t)(it * 2654435761u) ^ (uint32_t)(tid * 40503u + blockIdx.x * 977u);
     const float* src = buf + 2 * (s % (uint32_t)(nbuf / 2 - 8));                       // 8-byte aligned pair (y.lo, y.hi), different lines per lane: the returns straggle
@@ -73,16 +83,16 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
 static float* g_buf;
 static const int NBUF = 1 << 24;                                                      // 64 MB of floats: most loads miss the caches
 
-template <int FORM, int MF, int EXTRA, int THREADS>
+template <int FORM, int MF, int EXTRA, int THREADS, int SPLIT = 0>
 void run(unsigned long long* bad, int blocks, int iters) {
   (void)hipMemset(bad, 0, 64);
-  hipLaunchKernelGGL((k<FORM, MF, EXTRA>), dim3(blocks), dim3(THREADS), 0, 0, g_buf, NBUF, bad, iters);
+  hipLaunchKernelGGL((k<FORM, MF, EXTRA, SPLIT>), dim3(blocks), dim3(THREADS), 0, 0, g_buf, NBUF, bad, iters);
   (void)hipDeviceSynchronize();
   unsigned long long h[8];
   (void)hipMemcpy(h, bad, 64, hipMemcpyDeviceToHost);
   static const char* names[3] = {"pk_mul op_sel:[0,1]        ", "pk_mul (no op_sel)         ", "v_mov hi; pk_mul op_sel_hi "};
-  printf("  %s  %d x 4 MFMA in flight, %d loads left outstanding, %d waves / workgroup, %d workgroups: %.3g products | wrong LOW by lane quarter: %llu %llu %llu %llu | wrong HIGH: %llu %llu %llu %llu\n",
-         names[FORM], MF, EXTRA, THREADS / 64, blocks, (double)blocks * THREADS * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  printf("  %s%s  %d x 4 MFMA in flight, %d loads left outstanding, %d waves / workgroup, %d workgroups: %.3g products | wrong LOW by lane quarter: %llu %llu %llu %llu | wrong HIGH: %llu %llu %llu %llu\n",
+         SPLIT ? "[other wave of every SIMD: MFMAs only] " : "", names[FORM], MF, EXTRA, THREADS / 64, blocks, (double)blocks * THREADS * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
 }
 
 __global__ void fill(float* b, int n) {
@@ -98,6 +108,7 @@ int main() {
   for (int blocks : {256, 512}) {
     run<0, 0, 0, 256>(bad, blocks, iters); run<0, 0, 4, 256>(bad, blocks, iters); run<0, 2, 0, 256>(bad, blocks, iters); run<0, 2, 4, 256>(bad, blocks, iters);
     run<0, 2, 4, 512>(bad, blocks, iters); run<0, 4, 4, 512>(bad, blocks, iters); run<0, 1, 4, 512>(bad, blocks, iters); run<0, 2, 2, 512>(bad, blocks, iters);
+    run<0, 0, 4, 512, 1>(bad, blocks, iters); run<0, 0, 2, 512, 1>(bad, blocks, iters); run<0, 0, 0, 512, 1>(bad, blocks, iters); run<0, 1, 4, 512, 1>(bad, blocks, iters);
     run<1, 2, 4, 256>(bad, blocks, iters); run<1, 2, 4, 512>(bad, blocks, iters); run<2, 2, 4, 256>(bad, blocks, iters); run<2, 2, 4, 512>(bad, blocks, iters);
   }
   return 0;
