@@ -12,7 +12,7 @@ the text of an `asm` statement, so a hand-written instruction can end up back to
   P  (round 5, not a documented rule: an observation) a packed fp32 VALU (v_pk_mul/add/fma_f32) whose LOW lane takes the HIGH register of source 1 (`op_sel:[x,1,...]`).
      In the GroupNorm-folded projection `v_pk_mul_f32 vD, v_gamma, v_(mean,rstd) op_sel:[0,1]` gave a LOW product of exactly 0 in lanes 48-63 a few hundred times per
      launch; the same products as v_mul_f32, as a packed multiply on a broadcast pair, or with the select on source 0 (`op_sel:[1,0]`) never did
-     (tools/gnf_asm_probe.py, profiles/r05_gnfold_select.txt).  The library is kept free of the form: split_linear_gnf.hip is compiled without packed fp32, the one other
+     (tools/gnf_asm_probe.py, profiles/r05_gnfold_select.txt); tools/micro/pk_opsel_after_load.hip reproduces it standalone, v_pk_add_f32 included (profiles/r05_pk_opsel_erratum.txt).  The library is kept free of the form: split_linear_gnf.hip is compiled without packed fp32, the one other
      producer (the LayerNorm prologue of mlp_fused_h3.h) sums channel pairs instead of quads.
 
 Usage: python tools/isa_hazards.py [lib.so | file.o ...]   (default: rba_amd/csrc/librba_hip.so); exit status 1 if anything is found.

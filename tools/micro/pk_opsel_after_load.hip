@@ -4,6 +4,8 @@
 // outstanding.  The wrong values were always the LOW products of lanes 48-63.  Here: MF x 4 v_mfma_f32_32x32x16_f16, one global_load_dwordx2 into v[182:183] followed by
 // EXTRA more loads (left outstanding), s_waitcnt vmcnt(EXTRA), then the packed multiply in the form under test; the products are compared with plain v_mul_f32 of values
 // fetched again later.  Counted per lane quarter.
+// RESULT (profiles/r05_pk_opsel_erratum.txt): with SPLIT = 2 (the SIMDs' second waves issue MFMAs with plain VALU between them) the LOW result of the packed instruction is exactly 0 in
+// lanes 48-63 whenever its op_sel takes the HIGH register of SOURCE 1 (v_pk_mul_f32 and v_pk_add_f32; 1e5 ... 1e7 of 5e8 per launch); every other select form is exact.
 // The registers are the failing kernel's own (destination v[166:167], source 0 v[130:131], source 1 v[182:183]): the kernel then allocates > 184 registers, two waves per SIMD.
 // hipcc --offload-arch=gfx950 -O3 tools/micro/pk_opsel_after_load.hip -o tools/micro/bin/pk_opsel_after_load && tools/micro/bin/pk_opsel_after_load
 #include <hip/hip_runtime.h>
@@ -31,7 +33,13 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
   }
   f32x4 sinkv = {0.f, 0.f, 0.f, 0.f};
   if (SPLIT && tid >= 256) {                                                         // SPLIT: waves 4-7 (the SIMDs' second waves) only run MFMAs, for the whole launch
+    float va = 1.0f + tid, vb = 0.5f;
     for (int it = 0; it < iters * 4; ++it)
+      if (SPLIT == 2)                                                                // MFMAs with plain VALU between them: what the aggressor experiments of tools/gnf_asm_probe.py say it takes
+        asm volatile(".rept 8\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_add_f32 %6, %6, %7\n\tv_mul_f32 %7, %7, %6\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_add_f32 %6, %6, %7\n\t"
+                     "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\tv_fma_f32 %7, %6, %7, %6\n\tv_max_f32 %6, %6, %7\n\tv_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\tv_add_f32 %7, %6, %7\n\t.endr"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb), "v"(va), "v"(vb));
+      else
       asm volatile(".rept 8\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\t"
                    "v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\t.endr"
                    : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb));
@@ -64,8 +72,26 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
     if (FORM == 0) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[130:131], v[182:183] op_sel:[0,1]\n\t" TAIL OPS);
     if (FORM == 1) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[130:131], v[182:183]\n\t" TAIL OPS);
     if (FORM == 2) asm volatile(LOADS "v_mov_b32 v220, v183\n\tv_pk_mul_f32 v[166:167], v[220:221], v[130:131] op_sel_hi:[0,1]\n\t" TAIL OPS);
+    // the other select forms the library's kernels contain, in the same harness (x = v[130:131] from v_mov, y = v[182:183] from the load)
+    if (FORM == 3) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[182:183], v[130:131] op_sel:[1,0]\n\t" TAIL OPS);                       // cross select on source 0
+    if (FORM == 4) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[130:131], v[182:183] op_sel_hi:[1,0]\n\t" TAIL OPS);                    // HIGH product takes the LOW register of source 1 (broadcast)
+    if (FORM == 5) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[182:183], v[130:131] op_sel_hi:[0,1]\n\t" TAIL OPS);                    // ... of source 0
+    if (FORM == 6) asm volatile(LOADS "v_pk_fma_f32 v[166:167], v[130:131], v[130:131], v[182:183] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n\t" TAIL OPS);   // source 2 swapped
+    if (FORM == 7) asm volatile(LOADS "v_pk_add_f32 v[166:167], v[130:131], v[182:183] op_sel:[0,1] op_sel_hi:[1,0]\n\t" TAIL OPS);        // source 1 swapped (the horizontal-add form)
+    if (FORM == 8) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[182:183], v[130:131] op_sel:[0,1]\n\t" TAIL OPS);                       // source 1 cross, the LOADED pair as source 0
+    if (FORM == 9) asm volatile(LOADS "v_mul_f32 v166, v130, v183\n\tv_mul_f32 v167, v131, v183\n\t" TAIL OPS);
     const float y0 = src[0], y1 = src[1];
-    const float want_lo = FORM == 1 ? x0 * y0 : x0 * y1, want_hi = x1 * y1;
+    float want_lo = x0 * y1, want_hi = x1 * y1;                                        // FORM 0, 2, 3, 9
+    if (FORM == 1) want_lo = x0 * y0;
+    if (FORM == 4) { want_lo = x0 * y0; want_hi = x1 * y0; }
+    if (FORM == 5) { want_lo = y0 * x0; want_hi = y0 * x1; }
+    if (FORM == 6) { want_lo = fmaf(x0, x0, y1); want_hi = fmaf(x1, x1, y0); }
+    if (FORM == 7) { want_lo = x0 + y1; want_hi = x1 + y0; }
+    if (FORM == 8) { want_lo = y0 * x1; want_hi = y1 * x1; }
+    if (lo != want_lo && bad_lo == 0) {                                                // first wrong product of this thread: what did it get?
+      float* smp = reinterpret_cast<float*>(bad + 8);
+      smp[0] = lo; smp[1] = x0; smp[2] = y0; smp[3] = y1; smp[4] = hi; smp[5] = x1;
+    }
     bad_lo += lo != want_lo;
     bad_hi += hi != want_hi;
     if (EXTRA >= 1) sinkv += e0;
@@ -85,14 +111,20 @@ static const int NBUF = 1 << 24;                                                
 
 template <int FORM, int MF, int EXTRA, int THREADS, int SPLIT = 0>
 void run(unsigned long long* bad, int blocks, int iters) {
-  (void)hipMemset(bad, 0, 64);
+  (void)hipMemset(bad, 0, 128);
   hipLaunchKernelGGL((k<FORM, MF, EXTRA, SPLIT>), dim3(blocks), dim3(THREADS), 0, 0, g_buf, NBUF, bad, iters);
   (void)hipDeviceSynchronize();
-  unsigned long long h[8];
-  (void)hipMemcpy(h, bad, 64, hipMemcpyDeviceToHost);
-  static const char* names[3] = {"pk_mul op_sel:[0,1]        ", "pk_mul (no op_sel)         ", "v_mov hi; pk_mul op_sel_hi "};
+  unsigned long long h[16];
+  (void)hipMemcpy(h, bad, 128, hipMemcpyDeviceToHost);
+  static const char* names[10] = {"pk_mul x, y op_sel:[0,1]    ", "pk_mul (no op_sel)         ", "v_mov hi; pk_mul op_sel_hi ", "pk_mul y, x op_sel:[1,0]    ", "pk_mul x, y op_sel_hi:[1,0] ", "pk_mul y, x op_sel_hi:[0,1] ",
+                                  "pk_fma x, x, y src2 swapped ", "pk_add x, y src1 swapped    ", "pk_mul y, x op_sel:[0,1]    ", "2 x v_mul_f32              "};
   printf("  %s%s  %d x 4 MFMA in flight, %d loads left outstanding, %d waves / workgroup, %d workgroups: %.3g products | wrong LOW by lane quarter: %llu %llu %llu %llu | wrong HIGH: %llu %llu %llu %llu\n",
-         SPLIT ? "[other wave of every SIMD: MFMAs only] " : "", names[FORM], MF, EXTRA, THREADS / 64, blocks, (double)blocks * THREADS * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+         SPLIT == 2 ? "[other wave of every SIMD: MFMAs + VALU] " : SPLIT ? "[other wave of every SIMD: MFMAs only] " : "", names[FORM], MF, EXTRA, THREADS / 64, blocks, (double)blocks * THREADS * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  if (h[0] + h[1] + h[2] + h[3]) {
+    const float* smp = reinterpret_cast<const float*>(h + 8);
+    printf("      a wrong LOW product: got %.9g for x.lo %.9g, y = (%.9g, %.9g): x.lo * y.hi = %.9g, x.lo * y.lo = %.9g; its HIGH product %.9g (x.hi %.9g)\n", smp[0], smp[1], smp[2], smp[3],
+           smp[1] * smp[3], smp[1] * smp[2], smp[4], smp[5]);
+  }
 }
 
 __global__ void fill(float* b, int n) {
@@ -101,15 +133,19 @@ __global__ void fill(float* b, int n) {
 
 int main() {
   unsigned long long* bad;
-  (void)hipMalloc(&bad, 64);
+  (void)hipMalloc(&bad, 128);
   (void)hipMalloc(&g_buf, (size_t)NBUF * 4);
   hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, g_buf, NBUF);
   const int iters = 4000;
-  for (int blocks : {256, 512}) {
-    run<0, 0, 0, 256>(bad, blocks, iters); run<0, 0, 4, 256>(bad, blocks, iters); run<0, 2, 0, 256>(bad, blocks, iters); run<0, 2, 4, 256>(bad, blocks, iters);
-    run<0, 2, 4, 512>(bad, blocks, iters); run<0, 4, 4, 512>(bad, blocks, iters); run<0, 1, 4, 512>(bad, blocks, iters); run<0, 2, 2, 512>(bad, blocks, iters);
-    run<0, 0, 4, 512, 1>(bad, blocks, iters); run<0, 0, 2, 512, 1>(bad, blocks, iters); run<0, 0, 0, 512, 1>(bad, blocks, iters); run<0, 1, 4, 512, 1>(bad, blocks, iters);
-    run<1, 2, 4, 256>(bad, blocks, iters); run<1, 2, 4, 512>(bad, blocks, iters); run<2, 2, 4, 256>(bad, blocks, iters); run<2, 2, 4, 512>(bad, blocks, iters);
+  for (int rep = 0; rep < 2; ++rep) {
+    const int blocks = 256;
+    // the configuration that reproduces it: the SIMDs' second waves issue MFMAs with plain VALU between them, the first waves load the pair and multiply with 2 or 4 more loads outstanding
+    run<0, 0, 2, 512, 2>(bad, blocks, iters); run<0, 0, 4, 512, 2>(bad, blocks, iters); run<0, 0, 0, 512, 2>(bad, blocks, iters);
+    run<1, 0, 4, 512, 2>(bad, blocks, iters); run<2, 0, 4, 512, 2>(bad, blocks, iters); run<9, 0, 4, 512, 2>(bad, blocks, iters);          // controls
+    run<3, 0, 4, 512, 2>(bad, blocks, iters); run<4, 0, 4, 512, 2>(bad, blocks, iters); run<5, 0, 4, 512, 2>(bad, blocks, iters); run<6, 0, 4, 512, 2>(bad, blocks, iters);
+    run<7, 0, 4, 512, 2>(bad, blocks, iters); run<8, 0, 4, 512, 2>(bad, blocks, iters);
+    run<3, 0, 2, 512, 2>(bad, blocks, iters); run<4, 0, 2, 512, 2>(bad, blocks, iters); run<6, 0, 2, 512, 2>(bad, blocks, iters); run<7, 0, 2, 512, 2>(bad, blocks, iters); run<8, 0, 2, 512, 2>(bad, blocks, iters);
+    run<0, 0, 4, 512, 1>(bad, blocks, iters); run<0, 0, 4, 512, 0>(bad, blocks, iters);                                                     // aggressor: MFMAs only / the same code in every wave
   }
   return 0;
 }

@@ -23,11 +23,22 @@ __global__ __launch_bounds__(512) void k(unsigned long long* __restrict__ bad, i
       fa[e] = (_Float16)(0.001f * (tid + e));
       fb[e] = (_Float16)(0.002f * (tid - e));
     }
+    float va = 1.0f + tid, vb = 0.5f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pa = {1.0f + tid, 2.0f}, pb = {0.5f, 0.25f};
     for (int it = 0; it < iters; ++it) {
-      if (MFMA)
+      if (MFMA == 1)
         asm volatile(".rept 8\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\t"
                      "v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\t.endr"
                      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb));
+      else if (MFMA == 2)                                                             // MFMAs with plain VALU between them (the GEMM loop's shape: gnf_asm_probe's aggressor experiments)
+        asm volatile(".rept 8\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_add_f32 %6, %6, %7\n\tv_mul_f32 %7, %7, %6\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_add_f32 %6, %6, %7\n\t"
+                     "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\tv_fma_f32 %7, %6, %7, %6\n\tv_max_f32 %6, %6, %7\n\tv_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\tv_add_f32 %7, %6, %7\n\t.endr"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb), "v"(va), "v"(vb));
+      else if (MFMA == 3)                                                             // ... with PACKED VALU between them
+        asm volatile(".rept 8\n\tv_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\tv_pk_add_f32 %6, %6, %7\n\tv_pk_mul_f32 %7, %7, %6\n\tv_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n\tv_pk_add_f32 %6, %6, %7\n\t"
+                     "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n\tv_pk_fma_f32 %7, %6, %7, %6\n\tv_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n\tv_pk_add_f32 %7, %6, %7\n\t.endr"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(fa), "v"(fb), "v"(pa), "v"(pb));
       else
         asm volatile("s_sleep 16");
     }
@@ -66,7 +77,7 @@ void run(unsigned long long* bad, float* sink, int blocks, int iters) {
   (void)hipMemcpy(h, bad, 64, hipMemcpyDeviceToHost);
   static const char* names[4] = {"v_pk_mul_f32 op_sel:[0,1] (source 1 cross)", "v_pk_mul_f32 (no op_sel)                 ", "v_pk_mul_f32 op_sel:[1,0] (source 0 cross)", "2 x v_mul_f32                            "};
   printf("  %s  other wave of the SIMD: %s  %d workgroups: %.3g products | wrong LOW by lane quarter: %llu %llu %llu %llu | wrong HIGH: %llu %llu %llu %llu\n", names[FORM],
-         MFMA ? "MFMAs back to back" : "idle              ", blocks, (double)blocks * 256 * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+         MFMA == 1 ? "MFMAs back to back      " : MFMA == 2 ? "MFMAs + plain VALU      " : MFMA == 3 ? "MFMAs + packed VALU     " : "idle                    ", blocks, (double)blocks * 256 * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
 }
 
 int main() {
@@ -76,7 +87,7 @@ int main() {
   (void)hipMalloc(&sink, 64);
   const int iters = 20000;
   for (int blocks : {256, 512}) {
-    run<0, 0>(bad, sink, blocks, iters); run<0, 1>(bad, sink, blocks, iters); run<1, 1>(bad, sink, blocks, iters); run<2, 1>(bad, sink, blocks, iters); run<3, 1>(bad, sink, blocks, iters);
+    run<0, 0>(bad, sink, blocks, iters); run<0, 1>(bad, sink, blocks, iters); run<0, 2>(bad, sink, blocks, iters); run<0, 3>(bad, sink, blocks, iters); run<2, 2>(bad, sink, blocks, iters); run<3, 3>(bad, sink, blocks, iters); run<1, 1>(bad, sink, blocks, iters); run<2, 1>(bad, sink, blocks, iters); run<3, 1>(bad, sink, blocks, iters);
   }
   return 0;
 }
