@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
     if (FORM == 6) asm volatile(LOADS "v_pk_fma_f32 v[166:167], v[130:131], v[130:131], v[182:183] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n\t" TAIL OPS);   // source 2 swapped
     if (FORM == 7) asm volatile(LOADS "v_pk_add_f32 v[166:167], v[130:131], v[182:183] op_sel:[0,1] op_sel_hi:[1,0]\n\t" TAIL OPS);        // source 1 swapped (the horizontal-add form)
     if (FORM == 8) asm volatile(LOADS "v_pk_mul_f32 v[166:167], v[182:183], v[130:131] op_sel:[0,1]\n\t" TAIL OPS);                       // source 1 cross, the LOADED pair as source 0
+    if (FORM == 10) asm volatile(LOADS "v_pk_fma_f32 v[166:167], v[130:131], v[182:183], v[130:131] op_sel:[0,1,0]\n\t" TAIL OPS);                // source 1 cross in a fused multiply-add
     if (FORM == 9) asm volatile(LOADS "v_mul_f32 v166, v130, v183\n\tv_mul_f32 v167, v131, v183\n\t" TAIL OPS);
     const float y0 = src[0], y1 = src[1];
     float want_lo = x0 * y1, want_hi = x1 * y1;                                        // FORM 0, 2, 3, 9
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ buf, int nbuf
     if (FORM == 6) { want_lo = fmaf(x0, x0, y1); want_hi = fmaf(x1, x1, y0); }
     if (FORM == 7) { want_lo = x0 + y1; want_hi = x1 + y0; }
     if (FORM == 8) { want_lo = y0 * x1; want_hi = y1 * x1; }
+    if (FORM == 10) { want_lo = fmaf(x0, y1, x0); want_hi = fmaf(x1, y1, x1); }
     if (lo != want_lo && bad_lo == 0) {                                                // first wrong product of this thread: what did it get?
       float* smp = reinterpret_cast<float*>(bad + 8);
       smp[0] = lo; smp[1] = x0; smp[2] = y0; smp[3] = y1; smp[4] = hi; smp[5] = x1;
@@ -116,8 +118,8 @@ void run(unsigned long long* bad, int blocks, int iters) {
   (void)hipDeviceSynchronize();
   unsigned long long h[16];
   (void)hipMemcpy(h, bad, 128, hipMemcpyDeviceToHost);
-  static const char* names[10] = {"pk_mul x, y op_sel:[0,1]    ", "pk_mul (no op_sel)         ", "v_mov hi; pk_mul op_sel_hi ", "pk_mul y, x op_sel:[1,0]    ", "pk_mul x, y op_sel_hi:[1,0] ", "pk_mul y, x op_sel_hi:[0,1] ",
-                                  "pk_fma x, x, y src2 swapped ", "pk_add x, y src1 swapped    ", "pk_mul y, x op_sel:[0,1]    ", "2 x v_mul_f32              "};
+  static const char* names[11] = {"pk_mul x, y op_sel:[0,1]    ", "pk_mul (no op_sel)         ", "v_mov hi; pk_mul op_sel_hi ", "pk_mul y, x op_sel:[1,0]    ", "pk_mul x, y op_sel_hi:[1,0] ", "pk_mul y, x op_sel_hi:[0,1] ",
+                                  "pk_fma x, x, y src2 swapped ", "pk_add x, y src1 swapped    ", "pk_mul y, x op_sel:[0,1]    ", "2 x v_mul_f32              ", "pk_fma x, y, x op_sel:[0,1,0]"};
   printf("  %s%s  %d x 4 MFMA in flight, %d loads left outstanding, %d waves / workgroup, %d workgroups: %.3g products | wrong LOW by lane quarter: %llu %llu %llu %llu | wrong HIGH: %llu %llu %llu %llu\n",
          SPLIT == 2 ? "[other wave of every SIMD: MFMAs + VALU] " : SPLIT ? "[other wave of every SIMD: MFMAs only] " : "", names[FORM], MF, EXTRA, THREADS / 64, blocks, (double)blocks * THREADS * iters, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
   if (h[0] + h[1] + h[2] + h[3]) {
@@ -143,7 +145,7 @@ int main() {
     run<0, 0, 2, 512, 2>(bad, blocks, iters); run<0, 0, 4, 512, 2>(bad, blocks, iters); run<0, 0, 0, 512, 2>(bad, blocks, iters);
     run<1, 0, 4, 512, 2>(bad, blocks, iters); run<2, 0, 4, 512, 2>(bad, blocks, iters); run<9, 0, 4, 512, 2>(bad, blocks, iters);          // controls
     run<3, 0, 4, 512, 2>(bad, blocks, iters); run<4, 0, 4, 512, 2>(bad, blocks, iters); run<5, 0, 4, 512, 2>(bad, blocks, iters); run<6, 0, 4, 512, 2>(bad, blocks, iters);
-    run<7, 0, 4, 512, 2>(bad, blocks, iters); run<8, 0, 4, 512, 2>(bad, blocks, iters);
+    run<7, 0, 4, 512, 2>(bad, blocks, iters); run<8, 0, 4, 512, 2>(bad, blocks, iters); run<10, 0, 4, 512, 2>(bad, blocks, iters); run<10, 0, 2, 512, 2>(bad, blocks, iters);
     run<3, 0, 2, 512, 2>(bad, blocks, iters); run<4, 0, 2, 512, 2>(bad, blocks, iters); run<6, 0, 2, 512, 2>(bad, blocks, iters); run<7, 0, 2, 512, 2>(bad, blocks, iters); run<8, 0, 2, 512, 2>(bad, blocks, iters);
     run<0, 0, 4, 512, 1>(bad, blocks, iters); run<0, 0, 4, 512, 0>(bad, blocks, iters);                                                     // aggressor: MFMAs only / the same code in every wave
   }
