@@ -253,15 +253,20 @@ def ood_pred_head(mask_features, sd, p="sem_seg_head.predictor.ood_pred"):
 
 # ------------------------------------------------------------------------------ meta arch
 @torch.no_grad()
-def forward(image, sd, a, taps=None):
+def forward(image, sd, a, taps=None, canvas=None):
     """MaskFormer.forward inference branch (mask2former/maskformer_model.py:255-260, 290-333) for ONE image
     [3,h,w] (uint8 or float, 0..255) followed by get_RbA (evaluate_ood.py:143-150) and the argmax of
-    support.py:385-388.  Returns dict(pred_logits, pred_masks, sem_seg, rba, argmax)."""
+    support.py:385-388.  Returns dict(pred_logits, pred_masks, sem_seg, rba, argmax).
+    canvas = (H, W): the image as a member of a batch whose ImageList is padded to that common size (a multiple of 32 not smaller than the
+    image, maskformer_model.py:257); default = the image's own size rounded up to 32."""
     mean = torch.tensor(PIXEL_MEAN).view(-1, 1, 1)
     std = torch.tensor(PIXEL_STD).view(-1, 1, 1)
     x = (image.float() - mean) / std
     h, w = x.shape[-2:]
     H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    if canvas is not None:
+        assert canvas[0] % 32 == 0 and canvas[1] % 32 == 0 and canvas[0] >= H and canvas[1] >= W
+        H, W = canvas
     x = F.pad(x, (0, W - w, 0, H - h))[None]
     feats = resnet_backbone(x, sd, a) if a.get("resnet") else swin_backbone(x, sd, a)
     mask_features, multi_scale = pixel_decoder(feats, sd, a)
