@@ -154,7 +154,7 @@ def pixel_decoder(feats, sd, a, p="sem_seg_head.pixel_decoder"):
     d = a["conv_dim"]
     srcs, poss = [], []
     for idx, f in enumerate(enc_in[::-1]):
-        x = feats[f].float()
+        x = feats[f].to(torch.get_default_dtype())          # the reference says .float(); the default dtype is float32 unless a test asks for a float64 truth run
         s = F.conv2d(x, sd[f"{p}.input_proj.{idx}.0.weight"], sd[f"{p}.input_proj.{idx}.0.bias"])
         srcs.append(_gn(s, sd, f"{p}.input_proj.{idx}.1"))
         poss.append(R.position_embedding_sine(x.shape[2], x.shape[3], d // 2)[None])
@@ -179,7 +179,7 @@ def pixel_decoder(feats, sd, a, p="sem_seg_head.pixel_decoder"):
     num_fpn = {4: 0, 8: 1, 16: 2, 32: 3}[min_stride]
     for idx, f in enumerate(names[:num_fpn][::-1]):
         j = num_fpn - idx          # adapter_{j} / layer_{j}: adapter_1 = res2 (msdeformattn.py:293-301)
-        x = feats[f].float()
+        x = feats[f].to(torch.get_default_dtype())          # the reference says .float(); the default dtype is float32 unless a test asks for a float64 truth run
         cur = _gn(F.conv2d(x, sd[f"{p}.adapter_{j}.weight"]), sd, f"{p}.adapter_{j}.norm")
         y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
         y = F.relu(_gn(F.conv2d(y, sd[f"{p}.layer_{j}.weight"], padding=1), sd, f"{p}.layer_{j}.norm"))
@@ -189,8 +189,11 @@ def pixel_decoder(feats, sd, a, p="sem_seg_head.pixel_decoder"):
 
 
 # ------------------------------------------------------------------- transformer decoder
-def prediction_heads(output, mask_features, size, sd, a, p):
-    """forward_prediction_heads (transformer_decoder/mask2former_transformer_decoder.py:472-489)."""
+def prediction_heads(output, mask_features, size, sd, a, p, toggle=None, tap=None):
+    """forward_prediction_heads (transformer_decoder/mask2former_transformer_decoder.py:472-489).
+    Test hooks (no effect by default): `tap` (a list) receives the interpolated attention-mask logits [B, Q, h*w] this call thresholds; `toggle` (flat indices
+    into them) inverts the threshold decision of those entries -- tests/test_shape_sweep_gpu.py uses the pair to show that a product / reference difference is the
+    reference's own discontinuity at `sigmoid(logit) < 0.5` (a logit within rounding noise of 0) and nothing else."""
     dec = _ln(output, sd, p + ".decoder_norm").transpose(0, 1)
     cls = _lin(dec, sd, p + ".class_embed")
     me = dec
@@ -200,12 +203,20 @@ def prediction_heads(output, mask_features, size, sd, a, p):
             me = F.relu(me)
     masks = torch.einsum("bqc,bchw->bqhw", me, mask_features)
     am = F.interpolate(masks, size=size, mode="bilinear", align_corners=False)
-    am = (am.sigmoid().flatten(2).unsqueeze(1).repeat(1, a["nheads"], 1, 1).flatten(0, 1) < 0.5).bool()
+    if tap is not None:
+        tap.append(am.flatten(2).clone())
+    dec = am.sigmoid().flatten(2) < 0.5
+    if toggle is not None and len(toggle):
+        dec.view(-1)[toggle] ^= True
+    am = dec.unsqueeze(1).repeat(1, a["nheads"], 1, 1).flatten(0, 1).bool()
     return cls, masks, am
 
 
-def transformer_decoder(multi_scale, mask_features, sd, a, p="sem_seg_head.predictor", taps=None):
-    """MultiScaleMaskedTransformerDecoder.forward (mask2former_transformer_decoder.py:398-470), post-norm."""
+def transformer_decoder(multi_scale, mask_features, sd, a, p="sem_seg_head.predictor", taps=None, toggles=None):
+    """MultiScaleMaskedTransformerDecoder.forward (mask2former_transformer_decoder.py:398-470), post-norm.
+    toggles: {head call index (0 = before layer 0): flat indices} for prediction_heads' test hook; taps["am_logits"] lists every call's thresholded logits."""
+    toggles = toggles or {}
+    am_tap = [] if taps is not None else None
     Lv = len(multi_scale)
     d, nh = a["conv_dim"], a["nheads"]
     src, pos, sizes = [], [], []
@@ -217,7 +228,7 @@ def transformer_decoder(multi_scale, mask_features, sd, a, p="sem_seg_head.predi
     bs = src[0].shape[1]
     qe = sd[p + ".query_embed.weight"].unsqueeze(1).repeat(1, bs, 1)
     out = sd[p + ".query_feat.weight"].unsqueeze(1).repeat(1, bs, 1)
-    cls, masks, am = prediction_heads(out, mask_features, sizes[0], sd, a, p)
+    cls, masks, am = prediction_heads(out, mask_features, sizes[0], sd, a, p, toggles.get(0), am_tap)
     aux = [(cls, masks, am)]
     for i in range(a["dec_layers"]):
         li = i % Lv
@@ -236,10 +247,11 @@ def transformer_decoder(multi_scale, mask_features, sd, a, p="sem_seg_head.predi
         fp = f"{p}.transformer_ffn_layers.{i}"
         t2 = _lin(F.relu(_lin(out, sd, fp + ".linear1")), sd, fp + ".linear2")
         out = _ln(out + t2, sd, fp + ".norm")
-        cls, masks, am = prediction_heads(out, mask_features, sizes[(i + 1) % Lv], sd, a, p)
+        cls, masks, am = prediction_heads(out, mask_features, sizes[(i + 1) % Lv], sd, a, p, toggles.get(i + 1), am_tap)
         aux.append((cls, masks, am))
     if taps is not None:
         taps["aux"] = aux
+        taps["am_logits"] = am_tap
     return cls, masks
 
 
@@ -253,7 +265,7 @@ def ood_pred_head(mask_features, sd, p="sem_seg_head.predictor.ood_pred"):
 
 # ------------------------------------------------------------------------------ meta arch
 @torch.no_grad()
-def forward(image, sd, a, taps=None, canvas=None):
+def forward(image, sd, a, taps=None, canvas=None, toggles=None):
     """MaskFormer.forward inference branch (mask2former/maskformer_model.py:255-260, 290-333) for ONE image
     [3,h,w] (uint8 or float, 0..255) followed by get_RbA (evaluate_ood.py:143-150) and the argmax of
     support.py:385-388.  Returns dict(pred_logits, pred_masks, sem_seg, rba, argmax).
@@ -261,7 +273,7 @@ def forward(image, sd, a, taps=None, canvas=None):
     image, maskformer_model.py:257); default = the image's own size rounded up to 32."""
     mean = torch.tensor(PIXEL_MEAN).view(-1, 1, 1)
     std = torch.tensor(PIXEL_STD).view(-1, 1, 1)
-    x = (image.float() - mean) / std
+    x = (image.to(torch.get_default_dtype()) - mean) / std
     h, w = x.shape[-2:]
     H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
     if canvas is not None:
@@ -270,7 +282,7 @@ def forward(image, sd, a, taps=None, canvas=None):
     x = F.pad(x, (0, W - w, 0, H - h))[None]
     feats = resnet_backbone(x, sd, a) if a.get("resnet") else swin_backbone(x, sd, a)
     mask_features, multi_scale = pixel_decoder(feats, sd, a)
-    cls, masks = transformer_decoder(multi_scale, mask_features, sd, a, taps=taps)
+    cls, masks = transformer_decoder(multi_scale, mask_features, sd, a, taps=taps, toggles=toggles)
     up = R.upsample_bilinear(masks, (H, W))[0]
     sem = R.semantic_inference(cls[0], up)[:, :h, :w]
     if taps is not None:

@@ -187,12 +187,12 @@ def position_embedding_sine(h, w, num_pos_feats, temperature=10000.0):
     """PositionEmbeddingSine(normalize=True) for an all-valid h x w map -> [2*num_pos_feats, h, w]
     (transformer_decoder/position_encoding.py:29-52)."""
     ones = torch.ones(1, h, w)
-    y_embed = ones.cumsum(1, dtype=torch.float32)
-    x_embed = ones.cumsum(2, dtype=torch.float32)
+    y_embed = ones.cumsum(1, dtype=torch.get_default_dtype())
+    x_embed = ones.cumsum(2, dtype=torch.get_default_dtype())
     eps, scale = 1e-6, 2 * math.pi
     y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
     x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = torch.arange(num_pos_feats, dtype=torch.get_default_dtype())
     dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
     pos_x = x_embed[:, :, :, None] / dim_t
     pos_y = y_embed[:, :, :, None] / dim_t

@@ -74,17 +74,25 @@ def _err(a, b):
     return (a.detach().cpu().double() - b.double()).abs().max().item()
 
 
-def _threshold_margin(taps, a):
-    """smallest |logit| the reference's decoder thresholds at sigmoid < 0.5 (mask2former_transformer_decoder.py:483-487): a key whose logit is closer to 0 than fp32
-    re-association noise may be masked on one side and not on the other -- the reference's own discontinuity, reported, not a product error"""
-    import torch.nn.functional as F
-    aux = taps["aux"]
-    sizes = [tuple(x.shape[-2:]) for x in taps["multi_scale"]]
-    m = float("inf")
-    for i, (_, masks, _) in enumerate(aux[:-1]):
-        am = F.interpolate(masks, size=sizes[i % len(sizes)], mode="bilinear", align_corners=False)
-        m = min(m, am.abs().min().item())
-    return m
+def _explained_by_threshold(image, sd, a, taps, outs, h, w, tol, band=2e-5):
+    """The reference's decoder thresholds its interpolated mask logits at sigmoid < 0.5 (mask2former_transformer_decoder.py:483-487).  A logit within rounding noise
+    of 0 may fall on either side in two correct fp32 implementations, and the masked attention then differs by far more than 1e-4: the reference's own
+    discontinuity.  PROOF, not assumption: re-run the oracle with the decision of the near-zero entries (|logit| < band; the last head call's mask is never used)
+    inverted -- every subset of up to four of them -- and accept only if one of those runs reproduces every failing product output within `tol`."""
+    import itertools
+    logits = taps["am_logits"][:-1]
+    cand = [(ci, int(j)) for ci, l in enumerate(logits) for j in (l.abs().view(-1) < band).nonzero().flatten()]
+    if not cand or len(cand) > 4:
+        return False, f"{len(cand)} thresholded logits inside {band:.0e} of zero"
+    for n in range(1, len(cand) + 1):
+        for sub in itertools.combinations(cand, n):
+            toggles = {}
+            for ci, j in sub:
+                toggles.setdefault(ci, []).append(j)
+            ref_t = ref_model.forward(image, sd, a, toggles={k: torch.tensor(v) for k, v in toggles.items()})
+            if all(_check(o, ref_t, h, w, "", tol=tol)[0] for o in outs):
+                return True, f"inverting the threshold decision of {sub} (|logit| {[float(logits[ci].view(-1)[j].abs()) for ci, j in sub]}) reproduces the product"
+    return False, f"no inversion of {cand} reproduces the product"
 
 
 def _check(out, ref, h, w, what, tol=1e-4):
@@ -117,15 +125,36 @@ def _sweep_one(name, h, w, configs, canvas=None):
             ok, nums = _check(out, ref, h, w, what)
             assert torch.equal(rba2, out["rba"]) and torch.equal(arg2, out["argmax"]), what       # the score-only path of the evaluator = the dict path, bit for bit
             if not ok:
-                failures.append((what, nums))
+                failures.append((what, nums, {k: v.cpu() for k, v in out.items()}))
     finally:
         ops.set_concurrent_streams(prev_hint)
         model.fused_upsample = True
-    if failures:
-        margin = _threshold_margin(taps, a)
-        # a threshold logit inside 5e-5 of zero: the decoder's mask may legitimately differ (reference discontinuity); anything else is a product error
-        assert margin < 5e-5, f"{failures} (smallest thresholded |logit| in the reference {margin:.2e})"
-        pytest.skip(f"reference threshold discontinuity: smallest thresholded |logit| {margin:.2e}; {failures}")
+    if not failures:
+        return
+    # (1) is the SIZE ill-conditioned for fp32 itself?  A 32 x 32 canvas leaves 1 x 1 / 2 x 2 maps: GroupNorm(32) over two values, LayerNorm over near-equal rows --
+    # the reference's own fp32 forward is then 1e-4 ... 4e-4 from the float64 forward of the same weights (measured: tiny3 at 5 x 7, 13 x 11, 32 x 32).  The product
+    # must be as close to the float64 truth as the reference's fp32 is (factor 3), and never worse than 1e-4 where the reference is better than that.
+    ref64 = _truth64(image, sd, a)
+    own = max(_err(ref["sem_seg"], ref64["sem_seg"]), _err(ref["rba"], ref64["rba"]))
+    tol = max(1e-4, 3 * own)
+    ref64f = {k: (v.float() if v.is_floating_point() else v) for k, v in ref64.items()}
+    still = [(what, nums, out) for what, nums, out in failures if not _check(out, ref64f, h, w, "", tol=tol)[0]]
+    if not still:
+        return
+    # (2) the reference's threshold discontinuity, demonstrated by re-running the oracle with the near-zero decisions inverted
+    ok, why = _explained_by_threshold(image, sd, a, taps, [o for _, _, o in still], h, w, tol)
+    assert ok, f"{[(what, nums) for what, nums, _ in still]}: vs float64 truth tol {tol:.1e} (reference fp32 is {own:.1e} from it); {why}"
+    print(f"[sweep] {name} {h}x{w}: {[what for what, _, _ in still]} differ from the reference through its own threshold discontinuity: {why}")
+
+
+def _truth64(image, sd, a):
+    """the oracle in float64 on the same weights: how far the reference's own fp32 forward is from exact arithmetic at this size"""
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        return ref_model.forward(image.double(), sd64, a)
+    finally:
+        torch.set_default_dtype(torch.float32)
 
 
 ALL_CONFIGS = [(1, "f16x3"), (3, "f16x3"), (1, "bf16x6"), (3, "bf16x6")]
@@ -231,8 +260,8 @@ def test_size_sweep_real_widths(name, h, w):
 
 @pytest.mark.parametrize("name,h,w", [("wide_b", 352, 1216), ("wide_b", 192, 672), ("wide_l", 256, 736), ("wide_l", 352, 1216), ("wide_b", 363, 637)])
 def test_forced_launch_forms_do_not_change_a_bit(knobs, name, h, w):
-    """knobs build: the 256 x 128 form always / from 64 tiles / never, the K-split form wherever legal / never -- same bits as the rule-selected forms, and no
-    guard band touched in any of them"""
+    """knobs build: the 256 x 128 form always / from 64 tiles / never -- same bits as the rule-selected forms; the K-split form wherever legal / never -- same
+    result to the last bits' summation order; no guard band touched in any of them"""
     from rba_amd import _lib
     model, a, sd = _model(name)
     image = _image(h, w).cuda()
@@ -243,8 +272,16 @@ def test_forced_launch_forms_do_not_change_a_bit(knobs, name, h, w):
         for rs, ks in ((1, 1), (2, 0), (3, 0), (0, 2), (2, 2), (3, 1)):
             k_rs.value, k_ks.value = rs, ks
             out = model([{"image": image}], return_argmax=True)[0]
-            for k in ("sem_seg", "rba", "argmax"):
-                assert torch.equal(out[k], base[k]), (name, h, w, rs, ks, k)
+            if ks == 0 or (rs, ks) == (1, 1):
+                for k in ("sem_seg", "rba", "argmax"):           # the row-split forms (and no special form at all... where the rule picked none) are bit-identical
+                    if not torch.equal(out[k], base[k]):
+                        assert ks == 1, (name, h, w, rs, ks, k)  # ks = 1 removes the K-split form where the rule chose it: last bits may move (below)
+            # the K-split form sums the two halves of K in its own fixed order: last bits differ from the one-set kernel BY DESIGN (split_linear_h3.h:1020-1025;
+            # test_split_linear_k_split_form holds both to the same fp64 bound) -- end to end that stays far inside the parity budget
+            assert _err(out["sem_seg"], base["sem_seg"].cpu()) < 2e-5 and _err(out["rba"], base["rba"].cpu()) < 5e-5, (name, h, w, rs, ks)
+            top2 = base["sem_seg"].topk(2, dim=0).values
+            flips = out["argmax"] != base["argmax"]
+            assert int((flips & ((top2[0] - top2[1]) > 1e-4)).sum()) == 0, (name, h, w, rs, ks)
     finally:
         k_rs.value, k_ks.value = 0, 0
 
