@@ -36,17 +36,15 @@ __device__ __forceinline__ f32x2 rba_sigmoid2(f32x2 x) {
 
 // ReLU that PRESERVES NaN (fmaxf(NaN, 0) is 0): the f16x3 kernels answer an out-of-range operand with NaN, and that NaN must reach the score map, where
 // the evaluator's finiteness check sends the image to the full-range bf16x6 kernels -- a ReLU that swallowed it would turn a loud failure into a finite,
-// wrong score.  Arithmetic form: max(x, 0) + (x - x); x - x is +0 for every finite x and NaN for NaN (and for +-inf, which no kernel of this library
-// produces legitimately: an infinity is an overflow and becomes just as loud).  Two VALU instructions, no lane mask.
-//
-// Why not `x < 0 ? 0 : x`: no reason left.  Round 5 first blamed compare + select forms for wrong rows in the GroupNorm fold of split_linear_h3l_kernel; the
-// ReLU's form only moved the compiler's register allocation.  What went wrong was one packed multiply of that fold, `v_pk_mul_f32 ... op_sel:[0,1]` (cross select
-// on source 1), found by editing the failing build's assembly one instruction at a time (tools/gnf_asm_probe.py, profiles/r05_gnfold_select.txt,
-// csrc/split_linear_gnf.hip).  The arithmetic form stays: it is two instructions and needs no lane mask.
-__device__ __forceinline__ float rba_relu(float x) { return fmaxf(x, 0.f) + (x - x); }
+// wrong score.  Round 6: compare + select, `x != x ? x : max(x, floor)` -- exactly torch.relu for every input: relu(+inf) = +inf, relu(-inf) = 0,
+// and with the activation off (floor = -inf) the value passes untouched, -inf and -0.0 included.  Rounds 4-5 used the arithmetic form max(x, 0) + (x - x), which
+// also turned +-inf into NaN and -0.0 into +0.0 on the no-activation path.  Three VALU instructions either way.  (Round 5 once blamed compare + select forms for
+// wrong rows in the GroupNorm fold; the cause was one packed multiply, `v_pk_mul_f32 ... op_sel:[0,1]` -- tools/gnf_asm_probe.py, csrc/split_linear_gnf.hip --
+// and the build now refuses a library that contains that form: isa_hazards.gate.)
+__device__ __forceinline__ float rba_relu(float x) { return x != x ? x : fmaxf(x, 0.f); }
 // The same under a run-time (workgroup-uniform) switch: floor = rba_relu_floor(on) once, then rba_clamp_below(x, floor) per value.
 __device__ __forceinline__ float rba_relu_floor(bool on) { return on ? 0.f : -INFINITY; }
-__device__ __forceinline__ float rba_clamp_below(float x, float floor) { return fmaxf(x, floor) + (x - x); }
+__device__ __forceinline__ float rba_clamp_below(float x, float floor) { return x != x ? x : fmaxf(x, floor); }
 
 // tanh(x) = sign(x) * (1 - 2 / (e^{2|x|} + 1)); e^{2|x|} -> inf gives exactly 1.
 __device__ __forceinline__ float rba_tanh(float x) {

@@ -177,7 +177,7 @@ class PatchEmbed(nn.Module):
         # one gather + the library's GEMM (ops.linear pads K = 48 to 64) -- no MIOpen call on this path either (round 5)
         B, Cin, H, W = x.shape
         Wh, Ww = H // ps, W // ps
-        cols = x.view(B, Cin, Wh, ps, Ww, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, Wh * Ww, Cin * ps * ps).contiguous()
+        cols = x.reshape(B, Cin, Wh, ps, Ww, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, Wh * Ww, Cin * ps * ps).contiguous()     # reshape: channels_last / sliced inputs too, as conv2d took them
         w = self.proj.weight
         key = (w.data_ptr(), w._version, w.device)
         c = getattr(self, "_rba_lin", None)

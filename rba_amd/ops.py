@@ -617,6 +617,21 @@ def __getattr__(name):                     # module attribute: ops.SPLIT_MODE = 
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
+class _OpsModule(type(os)):
+    """`ops.SPLIT_MODE = "bf16x6"` was the supported switch until round 4.  Since the mode became per thread an assignment only created a module attribute that
+    SHADOWED the getter above: ops.SPLIT_MODE then read "bf16x6" (graph keys, cache names) while every kernel kept dispatching on the thread's real mode -- a NaN
+    re-score written the old way was a silent no-op.  Assignment now fails loudly."""
+
+    def __setattr__(self, name, value):
+        if name == "SPLIT_MODE":
+            raise AttributeError('ops.SPLIT_MODE is read-only (the arithmetic mode is per thread): run the block inside `with ops.split_mode("bf16x6"):`')
+        super().__setattr__(name, value)
+
+
+import sys as _sys  # noqa: E402
+_sys.modules[__name__].__class__ = _OpsModule
+
+
 @_hip_op
 def split_weight(weight, mode=None):
     """fp32 weight [N,K] -> the packed operand planes of the token Linear, tiled as the kernel's LDS image (once per weight load):
@@ -1064,7 +1079,7 @@ TOKEN_LINEAR = os.environ.get("RBA_TOKEN_LINEAR", "1") != "0"      # A/B switch 
 
 def token_linear_ok(N, K):
     """Shapes the row-complete token Linear serves (csrc/token_linear.hip): N <= 256 outputs, K a multiple of 32; f16x3 arithmetic only
-    (ops.SPLIT_MODE == "bf16x6", the full-range fallback, keeps the library GEMM)."""
+    (under ops.split_mode("bf16x6"), the full-range fallback, these Linears run the bf16x6 K6 kernel instead -- no library GEMM on any path since round 5)."""
     return TOKEN_LINEAR and _split_mode() == "f16x3" and 1 <= N <= 256 and K >= 32 and K % 32 == 0
 
 

@@ -96,8 +96,8 @@ class OODEvaluator:
         NaN scores: the f16x3 token Linears answer |value| >= 65504 with NaN (never a wrong number, never +-inf); once per CHUNK of images a
         fused `isnan` flag per image is read back, and an image whose score holds a NaN is scored again on the full-range bf16x6
         kernels before anything reaches the rank statistics (FloatingPointError if that one holds a NaN too).  An INFINITE score of a custom
-        score function is passed on, as the reference passes it on.  The re-score flips ops.SPLIT_MODE, a process global: this loop, like
-        the reference's, is single-threaded -- do not score on other threads of the process meanwhile (ops.split_mode is not thread-safe)."""
+        score function is passed on, as the reference passes it on.  The re-score runs inside `ops.split_mode("bf16x6")`: the
+        mode is per THREAD (round 5), other threads of the process keep scoring on their own mode."""
         anomaly_score, ood_gts, predictions = [], [], []
         on_gpu = torch.device(device).type == "cuda"
         if on_gpu:

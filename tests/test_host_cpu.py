@@ -322,6 +322,9 @@ def test_split_activations_layout_and_predicate():
             th.start(); th.join()
             assert seen == ["f16x3"]
         assert ops.SPLIT_MODE == "f16x3"
+        with pytest.raises(AttributeError, match="split_mode"):                  # the pre-round-5 switch must fail loudly, not shadow the getter
+            ops.SPLIT_MODE = "bf16x6"
+        assert ops.SPLIT_MODE == "f16x3"
 
 
 def test_shape_cache_pins_what_a_capture_reads(monkeypatch):
@@ -480,3 +483,85 @@ def test_registries_hold_the_reference_names():
                        (R.TRANSFORMER_DECODER_REGISTRY, ["MultiScaleMaskedTransformerDecoder"])):
         for n in names:
             assert isinstance(reg.get(n), type) or callable(reg.get(n)), n
+
+
+def _write_d2_checkpoints(folder, sd):
+    """the three on-disk forms a released / converted checkpoint comes in: Detectron2's periodic checkpointer (`model_final.pth`: model + optimizer + scheduler +
+    iteration, detectron2/checkpoint via fvcore Checkpointer.save), the model-zoo `.pkl` (numpy arrays, `__author__`, `matching_heuristics`), and the `.pkl` the
+    reference's own converter writes -- torch tensors inside a plain pickle (tools/convert-pretrained-swin-model-to-d2.py:22-30)"""
+    import pickle
+    os.makedirs(folder, exist_ok=True)
+    opt = {"state": {0: {"step": torch.tensor(90000.0), "exp_avg": torch.zeros(3)}}, "param_groups": [{"lr": 1e-4, "params": [0]}]}
+    torch.save({"model": dict(sd, **{"criterion.empty_weight": torch.ones(20)}), "optimizer": opt, "scheduler": {"last_epoch": 90000, "_step_count": 90001},
+                "iteration": 89999}, os.path.join(folder, "model_final.pth"))
+    with open(os.path.join(folder, "numpy.pkl"), "wb") as f:
+        pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "third_party", "matching_heuristics": True}, f)
+    with open(os.path.join(folder, "tensors.pkl"), "wb") as f:
+        pickle.dump({"model": dict(sd), "__author__": "third_party", "matching_heuristics": True}, f)
+
+
+def test_model_zoo_check_table_checkpoint_formats_and_comparison(tmp_path, capsys):
+    """tools/model_zoo_check.py (SURVEY 8(f) f1 made turnkey): (1) its table IS the reference's MODEL_ZOO.md (parsed here when the reference tree is present);
+    (2) the checkpoint files exactly as Detectron2 and the reference's converter write them load into the model on the CPU, key for key; (3) the comparison:
+    published vs results.pkl in percentage points, exit status, missing entries, --dry-run -- everything except the GPU run itself (tests/test_model_gpu.py)."""
+    import pickle
+    import re
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import model_zoo_check as Z
+    from rba_amd import arch as A
+    from rba_amd.checkpoint import load_checkpoint, read_state_dict
+    from rba_amd.maskformer_model import MaskFormer
+    # (1) the table
+    zoo = "/root/reference/MODEL_ZOO.md"
+    if os.path.exists(zoo):
+        txt = open(zoo).read()
+        rows = re.findall(r'<tr><td align="left">.*?</tr>', txt, flags=re.S)
+        got = {}
+        for r in rows:
+            cfg = re.search(r'ckpts/([a-z0-9_]+)/config.yaml', r).group(1)
+            nums = [float(x) for x in re.findall(r'<td align="center">([0-9.]+)</td>', r)]
+            got[cfg] = nums[-4:]                                   # ..., RA AP, RA FPR95, FS-LaF AP, FS-LaF FPR95
+        assert sorted(got) == sorted(Z.MODEL_ZOO)
+        for m, (ra_ap, ra_fpr, fs_ap, fs_fpr) in got.items():
+            t = Z.MODEL_ZOO[m]
+            assert (t["road_anomaly"]["aupr"], t["road_anomaly"]["fpr95"], t["fishyscapes_laf"]["aupr"], t["fishyscapes_laf"]["fpr95"]) == (ra_ap, ra_fpr, fs_ap, fs_fpr), m
+    assert Z.MODEL_ZOO["swin_b_1dl"]["road_anomaly"] == {"aupr": 78.45, "fpr95": 11.83}          # BASELINE.json's target row
+    # (2) checkpoint formats
+    a = A.complete(A.ARCHS["tiny1"])
+    sd = A.seeded_weights(a, 0)
+    ck = tmp_path / "ck"
+    _write_d2_checkpoints(str(ck), sd)
+    want = load_checkpoint(MaskFormer(a), sd).state_dict()
+    for fname, trusted in (("model_final.pth", False), ("numpy.pkl", False), ("tensors.pkl", True)):
+        got_sd = load_checkpoint(MaskFormer(a), str(ck / fname), trusted=trusted).state_dict()
+        assert sorted(got_sd) == sorted(want) and all(torch.equal(got_sd[k], want[k]) for k in want), fname
+    with pytest.raises(pickle.UnpicklingError, match="RBA_TRUSTED_CHECKPOINT"):
+        read_state_dict(str(ck / "tensors.pkl"))                                               # torch tensors in a pickle: refused unless trusted
+    # (3) the comparison
+    models = tmp_path / "ckpts"
+    for m in ("swin_b_1dl", "swin_l_1dl", "not_in_the_table"):
+        (models / m).mkdir(parents=True)
+        (models / m / "config.yaml").write_text("MODEL: {}\n")
+    (models / "swin_b_1dl" / "model_final.pth").write_bytes(b"")
+    out = tmp_path / "results"
+    (out / "swin_b_1dl").mkdir(parents=True)
+    exact = {ds: {k: v / 100.0 for k, v in Z.MODEL_ZOO["swin_b_1dl"][ds].items()} for ds in Z.DATASETS}
+    exact["road_anomaly"]["auroc"] = 0.97
+    with open(out / "swin_b_1dl" / "results.pkl", "wb") as f:
+        pickle.dump(exact, f)
+    base = ["--models_folder", str(models), "--datasets_folder", str(tmp_path), "--out_path", str(out), "--selected_models", "swin_b_1dl"]
+    assert Z.main(base + ["--dry-run"]) == 0
+    assert "swin_b_1dl: config.yaml found, checkpoint" in capsys.readouterr().out
+    assert Z.main(base + ["--results-only"]) == 0
+    txt = capsys.readouterr().out
+    assert "4 of 4 published numbers reproduced" in txt and "78.45" in txt
+    exact["road_anomaly"]["aupr"] += 0.0004                                                    # 0.04 percentage points: outside 0.005, inside "three decimals"
+    with open(out / "swin_b_1dl" / "results.pkl", "wb") as f:
+        pickle.dump(exact, f)
+    assert Z.main(base + ["--results-only"]) == 1
+    assert "DIFFERS" in capsys.readouterr().out
+    assert Z.main(base + ["--results-only", "--tolerance", "0.05"]) == 0
+    capsys.readouterr()
+    assert Z.main(["--models_folder", str(models), "--out_path", str(out), "--results-only"]) == 1          # swin_l_1dl has no results.pkl: MISSING rows
+    assert "MISSING" in capsys.readouterr().out
+    assert Z.main(["--models_folder", str(models), "--out_path", str(out), "--selected_models", "not_in_the_table", "--results-only"]) == 2

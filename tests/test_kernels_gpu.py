@@ -622,6 +622,22 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias, knobs):
     assert torch.equal(old, out) and torch.equal(new, out)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+def test_relu_helpers_follow_torch_for_infinities_and_nan(ops, relu):
+    """csrc/common.h's rba_relu / rba_clamp_below answered +-inf with NaN (max(x, floor) + (x - x)).  Round 6: compare + select -- exactly
+    torch.relu / identity for +inf, -inf, NaN, -0.0.  Driven through the bias of the skinny Linear (one row of zeros -> the output IS the bias after the
+    activation) and of the row-complete token Linear."""
+    vals = torch.tensor([float("inf"), float("-inf"), float("nan"), -0.0, 0.0, -3.5, 2.25, 1e-30] * 4)
+    N, K = vals.numel(), 64
+    x, w = torch.zeros(5, K), torch.randn(N, K)
+    out = ops.skinny_linear(dev(x), dev(w), dev(vals), relu).cpu()
+    want = (torch.relu(vals) if relu else vals).expand(5, N)
+    assert torch.equal(torch.isnan(out), torch.isnan(want))
+    assert torch.equal(out.nan_to_num(7.0), want.nan_to_num(7.0))            # +-inf kept, -inf -> 0 under ReLU
+    if not relu:
+        assert torch.equal(torch.signbit(out), torch.signbit(want))           # -0.0 passes untouched when there is no activation
+
+
 @pytest.mark.parametrize("M,E,K", [(100, 256, 256), (100, 64, 2048), (37, 32, 64), (128, 256, 256)])
 def test_skinny_linear_position_add_and_segments(ops, M, E, K, knobs):
     """the q / k / v projections of a decoder self-attention layer as ONE launch over the stacked in_proj weight: columns < 2E see x + x_add,

@@ -892,3 +892,50 @@ def test_model_with_captured_graphs_can_be_deep_copied_and_never_thrashes():
     assert churn.live_graphs() == n_before                                  # no new capture any more
     churn.drop_graphs()
     assert churn.__dict__.get("_graph_thrash", 0) == 0
+
+
+def test_model_zoo_check_tool_end_to_end(tmp_path, monkeypatch, capsys):
+    """tools/model_zoo_check.py on a models folder laid out as MODEL_ZOO.md:8-19 -- `swin_b_1dl/` holding Detectron2's model_final.pth (model + optimizer +
+    scheduler + iteration), `swin_l_1dl/` holding only a model-zoo style model_final.pkl (numpy arrays) -- and synthetic RoadAnomaly / Fishyscapes-LaF trees: the
+    tool runs the evaluator, reads results.pkl and compares with a table (here: the oracle's CPU forward + scikit-learn on the same files, in percent) at the
+    default 0.005 percentage points; a table that is off by 0.1 fails with exit status 1.  With the released weights the same command checks MODEL_ZOO.md itself."""
+    import json
+    import sys
+    import yaml
+    from oracle import ref_metrics
+    from tests.test_datasets_cpu import make_fs_laf, make_road_anomaly
+    from tests.test_host_cpu import _write_d2_checkpoints
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import model_zoo_check as Z
+    a = A.complete(A.ARCHS["tiny1"])
+    cfg = {"MODEL": {"SWIN": {"EMBED_DIM": 32, "DEPTHS": [2, 2, 2, 2], "NUM_HEADS": [1, 2, 4, 8], "WINDOW_SIZE": 6},
+                     "SEM_SEG_HEAD": {"CONVS_DIM": 64, "MASK_DIM": 64, "TRANSFORMER_ENC_LAYERS": 2, "DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES": ["res5"]},
+                     "MASK_FORMER": {"HIDDEN_DIM": 64, "NHEADS": 2, "NUM_OBJECT_QUERIES": 16, "DIM_FEEDFORWARD": 128, "DEC_LAYERS": 2}}}
+    data = tmp_path / "data"
+    ra_imgs, ra_labs = make_road_anomaly(str(data), h=48, w=80)
+    fs_imgs, fs_labs = make_fs_laf(str(data), h=40, w=72)
+    expected = {}
+    for model_name, seed in (("swin_b_1dl", 0), ("swin_l_1dl", 1)):
+        sd = A.seeded_weights(a, seed)
+        mdir = tmp_path / "ckpts" / model_name
+        _write_d2_checkpoints(str(mdir), sd)
+        (mdir / "config.yaml").write_text(yaml.safe_dump(cfg))
+        os.remove(mdir / "tensors.pkl")
+        if model_name == "swin_l_1dl":
+            os.remove(mdir / "model_final.pth")
+            os.rename(mdir / "numpy.pkl", mdir / "model_final.pkl")
+        expected[model_name] = {}
+        for name, imgs, labs in (("road_anomaly", ra_imgs, [(l == 2).astype(np.int64) for l in ra_labs]), ("fishyscapes_laf", fs_imgs, [l.astype(np.int64) for l in fs_labs])):
+            scores = np.stack([ref_model.forward(torch.from_numpy(im.transpose(2, 0, 1).copy()), sd, a)["rba"].numpy() for im in imgs])
+            m = ref_metrics.evaluate_ood(scores, np.stack(labs)[:, None])
+            expected[model_name][name] = {"aupr": 100.0 * m["aupr"], "fpr95": 100.0 * m["fpr95"]}
+    (tmp_path / "expected.json").write_text(json.dumps(expected))
+    monkeypatch.chdir(tmp_path)
+    argv = ["--models_folder", str(tmp_path / "ckpts"), "--datasets_folder", str(data), "--out_path", str(tmp_path / "zoo"), "--expected", str(tmp_path / "expected.json")]
+    assert Z.main(argv) == 0
+    txt = capsys.readouterr().out
+    assert "8 of 8 published numbers reproduced within 0.005" in txt, txt
+    expected["swin_l_1dl"]["road_anomaly"]["aupr"] += 0.1
+    (tmp_path / "expected.json").write_text(json.dumps(expected))
+    assert Z.main(argv + ["--results-only"]) == 1
+    assert "DIFFERS" in capsys.readouterr().out
