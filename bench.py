@@ -66,7 +66,7 @@ def parse():
                     help="N = 1 only: initialise a ONE-rank RCCL process group and run the metric-exchange leg through its collectives (all_gather of sizes + "
                          "all_gather_into_tensor of device tensors), so that a 1-GPU box executes the code an N > 1 run executes")
     ap.add_argument("--cpu-baseline", choices=["quick", "full"], default="quick",
-                    help="quick (default, <= ~15 s): ONE full-size forward of the oracle at the pre-chosen thread count + the isolated reduction; "
+                    help="quick (default, <= ~25 s): THREE full-size forwards (median) of the oracle at the pre-chosen thread count + the isolated reduction; "
                          "full: BASELINE.md section 3's protocol with the thread sweep, C1's size and one-thread legs (~50 s; also tools/cpu_baseline_sweep.py)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="thread count of the quick cpu_baseline (16 = the sweep's best on 2 x EPYC 9575F)")
     ap.add_argument("--cpu-budget", type=float, default=1.0, help="scale of the wall-time bounds of the cpu_baseline legs")
@@ -231,7 +231,7 @@ def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0, mode="quick"
         rec["cpu_model"] = None
 
     if mode == "quick":
-        # ONE full-size forward at the pre-chosen thread count (the full protocol's sweep picks 16 on the driver's 2 x 64-core EPYC 9575F: 5.7 s;
+        # THREE full-size forwards (median; one until round 5) at the pre-chosen thread count (the full protocol's sweep picks 16 on the driver's 2 x 64-core EPYC 9575F: 5.7 s;
         # `--cpu-baseline full` / tools/cpu_baseline_sweep.py re-derive it) + the isolated reduction: ~10 s, so that the bench's wall time is the
         # GPU's, not the baseline's
         t = max(1, min(threads, ncpu))
@@ -242,11 +242,11 @@ def cpu_baseline(arch_name, h, w, k1_gpu_ms=None, budget_scale=1.0, mode="quick"
 
         def fwd():
             out["o"] = ref_model.forward(image, sd, a)
-        full = _timed_runs(fwd, 1, 0)
+        full = _timed_runs(fwd, 3, 20.0 * budget_scale)                    # round 6: median of three runs (a single sample moved by 10 % between boxes)
         assert out["o"]["rba"].shape == (h, w)
-        rec.update(value=1.0 / full[0], cores=t, runs_s=full, protocol="quick",
-                   sample=f"1 run of 1 image 3x{h}x{w}, full forward + RbA score, torch CPU fp32, {t} threads (pre-chosen: best of the sweep in "
-                          f"tools/cpu_baseline_sweep.py on 2 x EPYC 9575F), {full[0]:.2f} s; warm-up = one 256x512 forward")
+        rec.update(value=1.0 / _med(full), cores=t, runs_s=full, protocol="quick",
+                   sample=f"{len(full)} run(s) of 1 image 3x{h}x{w}, full forward + RbA score, torch CPU fp32, {t} threads (pre-chosen: best of the sweep in "
+                          f"tools/cpu_baseline_sweep.py on 2 x EPYC 9575F), median {_med(full):.2f} s; warm-up = one 256x512 forward")
         Q, K = a["num_queries"], a["num_classes"]
         H, W = (h + 31) // 32 * 32, (w + 31) // 32 * 32
         g0 = torch.Generator().manual_seed(0)
@@ -386,6 +386,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args)
     share = os.environ.get("RBA_BENCH_SHARE_DEVICE") == "1"
+    launch_local = int(os.environ.get("LOCAL_RANK", "0"))          # this process's slot on the node (kept: the share-device plumbing mode rewrites LOCAL_RANK)
     if share:                                    # ranks share device 0: gloo (RCCL refuses two ranks on one device)
         os.environ["LOCAL_RANK"] = "0"
     if args.rccl_one_rank and "WORLD_SIZE" not in os.environ:      # 1-GPU box: a ONE-rank RCCL group, so that the exchange leg below runs its collectives on RCCL itself
@@ -399,6 +400,9 @@ def main():
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
+    # one process per GPU: pin each rank to its share of the cores next to its GPU (rba_amd.distributed.bind_rank_to_gpu_numa) -- the launch thread of a rank
+    # issues ~255 kernels per image and must not migrate across sockets or share cores with seven other ranks
+    affinity = D.bind_rank_to_gpu_numa(launch_local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else {"bound": False, "cpus": None, "source": None}
     dev = torch.device("cuda", local)
     dist = torch.distributed if (world > 1 or (args.rccl_one_rank and torch.distributed.is_initialized())) else None
     n_ranks_seen, backend_seen = 1, None
@@ -467,15 +471,17 @@ def main():
         prob = torch.softmax(mask_cls[0], dim=-1)[..., :-1].contiguous()
         return prob, mask_pred[0].contiguous(), sizes[0], padded
 
+    k1_mode = {"v": args.k1}             # the extra legs after the timed region switch it (value_up4)
+
     def post_part(prob, low, size, padded, record=True):
         """x4 mask upsample + K1 (or the fused up4 K1); HIP events bracket exactly the K1 launch"""
-        if args.k1 == "up4":
+        if k1_mode["v"] == "up4":
             ev = _timed(record, lambda: ops.rba_reduce_up4(low, prob, size))
         else:
             up = ops.resample_bilinear(low, padded)
             ev = _timed(record, lambda: ops.rba_reduce(up, prob))
         rba = ev[2][0]
-        if args.k1 != "up4" and size != padded:
+        if k1_mode["v"] != "up4" and size != padded:
             rba = rba[: size[0], : size[1]]
         k1_probe["ev"] = ev[:2] if record else None
         return rba
@@ -517,14 +523,18 @@ def main():
 
     # --graph with several streams: one captured graph of predict_part per stream (the K1 part stays eager on the main stream so that
     # its HIP events keep bracketing exactly the K1 launch)
-    part_graphs = None
-    if args.graph and S > 1:
-        graph = None
+    main_streams = {}
+
+    def capture_parts():
+        """one hipGraph per stream of the step (predict_part, and for the streams beyond --k1-alone also their upsample + K1), in the CURRENT arithmetic mode and
+        K1 form; None when the capture fails"""
         try:
             part_graphs = []
             with torch.no_grad():
                 for j in range(S):
-                    st = (part_streams[0] if part_streams else torch.cuda.Stream()) if j == 0 else side_streams[j - 1]
+                    if j == 0 and 0 not in main_streams:
+                        main_streams[0] = part_streams[0] if part_streams else torch.cuda.Stream()
+                    st = main_streams[0] if j == 0 else side_streams[j - 1]
                     st.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(st):
                         predict_part(static_ins[j])                      # warm the stream's allocator pool
@@ -543,11 +553,17 @@ def main():
                             outs = post_part(*outs, record=False)
                     torch.cuda.synchronize()
                     part_graphs.append((gj, st, outs, whole))
+            return part_graphs
         except Exception as e:
             if rank == 0:
                 print(f"[bench] per-stream hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            part_graphs = None
             torch.cuda.synchronize()
+            return None
+
+    part_graphs = None
+    if args.graph and S > 1:
+        graph = None
+        part_graphs = capture_parts()
 
     def step(i):
         if part_graphs is not None:
@@ -612,7 +628,13 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_busy_s = ev_first.elapsed_time(ev_last) * 1e-3   # device-side span of the timed steps, first launch to last completion
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = None
     if dist is not None:
+        # every rank's own clock over the same K steps (between the same two barriers) and the number of CPUs it is pinned to: the line reports min / max
+        mine = torch.tensor([elapsed, float(affinity["cpus"] or 0)], dtype=torch.float64, device=dev if backend_seen == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [(float(e[0]), int(e[1])) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert out.shape == (h, w) and bool(torch.isfinite(out).all())
@@ -676,6 +698,50 @@ def main():
         sustained = {"images_per_s": n_all * S / sus_s, "seconds": sus_s, "steps": n_sus, **cs.summary(),
                      "what": "the timed step loop continued for --sustain seconds after the K counted steps (same streams, graphs and K1 launches; "
                              "whole job, slowest rank's clock); clock = rank 0's GPU"}
+
+    # ---- extra legs (round 6), after the counted region and outside `value`: the SAME step loop (same streams, graphs, barriers, slowest rank's
+    # clock) (a) with the product's default K1 path -- the reduction fused with the x4 up-sample -- instead of the HBM-bound full-resolution K1 the metric
+    # names, (b) in the full-range bf16x6 arithmetic (what a re-scored image costs; <= 5 s)
+    extra_values = {}
+    out = out.clone()
+
+    def timed_leg(n_steps):
+        n0 = len(k1_events)
+        for i_ in range(2):
+            step(i_)
+        barrier()
+        t1_ = time.perf_counter()
+        for i_ in range(n_steps):
+            step(2 + i_)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t1_], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        del k1_events[n0:]
+        return world * n_steps * S / float(tt.item())
+
+    if part_graphs is not None and not os.environ.get("RBA_BENCH_NO_EXTRA_LEGS"):
+        default_graphs = part_graphs
+        try:
+            if args.k1 == "fullres":
+                k1_mode["v"] = "up4"
+                part_graphs = capture_parts()
+                if part_graphs is not None:
+                    extra_values["value_up4"] = timed_leg(args.steps)
+                k1_mode["v"] = args.k1
+            if ops.SPLIT_MODE == "f16x3":
+                with ops.split_mode("bf16x6"), torch.no_grad():
+                    forward_once(record=False)                              # packs the bf16 weight planes
+                    torch.cuda.synchronize()
+                    part_graphs = capture_parts()
+                    if part_graphs is not None:
+                        extra_values["value_bf16x6"] = timed_leg(max(5, min(args.steps, 20)))
+        except Exception as e:                                              # informational only
+            print(f"[bench] extra legs skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        finally:
+            k1_mode["v"] = args.k1
+            part_graphs = default_graphs
+        torch.cuda.synchronize()
 
     # ---- pooled OoD metric exchange over RCCL, outside the timed region
     exch_ms = None
@@ -750,7 +816,7 @@ def main():
     # get_RbA / get_logits read out[0]["sem_seg"], maskformer_model.py:381-386), + the int32 argmax map (support.py:385-388)
     k1_forms = None
     k1_up4_forms = None
-    single, single_windows = None, {}
+    single, single_windows, single_policy = None, {}, None
     if rank == 0:
         try:
             with torch.no_grad():
@@ -802,10 +868,11 @@ def main():
             if "RBA_K6_RS" not in os.environ:
                 ops.set_concurrent_streams(1)                          # one image at a time from here on
             prev_fused = model.fused_upsample
-            for label, replay in (("eager", False), ("model_graph_replay", True)):
-                model.graph_replay = replay
+            for label, replay in (("eager", False), ("model_graph_replay", True), ("model_default", "auto")):
+                model.drop_graphs()
+                model.graph_replay = replay                                # "auto" = the product default: replay only where measured to be launch-bound
                 model.fused_upsample = True                                # the product default of rba_scores (K1-up4)
-                for i in range(3):
+                for i in range(4):
                     model.rba_scores([{"image": images[i % len(images)]}])
                 torch.cuda.synchronize()
                 wins = []
@@ -817,11 +884,41 @@ def main():
                     wins.append(n1 / (time.perf_counter() - t1))
                 single[label] = sorted(wins)[1]
                 single_windows[label] = wins
+            single_policy = [dict(v, shape=list(k[0])) for k, v in model.graph_decisions().items()]
             model.fused_upsample = prev_fused
-            model.graph_replay = True
+            model.graph_replay = "auto"
             model.drop_graphs()
         except Exception as e:
             print(f"[bench] single-stream probe skipped ({type(e).__name__}: {e})", file=sys.stderr)
+
+    # ---- parity of THIS build on the bench's own configuration against the committed fixture of the reference's output (tests/golden/g5_*: the complete argmax
+    # map, the indices of the reference's near-tie pixels, a 64 x 128 grid of exact rba values -- data, generated by tests/golden/make_golden.py from the
+    # reference's modules): the flips the line's `value` comes with.  Same numbers as tests/test_model_gpu.py::_full_size asserts on.
+    parity = None
+    fixture = os.path.join(REPO, "tests", "golden", f"g5_{args.arch}_{h}x{w}.npz")
+    if rank == 0 and os.path.exists(fixture):
+        try:
+            import numpy as np
+            gfx = np.load(fixture, allow_pickle=False)
+            if int(gfx["seed"]) == 0 and ("recipe" not in gfx or str(gfx["recipe"]) == "base"):
+                gimg = torch.Generator().manual_seed(int(gfx["img_seed"]))
+                pimg = torch.randint(0, 256, (3, h, w), generator=gimg, dtype=torch.uint8).to(dev)
+                prev_replay, model.graph_replay = model.graph_replay, False
+                with torch.no_grad():
+                    rba_p, arg_p = model.rba_scores([{"image": pimg}], return_argmax=True)[0]
+                model.graph_replay = prev_replay
+                ref_arg = torch.from_numpy(gfx["argmax_full"].astype(np.int64)).to(dev)
+                tie = torch.zeros(h * w, dtype=torch.bool, device=dev)
+                tie[torch.from_numpy(gfx["neartie_idx"]).long().to(dev)] = True
+                flips = (arg_p.long() != ref_arg).flatten()
+                gy, gx = torch.from_numpy(gfx["gy"]).long().to(dev), torch.from_numpy(gfx["gx"]).long().to(dev)
+                e_grid = (rba_p[gy][:, gx].double().cpu() - torch.from_numpy(gfx["grid_rba"]).double()).abs().max().item()
+                parity = {"fixture": os.path.basename(fixture), "pixels": h * w, "argmax_flips": int(flips.sum()),
+                          "argmax_flips_outside_reference_near_ties": int((flips & ~tie).sum()), "reference_near_tie_pixels": int(tie.sum()),
+                          "max_abs_rba_err_on_64x128_grid": e_grid, "tolerance_rba": 1e-4,
+                          "k1_path": "fused x4 up-sample (product default)" if model.fused_upsample else "full-resolution planes"}
+        except Exception as e:                                           # informational only
+            print(f"[bench] parity leg skipped ({type(e).__name__}: {e})", file=sys.stderr)
 
     traffic = None
     import glob
@@ -883,12 +980,31 @@ def main():
             res["k1_fused_upsample_forms"] = k1_up4_forms
         if single is not None:
             res["single_stream_images_per_s"] = single["eager"] if "eager" in single else None
-            res["single_stream"] = {"images_per_s": single, "windows": single_windows, "protocol": "median of 3 windows", "what": "one image at a time on one stream through MaskFormer.rba_scores (fused x4 upsample + K1), "
+            res["single_stream"] = {"images_per_s": single, "windows": single_windows, "protocol": "median of 3 windows",
+                                    "model_default_policy": {"graph_replay": "auto", "measured": single_policy,
+                                                             "rule": "replay a shape iff host issue time >= 0.95 x GPU span of an eager forward (MaskFormer._graphed_scores)"},
+                                    "what": "one image at a time on one stream through MaskFormer.rba_scores (fused x4 upsample + K1), "
                                     "the caller reads every score back before issuing the next image"}
         if sustained is not None:
             res["sustained"] = sustained
+        for k_, v_ in extra_values.items():
+            res[k_] = v_
+        if extra_values:
+            res["extra_values_what"] = ("same step loop, streams, graphs and clock as `value`, run after it: value_up4 = K1 fused with the x4 up-sample (the "
+                                        "product's default path; `value` runs the HBM-bound full-resolution K1 the metric names), value_bf16x6 = every GEMM on "
+                                        "the full-range bf16x6 kernels (fp32's whole range; the arithmetic a NaN-scored image is re-scored in)")
+        if parity is not None:
+            res["parity_vs_reference_fixture"] = parity
+            if (args.arch, h, w) == ("swin_b_1dl", 1024, 2048):
+                res["argmax_flips_c2"] = parity["argmax_flips"]
         res["n_ranks_seen"] = n_ranks_seen
         res["dist_backend"] = backend_seen
+        if per_rank is not None:
+            ips = [args.steps * S / e for e, _ in per_rank]
+            res["per_rank"] = {"images_per_s": {"min": min(ips), "max": max(ips), "all": [round(v, 2) for v in ips]},
+                               "what": "each rank's own wall clock over the K timed steps (same barriers); `value` uses the slowest rank's",
+                               "cpu_affinity": {"cpus_per_rank": {"min": min(c for _, c in per_rank), "max": max(c for _, c in per_rank)},
+                                                "rank0": affinity}}
         if gemm is not None:
             res["roofline_gemm"] = gemm
         if exch_ms is not None:

@@ -32,6 +32,68 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist format) -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(index, sysfs="/sys/bus/pci/devices"):
+    """CPUs of the NUMA node the HIP device `index` hangs off: /sys/bus/pci/devices/<domain:bus:device.0>/local_cpulist of the device's PCI address
+    (torch.cuda.get_device_properties: pci_domain_id / pci_bus_id / pci_device_id).  None when the address or the sysfs entry is not there."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(os.path.join(sysfs, bdf, "local_cpulist")) as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except Exception:                                        # noqa: BLE001 -- placement is an optimisation
+        return None
+
+
+def plan_rank_cpus(local_rank, local_world, local_cpus_of, allowed):
+    """CPU set for the process of `local_rank`: the CPUs local to its GPU (local_cpus_of(rank) -> list | None) that this process may use (`allowed`), divided
+    evenly among the local ranks whose GPUs report the SAME set (8 GPUs on 2 sockets: four ranks share a socket, each gets a quarter of it, SMT siblings
+    included as the kernel numbers them).  Falls back to an even split of `allowed` by local rank.  -> (sorted cpu list, source string)"""
+    allowed = sorted(allowed)
+    mine = local_cpus_of(local_rank)
+    if mine:
+        mine = [c for c in mine if c in set(allowed)]
+    if mine:
+        peers = [r for r in range(local_world) if (local_cpus_of(r) or None) is not None and sorted(local_cpus_of(r)) == sorted(local_cpus_of(local_rank))]
+        k, n = peers.index(local_rank), len(peers)
+        share = mine[k * len(mine) // n:(k + 1) * len(mine) // n]
+        if share:
+            return share, f"sysfs local_cpulist of the GPU's PCI device, share {k + 1}/{n} of its NUMA node"
+    n = max(1, local_world)
+    share = allowed[local_rank * len(allowed) // n:(local_rank + 1) * len(allowed) // n] or allowed
+    return share, f"even split of the {len(allowed)} allowed CPUs by local rank (no NUMA information)"
+
+
+def bind_rank_to_gpu_numa(local_rank, local_world, set_torch_threads=True):
+    """One process per GPU: pin this process (and the threads it starts later: image decode, the CPU side of the launches) to the cores next to its GPU, so
+    that 8 ranks do not migrate across sockets or pile onto the same cores.  No-op for a single local rank or where
+    sched_setaffinity does not exist; RBA_NO_AFFINITY=1 switches it off.  Returns a small record for the bench line."""
+    rec = {"bound": False, "cpus": None, "source": None}
+    if local_world <= 1 or os.environ.get("RBA_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return rec
+    try:
+        allowed = os.sched_getaffinity(0)
+        cpus, source = plan_rank_cpus(local_rank, local_world, gpu_local_cpus if torch.cuda.is_available() else (lambda r: None), allowed)
+        os.sched_setaffinity(0, cpus)
+        if set_torch_threads:
+            torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+        rec.update(bound=True, cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1], source=source)
+    except Exception as e:                                   # noqa: BLE001
+        rec["source"] = f"not bound ({type(e).__name__}: {e})"
+    return rec
+
+
 def shard_indices(n_items: int, rank: int, world: int):
     """Image i -> rank i mod world (round-robin keeps shards balanced for any n)."""
     return list(range(rank, n_items, world))

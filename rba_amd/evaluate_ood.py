@@ -242,7 +242,10 @@ def _run_evaluations(model, dataset, model_name, dataset_name, args, rank=0, wor
     use_graphs = on_gpu and bool(int(getattr(args, "graph", 0)))
     prev_replay = getattr(model, "graph_replay", None)       # (the wrapper restores it, and the stream hint it set)
     if prev_replay is not None:
-        model.graph_replay = use_graphs                         # MaskFormer.rba_scores replays per (image shape, stream)
+        # MaskFormer.rba_scores replays per (image shape, stream).  Several streams fed by this one Python thread are launch-bound by construction (the thread
+        # issues S forwards per GPU-forward time): always replay.  One stream: the model's measured policy ("auto": replay only where the eager launches of
+        # the shape are launch-bound -- at 1024 x 2048 they are not, and eager is the faster path).
+        model.graph_replay = (True if n_streams > 1 else "auto") if use_graphs else False
     graphed = ({id(st_): GraphedScore(model, score_func, st_) for st_ in streams}
                if use_graphs and not args.store_anomaly_scores else None)
     scores, labels = [], []
@@ -389,12 +392,15 @@ def main(argv=None):
     from . import distributed as D
     from .datasets import available_datasets, get_dataset
     args = build_parser().parse_args(argv)
+    launch_local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_device:
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local = D.init_from_env(args.dist_backend or ("gloo" if args.share_device else None))
     device = torch.device(args.device, local) if args.device == "cuda" else torch.device(args.device)
     if device.type == "cuda":
         torch.cuda.set_device(device)
+    if world > 1:                    # one process per GPU: decode threads and the launch thread stay on the cores next to this rank's GPU
+        D.bind_rank_to_gpu_numa(launch_local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     names = args.selected_datasets if args.dataset_mode == "selective" else ["road_anomaly", "fishyscapes_laf"]
     if not names:
         raise ValueError("Selective Mode is chosen but number of selected datasets is 0")

@@ -42,7 +42,11 @@ class MaskFormer(nn.Module):
         self._mean3 = tuple(float(torch.tensor(v, dtype=torch.float32)) for v in a["pixel_mean"])      # fp32-rounded, as the buffers hold them
         self._std3 = tuple(float(torch.tensor(v, dtype=torch.float32)) for v in a["pixel_std"])
         self.fused_front_end = True
-        self.graph_replay = True        # rba_scores(): batch-1 forwards replayed from a per-shape hipGraph (opt out: False)
+        # rba_scores(): batch-1 forwards replayed from a per-shape hipGraph.  "auto" (default, round 6): per shape, only where the eager launches are MEASURED to be
+        # launch-bound (host issue time vs GPU span of an eager call, see _graphed_scores) -- at 1024 x 2048 the GPU is the bottleneck and eager is 4 % faster than
+        # replay on one stream (BENCH_r05: 124.7 vs 119.7 images/s), at 720 x 1280 / 9 layers and on small images replay wins.  True: always (the evaluator with
+        # several streams, tests); False: never.
+        self.graph_replay = "auto"
         self.fused_upsample = True      # K1 reads the low-res logits and up-samples on the fly (rba_reduce_up4)
         # panoptic inference (maskformer_model.py:202-220): off unless TEST.PANOPTIC_ON
         self.panoptic_on, self.open_panoptic = bool(a["panoptic_on"]), bool(a["open_panoptic"])
@@ -213,6 +217,26 @@ class MaskFormer(nn.Module):
     # ------------------------------------------------------------------ hipGraph replay of the scoring path
     GRAPH_MAX = 8            # live graphs per model (each keeps its own activation pool: ~1.5 GB at 1024 x 2048)
     GRAPH_THRASH_MAX = 4     # never-replayed graphs evicted before the model gives up capturing new keys
+    LAUNCH_BOUND_RATIO = 0.95      # graph_replay = "auto": capture a shape when host issue time >= this fraction of the GPU span of an eager forward
+    GRAPH_REMEASURE_EVERY = 32     # ... and measure a GPU-bound shape again after this many eager calls
+
+    def graph_decisions(self):
+        """graph_replay = "auto": {(image shape, dtype, return_argmax, score): {"decision": "eager" | "replay", "host_issue_ms", "gpu_span_ms"}} of the last
+        measurement of every shape met so far (bench.py reports it; tests assert on it)"""
+        return dict(self.__dict__.get("_graph_decisions", {}))
+
+    def _measured_eager(self, key, batched_inputs, return_argmax, score):
+        import time
+        dev = self.device
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(torch.cuda.current_stream(dev))
+        out = self._rba_scores_eager(batched_inputs, return_argmax, score)
+        e1.record(torch.cuda.current_stream(dev))
+        seen = self.__dict__.setdefault("_graph_seen", {})
+        if key in seen:
+            seen[key] = (time.perf_counter() - t0, e0, e1)
+        return out
 
     def _weights_version(self):
         v = 0
@@ -239,10 +263,11 @@ class MaskFormer(nn.Module):
         self.__dict__.pop("_graphs", None)
         self.__dict__.pop("_graph_seen", None)
         self.__dict__.pop("_graph_thrash", None)
+        self.__dict__.pop("_graph_probe", None)
 
     def __getstate__(self):
         st = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
-        for k in ("_graphs", "_graph_seen", "_graph_thrash"):       # hipGraphs cannot be copied or pickled; a copy captures its own
+        for k in ("_graphs", "_graph_seen", "_graph_thrash", "_graph_probe", "_graph_decisions"):       # hipGraphs / events cannot be copied or pickled; a copy captures its own
             st.pop(k, None)
         return st
 
@@ -252,7 +277,7 @@ class MaskFormer(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k not in ("_graphs", "_graph_seen", "_graph_thrash"):
+            if k not in ("_graphs", "_graph_seen", "_graph_thrash", "_graph_probe", "_graph_decisions"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
@@ -279,6 +304,28 @@ class MaskFormer(nn.Module):
                 while len(seen) > 4 * self.GRAPH_MAX:
                     seen.pop(next(iter(seen)))
                 return None
+            if self.graph_replay == "auto":
+                # measured policy (round 6).  Call 1 of a key ran eagerly (lazy initialisation); call 2 runs eagerly between two HIP events with the host's issue
+                # time taken beside them (rba_scores -> _measured_eager); call 3 reads the pair: the forward is LAUNCH-BOUND when the Python thread needed at
+                # least LAUNCH_BOUND_RATIO of the GPU's own span to issue it (a launch-bound GPU span stretches to the issue time, so the ratio saturates
+                # near 1) -- then, and only then, the shape is captured.  A GPU-bound shape stays eager and is measured again every GRAPH_REMEASURE_EVERY
+                # calls (the host may get busier: decode threads, other ranks).
+                st = seen[key]
+                if st is True or (isinstance(st, int) and st <= 0):
+                    self.__dict__["_graph_probe"] = key
+                    return None
+                if isinstance(st, int):
+                    seen[key] = st - 1
+                    return None
+                t_issue, e0, e1 = st
+                e1.synchronize()
+                t_gpu = e0.elapsed_time(e1) * 1e-3
+                bound = t_issue >= self.LAUNCH_BOUND_RATIO * t_gpu
+                self.__dict__.setdefault("_graph_decisions", {})[key[:2] + key[4:6]] = {
+                    "decision": "replay" if bound else "eager", "host_issue_ms": t_issue * 1e3, "gpu_span_ms": t_gpu * 1e3}
+                if not bound:
+                    seen[key] = self.GRAPH_REMEASURE_EVERY
+                    return None
             del seen[key]
             entry = "seen"
             while len(graphs) >= self.GRAPH_MAX:                # oldest first; a graph owns its pool, dropping it frees the memory
@@ -319,8 +366,9 @@ class MaskFormer(nn.Module):
     def rba_scores(self, batched_inputs, return_argmax=False, score="rba"):
         """Fast path: anomaly-score maps (and optional int32 argmax maps) without materialising sem_seg.
         score: "rba" (evaluate_ood.py:143-150), "energy" (:152-159) or "neg_logit_sum" (support.py:115-132).
-        Batch-1 calls on a HIP device are replayed from a captured hipGraph from the third call of an image shape on
-        (``model.graph_replay = False`` opts out; see _graphed_scores)."""
+        Batch-1 calls on a HIP device are replayed from a captured hipGraph -- with ``model.graph_replay = True`` from the third call of an image shape on, with
+        the default "auto" from the fourth call on and only for shapes whose eager launches are measured to be launch-bound (see _graphed_scores);
+        ``model.graph_replay = False`` opts out."""
         if (self.graph_replay and len(batched_inputs) == 1 and self.device.type == "cuda"
                 and not torch.cuda.is_current_stream_capturing()):
             image = batched_inputs[0]["image"]
@@ -331,6 +379,9 @@ class MaskFormer(nn.Module):
                 if r is not None:
                     return [r]
                 batched_inputs = [{"image": image}]
+                probe = self.__dict__.pop("_graph_probe", None)
+                if probe is not None:                          # graph_replay = "auto": this eager call is the one that is measured
+                    return self._measured_eager(probe, batched_inputs, return_argmax, score)
         return self._rba_scores_eager(batched_inputs, return_argmax, score)
 
     @torch.no_grad()

@@ -188,12 +188,14 @@ import numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from rba_amd import distributed as D
 from rba_amd.metrics import ood_metrics, select_labelled
-rank, world, _ = D.init_from_env("gloo")
+rank, world, local = D.init_from_env("gloo")
+aff = D.bind_rank_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))     # no GPU here: the even split of the allowed CPUs by local rank
+assert aff["bound"] and aff["cpus"] >= 1 and len(os.sched_getaffinity(0)) == aff["cpus"], aff
 rng = np.random.RandomState(0)
-n_img = 5
+n_img = int(sys.argv[2])
 gts = rng.choice([0, 1, 255], size=(n_img, 40, 50), p=[0.85, 0.05, 0.10])
 scores = (rng.randn(n_img, 40, 50) + 1.5 * (gts == 1)).astype(np.float32)
-mine = D.shard_indices(n_img, rank, world)                      # ragged: 3 + 2 images
+mine = D.shard_indices(n_img, rank, world)                      # ragged: 3 + 2 images (world 2), 2 + 2 + 2 + 1 x 5 (world 8)
 s, y = select_labelled(torch.from_numpy(scores[mine]), torch.from_numpy(gts[mine]))
 pooled = D.pooled_ood_metrics(s, y)
 hist = D.histogram_ood_metrics(s, y)
@@ -201,22 +203,55 @@ single = ood_metrics(*select_labelled(torch.from_numpy(scores), torch.from_numpy
 # order of pooling differs from the single-process concatenation but the metrics are rank statistics: identical
 ok = all(abs(pooled[k] - single[k]) < 1e-12 for k in single) and all(abs(hist[k] - single[k]) < 2e-3 for k in single)
 g = D.all_gather_variable(torch.arange(rank + 2, dtype=torch.float32))
-ok = ok and g.tolist() == [0.0, 1.0, 0.0, 1.0, 2.0]
-print(json.dumps({"rank": rank, "ok": bool(ok), "pooled": pooled, "single": single, "hist": hist}), flush=True)
+ok = ok and g.tolist() == [float(v) for r in range(world) for v in range(r + 2)]
+print(json.dumps({"rank": rank, "ok": bool(ok), "pooled": pooled, "single": single, "hist": hist, "affinity": aff}), flush=True)
 torch.distributed.destroy_process_group()
 sys.exit(0 if ok else 1)
 '''
 
 
-def test_metric_exchange_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world,n_img,port", [(2, 5, 29611), (8, 11, 29627)])
+def test_metric_exchange_gloo(tmp_path, world, n_img, port):
+    """the pooled-metric exchange of rba_amd.distributed (sizes all_gather + padded all_gather_into_tensor, histogram all_reduce) under torch.distributed.run
+    with 2 and with 8 ranks (gloo, CPU): ragged shards, pooled == single-process to 1e-12; every rank pins itself to its share of the CPUs first
+    (bind_rank_to_gpu_numa -- here the no-NUMA-information fallback)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), REPO],
-                       env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), REPO, str(n_img)],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count('"ok": true') == 2
+    assert r.stdout.count('"ok": true') == world
+
+
+def test_rank_cpu_placement_follows_the_gpus_numa_node(tmp_path):
+    """rba_amd.distributed.plan_rank_cpus / gpu_local_cpus / parse_cpulist: 8 GPUs on two sockets with SMT (GPU 0-3 -> node 0: CPUs 0-63,128-191; GPU 4-7 ->
+    node 1) -- every rank gets a quarter of ITS node, disjoint from every other rank's, inside the cgroup's allowed set; no NUMA information -> even split."""
+    from rba_amd import distributed as D
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and D.parse_cpulist("") == []
+    node = {0: D.parse_cpulist("0-63,128-191"), 1: D.parse_cpulist("64-127,192-255")}
+    local = lambda r: node[r // 4]
+    plans = [D.plan_rank_cpus(r, 8, local, range(256)) for r in range(8)]
+    sets = [set(p[0]) for p in plans]
+    assert all(len(s_) == 32 for s_ in sets) and len(set().union(*sets)) == 256
+    assert all(sets[r] <= set(node[r // 4]) for r in range(8)) and "share 2/4" in plans[1][1]
+    restricted = [D.plan_rank_cpus(r, 8, local, range(0, 96)) for r in range(8)]                 # a cgroup that only grants CPUs 0-95
+    assert all(set(p[0]) <= set(range(96)) and p[0] for p in restricted)
+    assert set(restricted[0][0]) <= set(node[0]) and set(restricted[5][0]) <= set(node[1])
+    none = [D.plan_rank_cpus(r, 4, lambda r_: None, range(8)) for r in range(4)]
+    assert [p[0] for p in none] == [[0, 1], [2, 3], [4, 5], [6, 7]] and "even split" in none[0][1]
+    # sysfs reader on a fake tree
+    class P:                                                                                          # noqa: N801
+        pci_domain_id, pci_bus_id, pci_device_id = 0, 0xC1, 0
+    d = tmp_path / "0000:c1:00.0"
+    d.mkdir()
+    (d / "local_cpulist").write_text("64-67\n")
+    import unittest.mock as um
+    with um.patch("torch.cuda.get_device_properties", return_value=P()):
+        assert D.gpu_local_cpus(0, sysfs=str(tmp_path)) == [64, 65, 66, 67]
+        assert D.gpu_local_cpus(0, sysfs=str(tmp_path / "missing")) is None
+    assert D.bind_rank_to_gpu_numa(0, 1)["bound"] is False                                            # a single local rank is left alone
 
 
 def test_bench_self_launch_refuses_without_devices():

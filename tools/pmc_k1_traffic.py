@@ -22,7 +22,7 @@ fetch, write = vals["FETCH_SIZE"] * 1024 * 2.0, vals["WRITE_SIZE"] * 1024
 alg = 4 * Q * HW + 4 * Q * K + 4 * HW
 out = {
     "kernel": "rba_reduce_pk_kernel<19,false,false,2,4,true> (rba_reduce_ws_f32, the product path)",
-    "workload": f"mask_pred N(0,25) [100,{H},{W}] fp32, cls_prob [100,19] (tools/k1_sweep.py 121{' --hw %d %d' % (H, W) if TAG else ''})", "round": 3,
+    "workload": f"mask_pred N(0,25) [100,{H},{W}] fp32, cls_prob [100,19] (tools/k1_sweep.py 121{' --hw %d %d' % (H, W) if TAG else ''})", "round": int(__import__("os").environ.get("RBA_ROUND", "6")),
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python tools/k1_sweep.py 121 (one counter per pass; tools/pmc_k1_traffic.sh)",
     "FETCH_SIZE_raw_KB": vals["FETCH_SIZE"], "WRITE_SIZE_raw_KB": vals["WRITE_SIZE"], "fetch_correction": 2.0,
     "fetch_correction_reason": "gfx950 rocprofv3: FETCH_SIZE = TCC_EA0_RDREQ x 64 B while wide coalesced reads are 128-B requests (MI355X_MICROARCH.md section HBM); WRITE_SIZE calibrates exactly (4*H*W bytes)",
