@@ -402,7 +402,7 @@ def main():
     torch.cuda.set_device(local)
     # one process per GPU: pin each rank to its share of the cores next to its GPU (rba_amd.distributed.bind_rank_to_gpu_numa) -- the launch thread of a rank
     # issues ~255 kernels per image and must not migrate across sockets or share cores with seven other ranks
-    affinity = D.bind_rank_to_gpu_numa(launch_local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else {"bound": False, "cpus": None, "source": None}
+    affinity = D.bind_rank_to_gpu_numa(launch_local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_of=(lambda r: 0) if share else None) if world > 1 else {"bound": False, "cpus": None, "source": None}
     dev = torch.device("cuda", local)
     dist = torch.distributed if (world > 1 or (args.rccl_one_rank and torch.distributed.is_initialized())) else None
     n_ranks_seen, backend_seen = 1, None

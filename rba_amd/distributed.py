@@ -75,16 +75,25 @@ def plan_rank_cpus(local_rank, local_world, local_cpus_of, allowed):
     return share, f"even split of the {len(allowed)} allowed CPUs by local rank (no NUMA information)"
 
 
-def bind_rank_to_gpu_numa(local_rank, local_world, set_torch_threads=True):
+def bind_rank_to_gpu_numa(local_rank, local_world, set_torch_threads=True, device_of=None):
     """One process per GPU: pin this process (and the threads it starts later: image decode, the CPU side of the launches) to the cores next to its GPU, so
     that 8 ranks do not migrate across sockets or pile onto the same cores.  No-op for a single local rank or where
-    sched_setaffinity does not exist; RBA_NO_AFFINITY=1 switches it off.  Returns a small record for the bench line."""
+    sched_setaffinity does not exist; RBA_NO_AFFINITY=1 switches it off.  device_of: local rank -> HIP device index (default: the rank itself; the share-device
+    plumbing tests map every rank to device 0).  Returns a small record for the bench line."""
     rec = {"bound": False, "cpus": None, "source": None}
     if local_world <= 1 or os.environ.get("RBA_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
         return rec
     try:
         allowed = os.sched_getaffinity(0)
-        cpus, source = plan_rank_cpus(local_rank, local_world, gpu_local_cpus if torch.cuda.is_available() else (lambda r: None), allowed)
+        dev_of = device_of or (lambda r: r)
+        cache = {}
+
+        def local_cpus(r):
+            d = dev_of(r)
+            if d not in cache:
+                cache[d] = gpu_local_cpus(d) if torch.cuda.is_available() and d < torch.cuda.device_count() else None
+            return cache[d]
+        cpus, source = plan_rank_cpus(local_rank, local_world, local_cpus, allowed)
         os.sched_setaffinity(0, cpus)
         if set_torch_threads:
             torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))

@@ -400,7 +400,7 @@ def main(argv=None):
     if device.type == "cuda":
         torch.cuda.set_device(device)
     if world > 1:                    # one process per GPU: decode threads and the launch thread stay on the cores next to this rank's GPU
-        D.bind_rank_to_gpu_numa(launch_local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        D.bind_rank_to_gpu_numa(launch_local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_of=(lambda r: 0) if args.share_device else None)
     names = args.selected_datasets if args.dataset_mode == "selective" else ["road_anomaly", "fishyscapes_laf"]
     if not names:
         raise ValueError("Selective Mode is chosen but number of selected datasets is 0")

