@@ -239,8 +239,13 @@ class MaskFormer(nn.Module):
         return out
 
     def _weights_version(self):
+        # the Parameter OBJECTS of a module tree are stable (load_state_dict copies in place, .to() swaps .data): walk the tree once, then sum the versions of a
+        # flat list -- the generator walk cost 0.3 ms per call, which a serial caller pays in front of every image's first launch (round 6)
+        flat = self.__dict__.get("_param_flat")
+        if flat is None:
+            flat = self.__dict__["_param_flat"] = list(self.parameters())
         v = 0
-        for p_ in self.parameters():
+        for p_ in flat:
             v += p_._version
         return v
 
@@ -264,10 +269,11 @@ class MaskFormer(nn.Module):
         self.__dict__.pop("_graph_seen", None)
         self.__dict__.pop("_graph_thrash", None)
         self.__dict__.pop("_graph_probe", None)
+        self.__dict__.pop("_graph_eager_fast", None)
 
     def __getstate__(self):
         st = dict(super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__)
-        for k in ("_graphs", "_graph_seen", "_graph_thrash", "_graph_probe", "_graph_decisions"):       # hipGraphs / events cannot be copied or pickled; a copy captures its own
+        for k in ("_graphs", "_graph_seen", "_graph_thrash", "_graph_probe", "_graph_decisions", "_graph_eager_fast", "_param_flat"):       # hipGraphs / events cannot be copied or pickled; a copy captures its own
             st.pop(k, None)
         return st
 
@@ -277,11 +283,12 @@ class MaskFormer(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k not in ("_graphs", "_graph_seen", "_graph_thrash", "_graph_probe", "_graph_decisions"):
+            if k not in ("_graphs", "_graph_seen", "_graph_thrash", "_graph_probe", "_graph_decisions", "_graph_eager_fast", "_param_flat"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
     def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_param_flat", None)
         self.drop_graphs(release_constants=True)   # .to() / .cuda() / .float(): every captured graph holds the old parameter addresses
         return super()._apply(fn, *args, **kwargs)
 
@@ -324,7 +331,12 @@ class MaskFormer(nn.Module):
                 self.__dict__.setdefault("_graph_decisions", {})[key[:2] + key[4:6]] = {
                     "decision": "replay" if bound else "eager", "host_issue_ms": t_issue * 1e3, "gpu_span_ms": t_gpu * 1e3}
                 if not bound:
-                    seen[key] = self.GRAPH_REMEASURE_EVERY
+                    seen[key] = 0                                   # the next slow-path call of this key is a measurement again ...
+                    fast = self.__dict__.setdefault("_graph_eager_fast", {})
+                    while len(fast) > 4 * self.GRAPH_MAX:
+                        fast.pop(next(iter(fast)))
+                    # ... and rba_scores serves the next GRAPH_REMEASURE_EVERY calls of the shape eagerly before it asks again
+                    fast[(key[0], key[1], key[4], key[5], key[8], key[3])] = self.GRAPH_REMEASURE_EVERY
                     return None
             del seen[key]
             entry = "seen"
@@ -375,6 +387,16 @@ class MaskFormer(nn.Module):
             if torch.is_tensor(image) and image.dim() == 3 and image.dtype in (torch.uint8, torch.float32) \
                     and set(batched_inputs[0]) <= {"image"}:
                 image = to_device(image, self.device).contiguous()
+                if self.graph_replay == "auto":
+                    # a shape measured to be GPU-bound stays eager for GRAPH_REMEASURE_EVERY calls without even building the graph key (the key walks every
+                    # parameter's version: host time in front of the image's first launch, which the serial caller pays in full).  A stale entry costs
+                    # speed only -- eager launches are always right.
+                    fast = self.__dict__.setdefault("_graph_eager_fast", {})
+                    fk = (tuple(image.shape), image.dtype, bool(return_argmax), score, ops.SPLIT_MODE, torch.cuda.current_stream(image.device).cuda_stream)
+                    left = fast.get(fk, 0)
+                    if left > 0:
+                        fast[fk] = left - 1
+                        return self._rba_scores_eager([{"image": image}], return_argmax, score)
                 r = self._graphed_scores(image, return_argmax, score)
                 if r is not None:
                     return [r]

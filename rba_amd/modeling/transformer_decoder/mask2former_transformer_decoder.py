@@ -28,9 +28,10 @@ def _qlinear(x, weight, bias=None, relu=False, x_add=None):
     a2 = None if x_add is None else x_add.contiguous().view(M, K)
     if M <= 128:
         return ops.skinny_linear(x2, weight, bias, relu, x_add=a2).view(tuple(x.shape[:-1]) + (weight.shape[0],))
+    # more than 128 rows (a batch of B >= 2 images): 128-row blocks, every launch writing ITS rows of the one output tensor (no per-block allocation + copy)
     out = torch.empty((M, weight.shape[0]), dtype=torch.float32, device=x.device)
     for r0 in range(0, M, 128):
-        out[r0:r0 + 128] = ops.skinny_linear(x2[r0:r0 + 128], weight, bias, relu, x_add=None if a2 is None else a2[r0:r0 + 128])
+        ops.skinny_linear(x2[r0:r0 + 128], weight, bias, relu, x_add=None if a2 is None else a2[r0:r0 + 128], out=out[r0:r0 + 128])
     return out.view(tuple(x.shape[:-1]) + (weight.shape[0],))
 
 
@@ -187,6 +188,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # inference-only shortcut, exact: intermediate heads evaluate mask logits only where the attention mask samples them
         # (aux_outputs then carry pred_logits only)
         self.sparse_intermediate_heads = True
+        self.cache_initial_heads = True          # the heads of the un-decoded queries are constants of the checkpoint (_initial_query_side)
         self._plan_cache = ShapeCache(8)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
@@ -216,15 +218,39 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         plan = self._plan_cache.get(key, build)
         return None if plan is False else plan
 
+    def _query_side_heads(self, output):
+        """decoder_norm -> class_embed, mask_embed MLP on the query tensor [B,Q,C] (reference :473-476): (class logits [B,Q,K+1], mask embedding [B,Q,md])"""
+        dec = ops.add_layer_norm(output.contiguous(), self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)[1]
+        return _qlinear(dec, self.class_embed.weight, self.class_embed.bias), self.mask_embed(dec).contiguous()
+
+    def _initial_query_side(self, B, device):
+        """The prediction heads BEFORE the first layer (reference :427-430) see `query_feat.weight` -- learnt parameters, not the image: decoder_norm, class_embed
+        and the three mask_embed Linears of that call are constants of the checkpoint.  Computed once per (weights version, batch size) with the same kernels
+        (bit-identical to evaluating them per image) and kept: five launches and the query tensor's expand + copy less per image (round 6)."""
+        ps = [self.query_feat.weight, self.decoder_norm.weight, self.decoder_norm.bias, self.class_embed.weight, self.class_embed.bias]
+        for ly in self.mask_embed.layers:
+            ps += [ly.weight, ly.bias]
+        key = (B, device, tuple((p_.data_ptr(), p_._version) for p_ in ps))
+        c = self.__dict__.get("_rba_heads0")
+        if c is None or c[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None                                           # never build a cache entry inside a capture: evaluate in line instead
+            output = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
+            side = self._query_side_heads(output)
+            torch.cuda.current_stream(device).synchronize()          # once per checkpoint: forwards on OTHER streams read these tensors without an event
+            c = self.__dict__["_rba_heads0"] = (key, output, side)
+        return c[1], c[2]
+
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, need_attn_mask=True, need_masks=True,
-                                 gathered=None):
+                                 gathered=None, query_side=None):
         """output [B,Q,C] -> class logits [B,Q,K+1], mask logits [B,Q,H/4,W/4] (None unless need_masks), attention-mask
         logits [B,Q,h*w] (reference :472-489; the threshold itself happens inside K3).  When only the attention mask is
         consumed (every call but the last) the mask logits are evaluated just at the 2x2 source pixels each attention
         cell interpolates -- the same arithmetic on 4*h*w instead of H*W/16 columns."""
-        dec = ops.add_layer_norm(output.contiguous(), self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)[1]
-        outputs_class = _qlinear(dec, self.class_embed.weight, self.class_embed.bias)
-        mask_embed = self.mask_embed(dec).contiguous()
+        if query_side is not None:
+            outputs_class, mask_embed = query_side
+        else:
+            outputs_class, mask_embed = self._query_side_heads(output)
         plan = None
         if need_attn_mask and not need_masks and self.sparse_intermediate_heads:
             plan = self._sparse_plan(mask_features.shape[-2:], attn_mask_target_size, mask_features.device)
@@ -265,12 +291,16 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             tok = t.reshape(B, -1, x[i].shape[1]) if t.is_contiguous() else x[i].flatten(2).transpose(1, 2)
             src.append(tok + self.level_embed.weight[i])                                      # [B,S,C] contiguous (:424-426)
         query_embed = self.query_embed.weight[None].expand(B, -1, -1)
-        output = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
+        first = self._initial_query_side(B, mask_features.device) if self.cache_initial_heads else None
+        if first is not None:
+            output, side0 = first                                     # constants of the checkpoint (never written: every layer returns new tensors)
+        else:
+            output, side0 = self.query_feat.weight[None].expand(B, -1, -1).contiguous(), None
         mask_features = mask_features.contiguous()
         predictions_class, predictions_mask = [], []
         gathered = {}
         cls, msk, attn_logits = self.forward_prediction_heads(output, mask_features, size_list[0], self.num_layers > 0,
-                                                              need_masks=self.num_layers == 0, gathered=gathered)
+                                                              need_masks=self.num_layers == 0, gathered=gathered, query_side=side0)
         predictions_class.append(cls)
         predictions_mask.append(msk)
         for i in range(self.num_layers):

@@ -507,11 +507,12 @@ def merge_layer_norm(x, H, W, weight, bias, eps=1e-5):
 
 
 @_hip_op
-def skinny_linear(x, weight, bias=None, relu=False, x_add=None, add_cols=None, segments=1):
+def skinny_linear(x, weight, bias=None, relu=False, x_add=None, add_cols=None, segments=1, out=None):
     """F.linear(x, weight, bias) [+ ReLU] for x with at most 128 rows (the decoder's 100 queries): [..., K] -> [..., N].
     x_add: output columns n < add_cols (default: all; a multiple of 16) are computed from ``x + x_add`` -- the query position embedding of
     mask2former_transformer_decoder.py:48-58, 106-118 added inside the projection.  segments = s > 1: the N outputs are returned as s
-    separately contiguous tensors [..., N / s] (q, k, v of a stacked in_proj weight) written by the one launch."""
+    separately contiguous tensors [..., N / s] (q, k, v of a stacked in_proj weight) written by the one launch.
+    out (segments = 1 only): a caller-owned contiguous fp32 [..., N] tensor (e.g. a row slice of a larger one) the launch writes instead of a new tensor."""
     lib = _lib.load()
     _chk(x, "x")
     _chk(weight, "weight", dim=2)
@@ -527,8 +528,13 @@ def skinny_linear(x, weight, bias=None, relu=False, x_add=None, add_cols=None, s
     segments = int(segments)
     if segments < 1 or N % segments:
         raise RbaHipError("segments must divide N")
+    if out is not None:
+        _chk(out, "out")
+        if segments != 1 or tuple(out.shape) != tuple(x.shape[:-1]) + (N,):
+            raise RbaHipError("out must be a contiguous fp32 [..., N] tensor with x's leading shape (segments = 1)")
     if x_add is None and segments == 1:
-        out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
         _lib.check(lib.rba_skinny_linear_f32(_p(x), _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), _stream()),
                    "rba_skinny_linear_f32")
         return out
@@ -540,6 +546,10 @@ def skinny_linear(x, weight, bias=None, relu=False, x_add=None, add_cols=None, s
     if add_cols % 16 or not 0 <= add_cols <= N:
         raise RbaHipError("add_cols must be a multiple of 16 in [0, N]")
     seg_n = N // segments
+    if out is not None:
+        _lib.check(lib.rba_skinny_linear_add_f32(_p(x), _p(x_add), add_cols, _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)), 0, _stream()),
+                   "rba_skinny_linear_add_f32")
+        return out
     out = torch.empty((segments,) + tuple(x.shape[:-1]) + (seg_n,), dtype=torch.float32, device=x.device)
     _lib.check(lib.rba_skinny_linear_add_f32(_p(x), _p(x_add), add_cols, _p(weight), _p(bias), _p(out), M, N, K, int(bool(relu)),
                                              seg_n if segments > 1 else 0, _stream()), "rba_skinny_linear_add_f32")

@@ -608,6 +608,9 @@ def test_skinny_linear(ops, M, N, K, relu, has_bias, knobs):
     assert out.shape == (M, N) and maxerr(out, ref) < 2e-5 * (K / 256) ** 0.5 + 2e-6
     out3 = ops.skinny_linear(dev(x.view(1, M, K)), dev(w), dev(b) if has_bias else None, relu)
     assert out3.shape == (1, M, N) and torch.equal(out3[0], out)
+    big = torch.full((M + 5, N), -7.0, device="cuda")                          # out=: the launch fills a row slice of a caller-owned tensor and nothing else
+    got = ops.skinny_linear(dev(x), dev(w), dev(b) if has_bias else None, relu, out=big[2:2 + M])
+    assert got.data_ptr() == big[2:].data_ptr() and torch.equal(big[2:2 + M], out) and bool((big[:2] == -7).all()) and bool((big[2 + M:] == -7).all())
     # round 3: the per-row-tile decomposition (default) assigns and reduces the k blocks exactly as the round 1-2 kernel: bit-identical
     import ctypes
     from rba_amd import _lib

@@ -383,6 +383,34 @@ def test_sparse_intermediate_heads_are_exact(name):
     assert torch.equal(cls_s, cls_d) and torch.equal(msk_s, msk_d)
 
 
+@pytest.mark.parametrize("name", ["tiny1", "tiny3"])
+def test_cached_initial_heads_are_exact_and_follow_the_weights(name):
+    """round 6: the prediction heads of the un-decoded queries (reference :427-430) see only learnt parameters -- decoder_norm, class_embed and mask_embed of that
+    call are computed once per checkpoint.  Same bits as evaluating them per image (batch 1 and 2, aux pred_logits included); a weight update invalidates the
+    cache."""
+    model, a, _ = build(name, 1)
+    g = torch.Generator().manual_seed(6)
+    images = [{"image": torch.randint(0, 256, (3, 60, 90), generator=g, dtype=torch.uint8)} for _ in range(2)]
+    pred = model.sem_seg_head.predictor
+    assert pred.cache_initial_heads
+    for batch in (images[:1], images):
+        cls_c, msk_c, _, _ = model.predict(batch)
+        cls_c2, msk_c2, _, _ = model.predict(batch)                    # second call: served from the cache
+        pred.cache_initial_heads = False
+        cls_p, msk_p, _, _ = model.predict(batch)
+        pred.cache_initial_heads = True
+        assert torch.equal(cls_c, cls_p) and torch.equal(msk_c, msk_p) and torch.equal(cls_c2, cls_p) and torch.equal(msk_c2, msk_p)
+    feats = model.backbone(model.preprocess(images[:1])[0])
+    mf, _, ms = model.sem_seg_head.pixel_decoder.forward_features(feats)
+    aux_c = pred(ms, mf)["aux_outputs"][0]["pred_logits"]
+    with torch.no_grad():
+        pred.query_feat.weight.mul_(1.5)                              # in-place update: parameter version changes -> recomputed
+    aux_new = pred(ms, mf)["aux_outputs"][0]["pred_logits"]
+    pred.cache_initial_heads = False
+    aux_plain = pred(ms, mf)["aux_outputs"][0]["pred_logits"]
+    assert torch.equal(aux_new, aux_plain) and not torch.equal(aux_new, aux_c)
+
+
 def test_batch_of_different_sizes_and_float_input(golden):
     """ImageList semantics (maskformer_model.py:255-257): each image is normalised, then zero-padded bottom/right to the
     common size (multiple of 32); every image's outputs are cropped back to its own size.  NOTE: padding an image to a
