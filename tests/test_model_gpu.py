@@ -1035,4 +1035,8 @@ def test_graph_replay_policy_is_measured():
     for _ in range(5):
         assert torch.equal(fresh.rba_scores([{"image": im}])[0], want)
     (dec,) = fresh.graph_decisions().values()
-    assert dec["decision"] == "replay" and fresh.live_graphs() == 1, dec
+    # ~300 launches of a few microseconds each: launch-bound on every host seen so far (ratio 0.98-1.0) -- but the DECISION is a measurement, so the test holds the
+    # model to its own reading rather than to a timing: a graph exists exactly when the measured ratio said launch-bound
+    assert dec["host_issue_ms"] > 0 and dec["gpu_span_ms"] > 0
+    assert fresh.live_graphs() == (1 if dec["decision"] == "replay" else 0), dec
+    assert (dec["decision"] == "replay") == (dec["host_issue_ms"] >= fresh.LAUNCH_BOUND_RATIO * dec["gpu_span_ms"]), dec
