@@ -173,7 +173,8 @@ int rba_merge_layer_norm_f32(const float* x, const float* gamma, const float* be
                              void* stream);
 
 /* Skinny linear layer: out[m,n] = act(sum_k x[m,k] * weight[n,k] + bias[n]), x [M,K] with M <= 128, weight [N,K]
- * (nn.Linear layout), bias [N] or NULL, relu != 0 applies max(.,0).  K % 32 == 0.  For the decoder's 100-query GEMMs
+ * (nn.Linear layout), bias [N] or NULL, relu != 0 applies torch.relu exactly (NaN stays NaN -- the f16x3 kernels' loud answer to an out-of-range
+ * operand must reach the score map --, +inf stays +inf, -inf becomes 0; every ReLU of this library: csrc/common.h rba_relu).  K % 32 == 0.  For the decoder's 100-query GEMMs
  * (mask2former_transformer_decoder.py:25-212). */
 int rba_skinny_linear_f32(const float* x, const float* weight, const float* bias, float* out, int M, int N, int K,
                           int relu, void* stream);

@@ -168,7 +168,9 @@ class PatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
 
     def forward(self, x):
-        """[B,3,H,W] -> tokens [B, Wh*Ww, C], Wh, Ww (swin.py:479-495)."""
+        """[B,3,H,W] -> tokens [B, Wh*Ww, C], Wh, Ww (swin.py:479-495).  Any memory layout (channels_last, sliced batches: the gather below copies).  Arithmetic of this
+        un-fused front end = the token Linears' (ops.SPLIT_MODE): f16x3 by default, i.e. fp32-GEMM accuracy for |x| < 65504 and NaN -- never a wrong number -- beyond;
+        normalised pixels are |x| < 3, and `ops.split_mode("bf16x6")` gives the full fp32 range (test_fused_front_end_matches_library_path holds both paths equal)."""
         ps = self.patch_size
         _, _, H, W = x.shape
         if W % ps or H % ps:
