@@ -720,13 +720,21 @@ def main():
         del k1_events[n0:]
         return world * n_steps * S / float(tt.item())
 
-    if part_graphs is not None and not os.environ.get("RBA_BENCH_NO_EXTRA_LEGS"):
+    def all_ranks(flag):
+        """a leg runs on every rank or on none: its barriers and all_reduces are collective (a capture that failed on ONE rank must not leave the others waiting)"""
+        if dist is None:
+            return bool(flag)
+        f = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev if backend_seen == "nccl" else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    if all_ranks(part_graphs is not None and not os.environ.get("RBA_BENCH_NO_EXTRA_LEGS")):
         default_graphs = part_graphs
         try:
             if args.k1 == "fullres":
                 k1_mode["v"] = "up4"
                 part_graphs = capture_parts()
-                if part_graphs is not None:
+                if all_ranks(part_graphs is not None):
                     extra_values["value_up4"] = timed_leg(args.steps)
                 k1_mode["v"] = args.k1
             if ops.SPLIT_MODE == "f16x3":
@@ -734,7 +742,7 @@ def main():
                     forward_once(record=False)                              # packs the bf16 weight planes
                     torch.cuda.synchronize()
                     part_graphs = capture_parts()
-                    if part_graphs is not None:
+                    if all_ranks(part_graphs is not None):
                         extra_values["value_bf16x6"] = timed_leg(max(5, min(args.steps, 20)))
         except Exception as e:                                              # informational only
             print(f"[bench] extra legs skipped ({type(e).__name__}: {e})", file=sys.stderr)
