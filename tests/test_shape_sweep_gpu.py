@@ -55,6 +55,13 @@ WIDE_ARCHS = {
 }
 WIDE_SIZES = [(352, 1216), (192, 672), (256, 736), (128, 768), (376, 1241), (60, 90), (333, 777), (363, 637)]      # (the CPU oracle is the cost: seconds per size)
 
+# RBA_SWEEP_EXTRA_WIDE=N: N more seeded random sizes (up to 800 x 1600: the CPU oracle at the released widths takes seconds per size) for test_size_sweep_real_widths
+WIDE_EXTRA_SIZES = []
+while len(WIDE_EXTRA_SIZES) < int(_os.environ.get("RBA_SWEEP_EXTRA_WIDE", "0")):
+    _hw = (_rnd.randint(33, 800), _rnd.randint(33, 1600))
+    if _hw not in WIDE_SIZES and _hw not in WIDE_EXTRA_SIZES:
+        WIDE_EXTRA_SIZES.append(_hw)
+
 _MODELS = {}
 
 
@@ -261,7 +268,7 @@ def test_size_sweep_tiny(name, h, w):
 
 
 @pytest.mark.parametrize("name", ["wide_b", "wide_l"])
-@pytest.mark.parametrize("h,w", WIDE_SIZES)
+@pytest.mark.parametrize("h,w", WIDE_SIZES + WIDE_EXTRA_SIZES)
 def test_size_sweep_real_widths(name, h, w):
     """the released channel widths (shallow depths): the sizes at which the wide kernels change launch form; bf16x6 on the 128 * odd sizes"""
     configs = ALL_CONFIGS if (h, w) in ODD_TILE_SIZES else ALL_CONFIGS[:2]
